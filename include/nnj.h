@@ -1,0 +1,161 @@
+/*
+ * nnj.h -- C ABI of the MI355X-native NeuralNJ hot path (libnnj_hip.so).
+ *
+ * Drop-in boundary for the Argmax inference path of DingShizhe/NeuralNJ: the
+ * axial-attention MSA encoder plus the iterative neural neighbour-joining loop.
+ * Every entry point names the reference interface it replaces (file:line are
+ * relative to the reference repository).  Plain pointers and sizes only; no
+ * torch types.  All entry points return 0 on success or a negative nnj_status;
+ * nnj_last_error() gives a message.  No C++ exception crosses this boundary and
+ * nothing here calls exit().
+ *
+ * Memory: every `dev` pointer is HIP device memory on the handle's device; every
+ * `host` pointer is ordinary host memory.  The library allocates only at
+ * nnj_create / nnj_load_weights; all scratch comes from the caller-provided
+ * workspace (size it with nnj_workspace_bytes).  Launches are asynchronous on
+ * the `stream` argument (a hipStream_t passed as void*; NULL = default stream);
+ * there is no hidden synchronisation.
+ *
+ * Layouts (row-major, last index fastest):
+ *   codes   uint8  [B,T,L]     site code: 0..3 = A,C,G,T one-hot, 4 = gap/N =
+ *                              [1,1,1,1], 5 = padding = [0,0,0,0]
+ *                              (lossless form of reference phydata.py:38-46,57-77)
+ *   onehot  float  [B,T,L,V]   the reference's own input (V = vocab_size)
+ *   mask    uint8  [B,L]       1 = padded site (reference finetune_rl_search.py:93)
+ *   state   float  [B,n,C,D]   row embeddings, C = L / patch_size
+ *   logits  float  [B,P(n)]    P(n) = n(n-1)/2, pair order = itertools.combinations
+ *                              = torch.triu_indices(n,n,1) order
+ *                              (reference environment.py:457-462, model.py:176)
+ *   merges  int32  [B,T-1,2]   chosen (i,j), i<j, row indices at that step
+ */
+#ifndef NNJ_H
+#define NNJ_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NNJ_ABI_VERSION 1
+
+typedef enum nnj_status {
+  NNJ_OK = 0,
+  NNJ_ERR_ARG = -1,         /* bad argument (null pointer, bad size)          */
+  NNJ_ERR_UNSUPPORTED = -2, /* model/config shape the HIP kernels do not cover */
+  NNJ_ERR_NO_WEIGHTS = -3,  /* compute call before nnj_load_weights           */
+  NNJ_ERR_WORKSPACE = -4,   /* workspace too small                            */
+  NNJ_ERR_HIP = -5,         /* a HIP runtime call failed                      */
+  NNJ_ERR_NO_DEVICE = -6    /* no usable gfx950 device                        */
+} nnj_status;
+
+/* Mirrors cfgs.model.* read by PhyloATTN.__init__ (reference model.py:15-22). */
+typedef struct nnj_config {
+  int32_t vocab_size;  /* cfgs.model.vocab_size   (4)                      */
+  int32_t patch_size;  /* cfgs.model.patch_size   (1 in the shipped yaml)  */
+  int32_t embed_dim;   /* cfgs.model.embed_dim    (64)                     */
+  int32_t num_heads;   /* cfgs.model.num_enc_heads (8)                     */
+  int32_t num_layers;  /* cfgs.model.num_enc_layers (6)                    */
+  int32_t device;      /* HIP device ordinal                               */
+} nnj_config;
+
+typedef struct nnj_handle nnj_handle;
+
+int nnj_abi_version(void);
+
+/* PhyloATTN(cfgs).to(device) -- reference model.py:11-60, finetune_rl_search.py:482. */
+int nnj_create(const nnj_config* cfg, nnj_handle** out);
+int nnj_destroy(nnj_handle* h);
+/* Message for the last failing call on this handle (h == NULL: last nnj_create). */
+const char* nnj_last_error(const nnj_handle* h);
+
+/* Number of fp32 parameters of the packed vector for this config. */
+int nnj_num_params(const nnj_config* cfg, size_t* n);
+
+/* load_state_dict(checkpoint['model_state_dict']) -- reference
+ * finetune_rl_search.py:481-484.  `packed_host` is the concatenation of the 172
+ * state_dict tensors in state_dict order. Synchronous. */
+int nnj_load_weights(nnj_handle* h, const float* packed_host, size_t n);
+
+/* Scratch bytes needed by any entry point below for shapes up to (B,T,L). */
+int nnj_workspace_bytes(const nnj_handle* h, int32_t B, int32_t T, int32_t L, size_t* bytes);
+
+/* PhyloATTN.encode_zxr -- reference model.py:67-88 (+ msa_modules.py:62-151,
+ * axial_attention.py:6-255).  Exactly one of codes_dev / onehot_dev is non-NULL. */
+int nnj_encode(nnj_handle* h, const uint8_t* codes_dev, const float* onehot_dev,
+               const uint8_t* mask_dev, float* state_out_dev,
+               int32_t B, int32_t T, int32_t L,
+               void* ws_dev, size_t ws_bytes, void* stream);
+
+/* PhyloATTN.decode_zxr with logits_prev=None -- reference model.py:168-181
+ * (decode_gg 90-99, aggregate 102-155): scores of all P(n) pairs. */
+int nnj_pair_scores_full(nnj_handle* h, const float* state_dev, const uint8_t* mask_dev,
+                         float* logits_out_dev, int32_t B, int32_t n, int32_t L,
+                         void* ws_dev, size_t ws_bytes, void* stream);
+
+/* PhyloATTN.decode_zxr with logits_prev given -- reference model.py:184-201
+ * together with utils.get_score_indices_to_prev (utils.py:213-251): scores the n
+ * pairs (i_prev, r), then assembles the P(n) table from logits_prev [B,P(n+1)] by
+ * the old->new index map computed on the device from ij_prev [B,2]. */
+int nnj_pair_scores_incr(nnj_handle* h, const float* state_dev, const uint8_t* mask_dev,
+                         const int32_t* ij_prev_dev, const float* logits_prev_dev,
+                         float* logits_out_dev, int32_t B, int32_t n, int32_t L,
+                         void* ws_dev, size_t ws_bytes, void* stream);
+
+/* utils.get_score_indices_to_prev alone -- reference utils.py:213-251:
+ * idx_out int64 [B,P(n)] indexes cat(logits_prev[P(n+1)], new_scores[n]). */
+int nnj_score_index_map(nnj_handle* h, const int32_t* ij_prev_dev, int64_t* idx_out_dev,
+                        int32_t B, int32_t n, void* stream);
+
+/* PhyloATTN.aggregate(x_i, x_j, (ii,jj), batchwise_ij_indices=True) as called from
+ * PhyInferEnv.step -- reference environment.py:822-831, model.py:102-155.  Rows
+ * ij_dev[b] = (i,j) of state [B,n,C,D] are merged with the other n-2 rows as
+ * context; writes one row per batch element: out [B,1,C,D]. */
+int nnj_aggregate(nnj_handle* h, const float* state_dev, const int32_t* ij_dev,
+                  float* out_row_dev, int32_t B, int32_t n, int32_t L,
+                  void* ws_dev, size_t ws_bytes, void* stream);
+
+/* Tensor half of PhyInferEnv.step -- reference environment.py:760-835: aggregate
+ * rows (i,j), put the merged row in slot i, drop slot j, shift later rows down.
+ * state_out [B,n-1,C,D] must not alias state. */
+int nnj_env_step(nnj_handle* h, const float* state_dev, const int32_t* ij_dev,
+                 float* state_out_dev, int32_t B, int32_t n, int32_t L,
+                 void* ws_dev, size_t ws_bytes, void* stream);
+
+/* argmax(logits,-1) and flat index -> (i,j) -- reference
+ * finetune_rl_search.py:145,159-160 (first maximal index wins).
+ * ij_out int32 [B,2]; top2_gap_out float [B] may be NULL. */
+int nnj_select_pair(nnj_handle* h, const float* logits_dev, int32_t* ij_out_dev,
+                    float* top2_gap_out_dev, int32_t B, int32_t n, void* stream);
+
+/* The whole eval+argmax branch of reinforce_rollout -- reference
+ * finetune_rl_search.py:78-189 -- resident on the device with no host sync:
+ * encode, then T-1 x (score new pairs, assemble table, argmax, merge).
+ *   forced_merges_dev : NULL, or int32 [B,T-1,2] merges to apply instead of the
+ *                       argmax (teacher forcing for parity tests)
+ *   merges_out_dev    : int32 [B,T-1,2] the argmax pair of every step
+ *   logits_trace_dev  : NULL, or float [B, sum_{n=T..2} P(n)] per-step tables
+ *   top2_gap_dev      : NULL, or float [B,T-1]
+ *   state_out_dev     : NULL, or float [B,T,C,D] encoder output */
+int nnj_rollout_argmax(nnj_handle* h, const uint8_t* codes_dev, const uint8_t* mask_dev,
+                       int32_t B, int32_t T, int32_t L,
+                       const int32_t* forced_merges_dev, int32_t* merges_out_dev,
+                       float* logits_trace_dev, float* top2_gap_dev, float* state_out_dev,
+                       void* ws_dev, size_t ws_bytes, void* stream);
+
+/* Kernel timing for bench.py's roofline object: when enabled, the entry points
+ * bracket their kernel groups with HIP events on the launch stream; after the
+ * caller has synchronised the stream, nnj_profile_read returns accumulated
+ * milliseconds and launch counts per group and resets them.
+ * groups: 0 = encoder, 1 = step-0 pair scorer, 2 = NJ step (new-pair scorer +
+ * merged-row aggregate), 3 = table assemble + argmax + bookkeeping. */
+#define NNJ_PROFILE_GROUPS 4
+int nnj_profile_enable(nnj_handle* h, int32_t on);
+int nnj_profile_read(nnj_handle* h, double ms_out[NNJ_PROFILE_GROUPS],
+                     int64_t launches_out[NNJ_PROFILE_GROUPS]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NNJ_H */

@@ -1,0 +1,275 @@
+#!/usr/bin/env python3
+"""Generate golden vectors for the NeuralNJ Argmax hot path from the REFERENCE itself.
+
+Runs ONLY in the build container (needs /root/reference, read-only).  It imports the
+reference's own model.py / environment.py / utils.py / finetune_rl_search.py and runs
+`reinforce_rollout(eval=True, argmax=True, branch_optimize=False)` unmodified
+(reference finetune_rl_search.py:78-189), recording what that code computes.  Nothing
+of the reference is copied: the outputs below are numeric vectors and result strings.
+
+Third-party packages the reference imports at module import time but never calls on
+this path (raxmlpy's native binding, fvcore, ete3, dendropy, Bio, tensorboard) are
+absent from this image; inert placeholder modules are registered in `sys.modules` so
+the imports succeed.  None of their functions is executed on the Argmax path (a call
+raises).  `fvcore`'s CfgNode is only an attribute container here.
+
+Weights are NOT stored: they come from neuralnj_amd.weights.seeded_state (numpy
+Philox) and are pushed into the reference model with load_state_dict(strict=True);
+the fixture stores their sha256 so drift is detected.
+
+Usage:  python tests/golden/gen_golden.py [--only NAME]
+Output: tests/golden/<case>.npz
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import sys
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.path.insert(0, REPO)
+
+
+def _install_placeholders():
+    def _never(*a, **k):
+        raise RuntimeError("placeholder for an absent third-party function was called")
+
+    def mod(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+        return m
+
+    class CfgNode(dict):
+        def __getattr__(self, k):
+            try:
+                return self[k]
+            except KeyError as e:
+                raise AttributeError(k) from e
+
+        def __setattr__(self, k, v):
+            self[k] = v
+
+    mod("raxmlpy.cpp_binding", optimize_brlen=_never, compute_llh=_never, test_func=_never)
+    mod("fvcore")
+    mod("fvcore.common")
+    mod("fvcore.common.config", CfgNode=CfgNode)
+    mod("ete3", Tree=_never)
+    mod("dendropy")
+    bio = mod("Bio")
+    phylo = mod("Bio.Phylo", read=_never)
+    bt = mod("Bio.Phylo.BaseTree", Clade=type("Clade", (), {}))
+    bio.Phylo = phylo
+    phylo.BaseTree = bt
+    try:
+        import torch.utils.tensorboard  # noqa: F401
+    except Exception:
+        mod("torch.utils.tensorboard", SummaryWriter=_never)
+    sys.path.insert(0, os.path.join(REF, "RAxMLpy"))
+    sys.path.insert(0, REF)
+
+
+def make_cfg(utils_mod, layers=6):
+    cfgs = utils_mod.empty_config()
+    cfgs.model.vocab_size = 4
+    cfgs.model.patch_size = 1
+    cfgs.model.embed_dim = 64
+    cfgs.model.num_enc_heads = 8
+    cfgs.model.num_enc_layers = layers
+    cfgs.env.batch_size = 1
+    return cfgs
+
+
+def run_case(name, codes, mask, wseed, style, ref, keys=None, layers=6, capture_layers=False):
+    """codes uint8 [B,T,L]; mask bool [B,L] (True = padded site)."""
+    import torch
+    from neuralnj_amd import synth, weights
+
+    frs, utils_mod, PGPI, PhyInferEnv = ref
+    torch.manual_seed(0)
+    cfgs = make_cfg(utils_mod, layers)
+    agent = PGPI(cfgs)
+    st = weights.seeded_state(cfgs, wseed, style)
+    agent.load_state_dict({k: torch.from_numpy(v) for k, v in st.items()}, strict=True)
+    agent.eval()
+    packed = weights.pack(cfgs, st)
+
+    B, T, L = codes.shape
+    onehot = synth.codes_to_onehot(codes)  # int8 [B,T,L,4]
+    seqs = [synth.codes_to_seqs(codes[b]) for b in range(B)]
+    if keys is None:
+        keys = [[f"taxon{i + 1}" for i in range(T)] for _ in range(B)]
+    batch = {
+        "seqs": seqs,
+        "seq_keys": keys,
+        "data": torch.from_numpy(onehot),
+        "seq_weights": torch.from_numpy((~mask).astype(np.float32)),
+    }
+    env = PhyInferEnv(cfgs, torch.device("cpu"))
+
+    # record every decode_zxr result and the encoder output by wrapping bound methods
+    trace = {"logits": [], "enc": None, "sub": {}}
+    orig_decode, orig_encode = agent.decode_zxr, agent.encode_zxr
+
+    def decode_spy(*a, **k):
+        r = orig_decode(*a, **k)
+        trace["logits"].append(r["logits"].detach().cpu().numpy().copy())
+        return r
+
+    def encode_spy(*a, **k):
+        r = orig_encode(*a, **k)
+        trace["enc"] = r.detach().cpu().numpy().copy()
+        return r
+
+    agent.decode_zxr, agent.encode_zxr = decode_spy, encode_spy
+    hooks = []
+    if capture_layers:
+        def mk(tag):
+            def hook(_m, _i, o):
+                t = o[0] if isinstance(o, tuple) else o
+                trace["sub"][tag] = t.detach().cpu().numpy().copy()
+            return hook
+        hooks.append(agent.embed.register_forward_hook(mk("embed")))
+        l0 = agent.seq_emb_layers[0]
+        hooks.append(l0.row_self_attention.register_forward_hook(mk("l0_row")))
+        hooks.append(l0.column_self_attention.register_forward_hook(mk("l0_col")))
+        hooks.append(l0.feed_forward_layer.register_forward_hook(mk("l0_ffn")))
+
+    # record the merges by wrapping env.step
+    merges = []
+    orig_step = env.step
+
+    def step_spy(actions, *a, **k):
+        n = env.states[0].num_trees
+        merges.append([env.tree_pairs_dict[n][int(x)] for x in actions])
+        return orig_step(actions, *a, **k)
+
+    env.step = step_spy
+    frs.device = torch.device("cpu")
+    with torch.no_grad():
+        _sel, _lps, scores, best_tree = frs.reinforce_rollout(
+            batch, agent, env, cfgs, eval=True, argmax=True, branch_optimize=False)
+    for h in hooks:
+        h.remove()
+
+    enc = trace["enc"]  # [B,T,C,D]
+    merges = np.array(merges, dtype=np.int32).transpose(1, 0, 2)  # [B,T-1,2]
+    # per-step logits: ragged -> one flat vector per batch element + offsets
+    offs = np.cumsum([0] + [l.shape[1] for l in trace["logits"]]).astype(np.int64)
+    logits = np.concatenate(trace["logits"], axis=1).astype(np.float32)  # [B, sum P(n)]
+    gaps = []
+    for l in trace["logits"]:
+        if l.shape[1] >= 2:
+            s = np.sort(l, axis=1)
+            gaps.append(s[:, -1] - s[:, -2])
+        else:
+            gaps.append(np.zeros(l.shape[0], dtype=l.dtype))
+    gaps = np.stack(gaps, 1).astype(np.float32)
+
+    newick = [st_.subtrees[0].utree_op_str for st_ in env.states]
+    topo = [st_.subtrees[0].topo_repr for st_ in env.states]
+
+    out = dict(
+        codes=codes, mask=mask, wseed=np.int64(wseed), style=np.array(style),
+        layers=np.int64(layers), weights_sha256=np.array(weights.digest(packed)),
+        merges=merges, logits=logits, logits_offsets=offs, top2_gap=gaps,
+        newick=np.array(newick), topo=np.array(topo), best_tree=np.array(best_tree),
+        keys=np.array(keys),
+        enc_checksum=np.float64(enc.astype(np.float64).sum()),
+        enc_abs_checksum=np.float64(np.abs(enc.astype(np.float64)).sum()),
+    )
+    if enc.size <= 2 * 8 * 128 * 64:
+        out["enc"] = enc.astype(np.float32)
+    else:
+        # strided slice: every 7th row, every 61st column, all features
+        out["enc_rows"] = np.arange(0, T, 7, dtype=np.int64)
+        out["enc_cols"] = np.arange(0, L, 61, dtype=np.int64)
+        out["enc_slice"] = enc[:, ::7, ::61, :].astype(np.float32)
+    for k, v in trace["sub"].items():
+        out["sub_" + k] = v.astype(np.float32)
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"{name}: B={B} T={T} L={L} min top2 gap={gaps[:, :-1].min() if gaps.shape[1] > 1 else 0:.3e} "
+          f"max|logit|={np.abs(logits).max():.3e} -> {os.path.relpath(path, REPO)}", flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default=None)
+    args = ap.parse_args()
+
+    _install_placeholders()
+    import torch
+    torch.set_num_threads(8)
+    import finetune_rl_search as frs  # noqa: E402  (reference module)
+    import utils as utils_mod  # noqa: E402  (reference module)
+    from environment import PhyInferEnv  # noqa: E402
+    from model import PhyloATTN as PGPI  # noqa: E402
+    from neuralnj_amd import synth
+
+    ref = (frs, utils_mod, PGPI, PhyInferEnv)
+    cases = []
+
+    def add(name, fn):
+        if args.only is None or args.only == name:
+            cases.append((name, fn))
+
+    for seed in (0, 1, 2):
+        for (B, T, L) in ((1, 8, 128), (2, 8, 128), (1, 20, 256), (1, 50, 1024)):
+            nm = f"synth_b{B}_t{T}_l{L}_s{seed}"
+            def fn(nm=nm, B=B, T=T, L=L, seed=seed):
+                if seed == 2:   # i.i.d. columns: no phylogenetic signal, decisions are near-ties
+                    codes = synth.synth_codes(B, T, L, 1000 + seed, gap_frac=0.2)
+                else:           # evolved down a random tree, 10 % gaps
+                    codes = synth.synth_codes_tree(B, T, L, 1000 + seed)
+                mask = np.zeros((B, L), dtype=bool)
+                run_case(nm, codes, mask, seed, "sharp", ref, capture_layers=(T == 8 and B == 1))
+            add(nm, fn)
+
+    # padded-site case: last 24 columns are '*' padding with mask=True
+    def padded():
+        codes = synth.synth_codes_tree(2, 8, 128, 77)
+        codes[:, :, 104:] = 5
+        mask = np.zeros((2, 128), dtype=bool)
+        mask[:, 104:] = True
+        run_case("padded_b2_t8_l128_s3", codes, mask, 3, "sharp", ref, capture_layers=False)
+    add("padded_b2_t8_l128_s3", padded)
+
+    # plain-style weights (reference-like init scale), small
+    def plain():
+        codes = synth.synth_codes_tree(1, 12, 96, 5)
+        run_case("plain_b1_t12_l96_s4", codes, np.zeros((1, 96), dtype=bool), 4, "plain", ref)
+    add("plain_b1_t12_l96_s4", plain)
+
+    # 3 taxa (single decision, context of one row) and 2-layer model
+    def tiny():
+        codes = synth.synth_codes_tree(2, 3, 64, 9)
+        run_case("tiny_b2_t3_l64_s5", codes, np.zeros((2, 64), dtype=bool), 5, "sharp", ref, layers=2)
+    add("tiny_b2_t3_l64_s5", tiny)
+
+    # the two example MSAs shipped with the reference, through its own loader
+    ex_dir = os.path.join(REF, "examples", "len1024taxa50")
+    for fname in sorted(os.listdir(ex_dir)):
+        if not fname.endswith(".phy"):
+            continue
+        nm = "example_" + fname[:-4].replace(".", "p")
+        def fn(nm=nm, fname=fname):
+            from phydata import load_pi_instance  # reference loader
+            batch = load_pi_instance(os.path.join(ex_dir, fname))
+            onehot = batch["data"].numpy()
+            codes = synth.onehot_to_codes(onehot)
+            mask = (batch["seq_weights"].numpy() == 0)
+            run_case(nm, codes, mask, 0, "sharp", ref, keys=batch["seq_keys"])
+        add(nm, fn)
+
+    for nm, fn in cases:
+        fn()
+
+
+if __name__ == "__main__":
+    main()
