@@ -144,16 +144,19 @@ int nnj_rollout_argmax(nnj_handle* h, const uint8_t* codes_dev, const uint8_t* m
                        float* logits_trace_dev, float* top2_gap_dev, float* state_out_dev,
                        void* ws_dev, size_t ws_bytes, void* stream);
 
-/* Kernel timing for bench.py's roofline object: when enabled, the entry points
- * bracket their kernel groups with HIP events on the launch stream; after the
- * caller has synchronised the stream, nnj_profile_read returns accumulated
- * milliseconds and launch counts per group and resets them.
- * groups: 0 = encoder, 1 = step-0 pair scorer, 2 = NJ step (new-pair scorer +
- * merged-row aggregate), 3 = table assemble + argmax + bookkeeping. */
-#define NNJ_PROFILE_GROUPS 4
+/* Kernel timing for bench.py's roofline object: when enabled, every kernel launch of
+ * the entry points is bracketed by a HIP event pair on the launch stream, tagged with
+ * its kernel kind.  After the caller has synchronised the stream, nnj_profile_read
+ * returns accumulated milliseconds and launch counts per kind (arrays of
+ * nnj_profile_kinds() entries, `cap` = their length) and resets the counters. */
 int nnj_profile_enable(nnj_handle* h, int32_t on);
-int nnj_profile_read(nnj_handle* h, double ms_out[NNJ_PROFILE_GROUPS],
-                     int64_t launches_out[NNJ_PROFILE_GROUPS]);
+int nnj_profile_kinds(void);
+const char* nnj_profile_kind_name(int32_t kind);
+int nnj_profile_read(nnj_handle* h, double* ms_out, int64_t* launches_out, int32_t cap);
+
+/* Test tap: make nnj_encode stop inside layer 0 (1 = after the row-attention block,
+ * 2 = after the column-attention block, 0 = run everything). */
+int nnj_debug_encoder_stop(nnj_handle* h, int32_t stage);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,257 @@
+"""ctypes binding of libnnj_hip.so (include/nnj.h).  PyTorch is used only for device
+memory and streams.  There is NO fallback: if the HIP library is missing or no gfx950
+device is usable, construction raises."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+import torch
+
+from . import weights as _weights
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libnnj_hip.so")
+
+_vp = C.c_void_p
+
+
+class NnjConfig(C.Structure):
+    _fields_ = [(k, C.c_int32) for k in
+                ("vocab_size", "patch_size", "embed_dim", "num_heads", "num_layers", "device")]
+
+
+_SIGS = {
+    "nnj_abi_version": ([], C.c_int),
+    "nnj_create": ([C.POINTER(NnjConfig), C.POINTER(_vp)], C.c_int),
+    "nnj_destroy": ([_vp], C.c_int),
+    "nnj_last_error": ([_vp], C.c_char_p),
+    "nnj_num_params": ([C.POINTER(NnjConfig), C.POINTER(C.c_size_t)], C.c_int),
+    "nnj_load_weights": ([_vp, _vp, C.c_size_t], C.c_int),
+    "nnj_workspace_bytes": ([_vp, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_size_t)], C.c_int),
+    "nnj_encode": ([_vp, _vp, _vp, _vp, _vp, C.c_int32, C.c_int32, C.c_int32, _vp, C.c_size_t, _vp], C.c_int),
+    "nnj_pair_scores_full": ([_vp, _vp, _vp, _vp, C.c_int32, C.c_int32, C.c_int32, _vp, C.c_size_t, _vp], C.c_int),
+    "nnj_pair_scores_incr": ([_vp, _vp, _vp, _vp, _vp, _vp, C.c_int32, C.c_int32, C.c_int32, _vp, C.c_size_t, _vp], C.c_int),
+    "nnj_score_index_map": ([_vp, _vp, _vp, C.c_int32, C.c_int32, _vp], C.c_int),
+    "nnj_aggregate": ([_vp, _vp, _vp, _vp, C.c_int32, C.c_int32, C.c_int32, _vp, C.c_size_t, _vp], C.c_int),
+    "nnj_env_step": ([_vp, _vp, _vp, _vp, C.c_int32, C.c_int32, C.c_int32, _vp, C.c_size_t, _vp], C.c_int),
+    "nnj_select_pair": ([_vp, _vp, _vp, _vp, C.c_int32, C.c_int32, _vp], C.c_int),
+    "nnj_rollout_argmax": ([_vp, _vp, _vp, C.c_int32, C.c_int32, C.c_int32, _vp, _vp, _vp, _vp, _vp, _vp,
+                            C.c_size_t, _vp], C.c_int),
+    "nnj_profile_enable": ([_vp, C.c_int32], C.c_int),
+    "nnj_profile_kinds": ([], C.c_int),
+    "nnj_profile_kind_name": ([C.c_int32], C.c_char_p),
+    "nnj_profile_read": ([_vp, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int32], C.c_int),
+    "nnj_debug_encoder_stop": ([_vp, C.c_int32], C.c_int),
+}
+
+_lib = None
+
+
+def exported_symbols():
+    return sorted(_SIGS)
+
+
+def load_library(path: str = LIB_PATH):
+    """dlopen the HIP library and bind every symbol of include/nnj.h (no compute call)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(path):
+        raise RuntimeError(
+            f"{path} is missing: build it with `python -m neuralnj_amd.build` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    lib = C.CDLL(path)
+    for name, (argt, rest) in _SIGS.items():
+        fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
+        fn.argtypes = argt
+        fn.restype = rest
+    _lib = lib
+    return lib
+
+
+def _p(t):
+    if t is None:
+        return None
+    return _vp(t.data_ptr())
+
+
+class Nnj:
+    """One device context: handle + weights + a growable torch workspace."""
+
+    def __init__(self, cfgs, device=None):
+        self.lib = load_library()
+        if not torch.cuda.is_available():
+            raise RuntimeError("neuralnj_amd needs a ROCm GPU (gfx950); none is visible and there is no CPU fallback")
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("neuralnj_amd runs on HIP devices only")
+        m = cfgs.model
+        self.cfg = NnjConfig(int(m.vocab_size), int(m.patch_size), int(m.embed_dim), int(m.num_enc_heads),
+                             int(m.num_enc_layers), int(self.device.index or 0))
+        self.cfgs = cfgs
+        self.D = int(m.embed_dim)
+        self.h = _vp()
+        rc = self.lib.nnj_create(C.byref(self.cfg), C.byref(self.h))
+        if rc != 0:
+            raise RuntimeError(f"nnj_create failed ({rc}): {self.lib.nnj_last_error(None).decode()}")
+        self._ws = None
+        self._has_weights = False
+
+    # ------------------------------------------------------------------ plumbing
+    def _chk(self, rc):
+        if rc != 0:
+            raise RuntimeError(f"libnnj_hip error {rc}: {self.lib.nnj_last_error(self.h).decode()}")
+
+    def close(self):
+        if getattr(self, "h", None) and self.h:
+            self.lib.nnj_destroy(self.h)
+            self.h = _vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _stream(self):
+        return _vp(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def workspace(self, B, T, L):
+        need = C.c_size_t()
+        self._chk(self.lib.nnj_workspace_bytes(self.h, B, T, L, C.byref(need)))
+        if self._ws is None or self._ws.numel() < need.value:
+            self._ws = None
+            self._ws = torch.empty(need.value, dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    def load_weights(self, packed):
+        """packed: flat fp32 numpy array / tensor in state_dict order (weights.pack)."""
+        if hasattr(packed, "detach"):
+            packed = packed.detach().cpu().numpy()
+        packed = np.ascontiguousarray(packed, dtype=np.float32)
+        self._chk(self.lib.nnj_load_weights(self.h, packed.ctypes.data_as(_vp), packed.size))
+        self._has_weights = True
+
+    def load_state_dict(self, state_dict):
+        self.load_weights(_weights.pack(self.cfgs, state_dict))
+
+    def _u8(self, t):
+        if t is None:
+            return None
+        t = torch.as_tensor(t)
+        if t.dtype == torch.bool:
+            t = t.to(torch.uint8)
+        return t.to(self.device, torch.uint8).contiguous()
+
+    def _i32(self, t):
+        return torch.as_tensor(t).to(self.device, torch.int32).contiguous()
+
+    def _f32(self, t):
+        return torch.as_tensor(t).to(self.device, torch.float32).contiguous()
+
+    # ------------------------------------------------------------------ entry points
+    def encode(self, codes, mask=None):
+        codes = self._u8(codes)
+        B, T, L = codes.shape
+        mask = self._u8(mask)
+        out = torch.empty((B, T, L, self.D), dtype=torch.float32, device=self.device)
+        ws = self.workspace(B, T, L)
+        self._chk(self.lib.nnj_encode(self.h, _p(codes), None, _p(mask), _p(out), B, T, L, _p(ws), ws.numel(),
+                                      self._stream()))
+        return out
+
+    def pair_scores_full(self, state, mask=None):
+        state = self._f32(state)
+        B, n, L, _ = state.shape
+        mask = self._u8(mask)
+        out = torch.empty((B, n * (n - 1) // 2), dtype=torch.float32, device=self.device)
+        ws = self.workspace(B, n, L)
+        self._chk(self.lib.nnj_pair_scores_full(self.h, _p(state), _p(mask), _p(out), B, n, L, _p(ws), ws.numel(),
+                                                self._stream()))
+        return out
+
+    def pair_scores_incr(self, state, mask, ij_prev, logits_prev):
+        state = self._f32(state)
+        B, n, L, _ = state.shape
+        mask = self._u8(mask)
+        ij_prev = self._i32(ij_prev)
+        logits_prev = self._f32(logits_prev)
+        assert tuple(logits_prev.shape) == (B, (n + 1) * n // 2)
+        out = torch.empty((B, n * (n - 1) // 2), dtype=torch.float32, device=self.device)
+        ws = self.workspace(B, n + 1, L)
+        self._chk(self.lib.nnj_pair_scores_incr(self.h, _p(state), _p(mask), _p(ij_prev), _p(logits_prev), _p(out),
+                                                B, n, L, _p(ws), ws.numel(), self._stream()))
+        return out
+
+    def score_index_map(self, ij_prev, n):
+        ij_prev = self._i32(ij_prev)
+        B = ij_prev.shape[0]
+        out = torch.empty((B, n * (n - 1) // 2), dtype=torch.int64, device=self.device)
+        self._chk(self.lib.nnj_score_index_map(self.h, _p(ij_prev), _p(out), B, n, self._stream()))
+        return out
+
+    def aggregate(self, state, ij):
+        state = self._f32(state)
+        B, n, L, _ = state.shape
+        ij = self._i32(ij)
+        out = torch.empty((B, 1, L, self.D), dtype=torch.float32, device=self.device)
+        ws = self.workspace(B, n, L)
+        self._chk(self.lib.nnj_aggregate(self.h, _p(state), _p(ij), _p(out), B, n, L, _p(ws), ws.numel(),
+                                         self._stream()))
+        return out
+
+    def env_step(self, state, ij):
+        state = self._f32(state)
+        B, n, L, _ = state.shape
+        ij = self._i32(ij)
+        out = torch.empty((B, n - 1, L, self.D), dtype=torch.float32, device=self.device)
+        ws = self.workspace(B, n, L)
+        self._chk(self.lib.nnj_env_step(self.h, _p(state), _p(ij), _p(out), B, n, L, _p(ws), ws.numel(),
+                                        self._stream()))
+        return out
+
+    def select_pair(self, logits, n):
+        logits = self._f32(logits)
+        B = logits.shape[0]
+        ij = torch.empty((B, 2), dtype=torch.int32, device=self.device)
+        gap = torch.empty((B,), dtype=torch.float32, device=self.device)
+        self._chk(self.lib.nnj_select_pair(self.h, _p(logits), _p(ij), _p(gap), B, n, self._stream()))
+        return ij, gap
+
+    def rollout_argmax(self, codes, mask=None, forced_merges=None, want_trace=False, want_state=False):
+        """Device-resident Argmax rollout.  Returns dict of device tensors (no host sync)."""
+        codes = self._u8(codes)
+        B, T, L = codes.shape
+        mask = self._u8(mask)
+        fm = None if forced_merges is None else self._i32(forced_merges)
+        merges = torch.empty((B, T - 1, 2), dtype=torch.int32, device=self.device)
+        total = sum(n * (n - 1) // 2 for n in range(2, T + 1))
+        trace = torch.empty((B, total), dtype=torch.float32, device=self.device) if want_trace else None
+        gap = torch.empty((B, T - 1), dtype=torch.float32, device=self.device) if want_trace else None
+        st = torch.empty((B, T, L, self.D), dtype=torch.float32, device=self.device) if want_state else None
+        ws = self.workspace(B, T, L)
+        self._chk(self.lib.nnj_rollout_argmax(self.h, _p(codes), _p(mask), B, T, L, _p(fm), _p(merges), _p(trace),
+                                              _p(gap), _p(st), _p(ws), ws.numel(), self._stream()))
+        out = dict(merges=merges)
+        if want_trace:
+            out["logits"] = trace
+            out["top2_gap"] = gap
+        if want_state:
+            out["state"] = st
+        return out
+
+    # ------------------------------------------------------------------ profiling
+    def profile_enable(self, on=True):
+        self._chk(self.lib.nnj_profile_enable(self.h, 1 if on else 0))
+
+    def profile_read(self):
+        k = self.lib.nnj_profile_kinds()
+        ms = (C.c_double * k)()
+        cnt = (C.c_int64 * k)()
+        self._chk(self.lib.nnj_profile_read(self.h, ms, cnt, k))
+        return {self.lib.nnj_profile_kind_name(i).decode(): (ms[i], cnt[i]) for i in range(k)}
+
+    def debug_encoder_stop(self, stage):
+        self._chk(self.lib.nnj_debug_encoder_stop(self.h, stage))

@@ -1,0 +1,35 @@
+"""Builds libnnj_hip.so (gfx950) in-tree with hipcc.  hipcc cross-compiles without a GPU."""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libnnj_hip.so")
+SOURCES = ["nnj_api.hip"]
+HEADERS = ["nnj_common.hpp", "nnj_encoder.hpp", "nnj_scorer.hpp", os.path.join("..", "..", "include", "nnj.h")]
+
+
+def _stale() -> bool:
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
+
+
+def build_hip(force: bool = False, verbose: bool = False) -> str:
+    if not force and not _stale():
+        return LIB
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+           "-Wno-unused-value", "-o", LIB] + SOURCES
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, cwd=CSRC, check=True)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build_hip(force=True, verbose=True))

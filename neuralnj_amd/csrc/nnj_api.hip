@@ -1,0 +1,690 @@
+// nnj_api.hip -- C ABI (include/nnj.h) of libnnj_hip.so: handle, weights, workspace
+// carving and the launch sequences of the encoder and the neural NJ loop.
+// gfx950 only; no CPU fallback: every compute entry point launches HIP kernels.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "../../include/nnj.h"
+#include "nnj_encoder.hpp"
+#include "nnj_scorer.hpp"
+
+namespace {
+
+enum ProfKind {
+  PK_EMBED_QKV = 0, PK_ROW_ATTN, PK_TOK1, PK_TOK2, PK_ROW_XF, PK_PAIR_ALPHA, PK_ALPHA_SOFTMAX,
+  PK_PAIR_SCORE, PK_ASSEMBLE, PK_AGG_ALPHA, PK_AGG_FINISH, PK_MISC, PK_COUNT
+};
+const char* const kProfNames[PK_COUNT] = {
+    "k_embed_qkv", "k_row_attn", "k_tok1", "k_tok2", "k_row_xf", "k_pair_alpha", "k_alpha_softmax",
+    "k_pair_score", "k_assemble_argmax", "k_agg_alpha", "k_agg_finish", "misc"};
+
+char g_err[512] = "";
+
+struct LayerOff {
+  size_t row[10], col[10];   // Wk,bk,Wv,bv,Wq,bq,Wo,bo,ln_w,ln_b
+  size_t W1, b1, W2, b2, ln_w, ln_b;
+};
+
+}  // namespace
+
+struct nnj_handle {
+  nnj_config cfg;
+  bool have_w = false;
+  float* d_w = nullptr;          // packed weights followed by derived tensors
+  size_t n_packed = 0;
+  std::vector<LayerOff> lo;
+  size_t oE0, oe0, oE2, oe2, oWh, obh, oWg, obg, oWgq, obgq, oWgk, obgk, oS0, os0, os2w, os2b;
+  size_t oA, oa0, ou, olut;      // derived (after the packed block)
+  float t0 = 0.f, s2b = 0.f;
+  int debug_stop = 0;            // encoder debug tap (nnj_debug_encoder_stop)
+  char err[512] = "";
+  // profiling
+  bool prof = false;
+  std::vector<hipEvent_t> ev;
+  std::vector<int> ev_kind;
+  size_t ev_used = 0;
+  double prof_ms[PK_COUNT] = {0};
+  int64_t prof_n[PK_COUNT] = {0};
+};
+
+namespace {
+
+int fail(nnj_handle* h, int code, const char* fmt, ...) {
+  char* dst = h ? h->err : g_err;
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(dst, 512, fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+#define HIPCHK(h, expr)                                                                       \
+  do {                                                                                        \
+    hipError_t e_ = (expr);                                                                   \
+    if (e_ != hipSuccess) return fail(h, NNJ_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+  } while (0)
+
+inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+size_t count_params(const nnj_config& c) {
+  size_t D = c.embed_dim, F = 4 * D, V = c.vocab_size, K = c.patch_size;
+  size_t per_layer = 2 * (4 * (D * D + D) + 2 * D) + (F * D + F) + (D * F + D) + 2 * D;
+  return per_layer * c.num_layers + (D * V * K + D) + (D * D + D) + 4 * (D * D + D) + (D * D + D) + (D + 1);
+}
+
+AttnW attn_ptrs(const nnj_handle* h, const size_t (&o)[10]) {
+  const float* w = h->d_w;
+  return AttnW{w + o[0], w + o[1], w + o[2], w + o[3], w + o[4], w + o[5], w + o[6], w + o[7], w + o[8], w + o[9]};
+}
+FfnW ffn_ptrs(const nnj_handle* h, const LayerOff& l) {
+  const float* w = h->d_w;
+  return FfnW{w + l.W1, w + l.b1, w + l.W2, w + l.b2, w + l.ln_w, w + l.ln_b};
+}
+ScorerW scorer_ptrs(const nnj_handle* h) {
+  const float* w = h->d_w;
+  ScorerW s;
+  s.Wh = w + h->oWh; s.bh = w + h->obh; s.Wg = w + h->oWg; s.bg = w + h->obg;
+  s.A = w + h->oA; s.a0 = w + h->oa0; s.u = w + h->ou; s.t0 = h->t0;
+  s.S0 = w + h->oS0; s.s0 = w + h->os0; s.s2w = w + h->os2w; s.s2b = h->s2b;
+  return s;
+}
+
+// ---- profiling: one event pair per launch, tagged with the kernel kind
+struct Scope {
+  nnj_handle* h; hipStream_t st; int kind; bool on;
+  Scope(nnj_handle* h_, hipStream_t st_, int kind_) : h(h_), st(st_), kind(kind_), on(false) {
+    if (h->prof && h->ev_used + 2 <= h->ev.size()) {
+      on = true;
+      hipEventRecord(h->ev[h->ev_used], st);
+    }
+  }
+  ~Scope() {
+    if (on) {
+      hipEventRecord(h->ev[h->ev_used + 1], st);
+      h->ev_kind[h->ev_used / 2] = kind;
+      h->ev_used += 2;
+    }
+  }
+};
+
+template <typename K>
+int set_lds(nnj_handle* h, K kernel, size_t bytes) {
+  if (bytes > 48 * 1024)
+    HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+  return NNJ_OK;
+}
+
+// ---- shapes the kernels cover
+int check_shape(nnj_handle* h, int B, int T, int L) {
+  if (B <= 0 || T < 1 || L <= 0) return fail(h, NNJ_ERR_ARG, "bad shape B=%d T=%d L=%d", B, T, L);
+  if (T > 50) return fail(h, NNJ_ERR_UNSUPPORTED, "T=%d: this build covers up to 50 rows (row-attention head dim 400)", T);
+  if (L % 4) return fail(h, NNJ_ERR_UNSUPPORTED, "L=%d must be a multiple of 4", L);
+  return NNJ_OK;
+}
+
+struct EncDims { int Epad, ld, NT; size_t hm; };   // hm = floats of one head-major buffer
+EncDims enc_dims(int B, int T, int C) {
+  EncDims d;
+  d.Epad = (T * 8 + 15) / 16 * 16;
+  d.ld = (d.Epad - 4 + 31) / 32 * 32 + 4;
+  d.NT = T <= 32 ? 1 : 2;
+  d.hm = (size_t)B * NNJ_NHEAD * C * d.Epad;
+  return d;
+}
+
+// pair-scorer launch geometry
+struct PairGeom { int npairs, tpw, pg, ppad, nsc, cs; };
+PairGeom pair_geom(int mode, int n, int B, int C) {
+  PairGeom g;
+  g.npairs = mode == PAIRS_FULL ? n * (n - 1) / 2 : n;
+  g.tpw = mode == PAIRS_FULL ? 2 : 1;
+  const int tiles = (g.npairs + 31) / 32;
+  g.pg = (tiles + 4 * g.tpw - 1) / (4 * g.tpw);
+  g.ppad = g.pg * 4 * g.tpw * 32;
+  int nsc = (2048 + g.pg * B - 1) / (g.pg * B);
+  const int max_nsc = (C + 7) / 8;
+  if (nsc > max_nsc) nsc = max_nsc;
+  if (nsc < 1) nsc = 1;
+  g.cs = (C + nsc - 1) / nsc;
+  g.nsc = (C + g.cs - 1) / g.cs;
+  return g;
+}
+
+// workspace regions of the NJ loop (after the state/slots buffer), in floats
+struct LoopWs {
+  size_t U, Kp, beta, alpha_part, alpha, score_part, agg_part, logits0, logits1, merged, live, ij, end;
+};
+LoopWs loop_ws(int B, int T, int C) {
+  LoopWs w;
+  const size_t rows = (size_t)B * T * C * 64;
+  const int nt32 = (C + 31) / 32;
+  size_t o = 0;
+  auto take = [&](size_t n) { size_t r = o; o += align_up(n, 64); return r; };
+  w.U = take(rows);
+  w.Kp = take(rows);
+  w.beta = take((size_t)B * T * nt32);
+  size_t ap = 0, al = 0, sp = 0;
+  for (int mode = 0; mode < 2; ++mode) {
+    PairGeom g = pair_geom(mode, T, B, C);
+    ap = std::max(ap, (size_t)B * g.nsc * g.ppad * 64);
+    al = std::max(al, (size_t)B * g.ppad * 64);
+    sp = std::max(sp, (size_t)B * g.nsc * g.ppad);
+  }
+  w.alpha_part = take(ap);
+  w.alpha = take(al);
+  w.score_part = take(sp);
+  w.agg_part = take((size_t)B * ((C + 15) / 16) * 64);
+  w.logits0 = take((size_t)B * T * (T - 1) / 2 + 1);
+  w.logits1 = take((size_t)B * T * (T - 1) / 2 + 1);
+  w.merged = take((size_t)B * C * 64);
+  w.live = take((size_t)B * T);
+  w.ij = take((size_t)B * 2 + 2);
+  w.end = o;
+  return w;
+}
+
+size_t ws_floats(int B, int T, int C) {
+  const EncDims d = enc_dims(B, T, C);
+  const size_t state = align_up((size_t)B * T * C * 64, 64);
+  const size_t enc = 4 * align_up(d.hm, 64);
+  const size_t loop = loop_ws(B, T, C).end;
+  return state + std::max(enc, loop) + 256;
+}
+
+// ------------------------------------------------------------------ encoder launches
+template <int NT>
+int launch_encoder(nnj_handle* h, const uint8_t* codes, const uint8_t* mask, float* x, float* scratch,
+                   int B, int T, int C, hipStream_t st) {
+  const EncDims d = enc_dims(B, T, C);
+  float* Q = scratch;
+  float* K = Q + align_up(d.hm, 64);
+  float* V = K + align_up(d.hm, 64);
+  float* ctx = V + align_up(d.hm, 64);
+  const int nl = h->cfg.num_layers;
+  const unsigned colblocks = (unsigned)(((size_t)B * C + 3) / 4);
+  const float* lut = h->d_w + h->olut;
+  AttnW none{};
+  {
+    Scope sc(h, st, PK_EMBED_QKV);
+    const size_t lds = 3 * 4096 * sizeof(float);
+    if (int rc = set_lds(h, k_embed_qkv<NT>, lds)) return rc;
+    hipLaunchKernelGGL(k_embed_qkv<NT>, dim3(colblocks), dim3(256), lds, st, codes, lut, mask, x, Q, K, V,
+                       nl > 0 ? attn_ptrs(h, h->lo[0].row) : none, B, T, C, d.Epad, nl > 0 ? 1 : 0);
+  }
+  // reference no-grad chunking: one masked_fill(-10000) per row chunk, summed (axial_attention.py:35-64)
+  int nchunks = 1;
+  if ((long)T * C > 1024) { int max_rows = 1024 / C; if (max_rows < 1) max_rows = 1; nchunks = (T + max_rows - 1) / max_rows; }
+  const float fill = -10000.0f * (float)nchunks;
+  for (int l = 0; l < nl; ++l) {
+    {
+      Scope sc(h, st, PK_ROW_ATTN);
+      const size_t lds = (size_t)2 * 32 * d.ld * sizeof(float);
+      if (int rc = set_lds(h, k_row_attn, lds)) return rc;
+      const int nq = (C + 63) / 64;
+      hipLaunchKernelGGL(k_row_attn, dim3((unsigned)(B * NNJ_NHEAD * nq)), dim3(256), lds, st, Q, K, V, mask, ctx, B, C,
+                         d.Epad, d.ld, fill);
+    }
+    {
+      Scope sc(h, st, PK_TOK1);
+      const size_t lds = (size_t)(16384 + 4 * 4096) * sizeof(float);
+      if (int rc = set_lds(h, k_tok1<NT>, lds)) return rc;
+      hipLaunchKernelGGL(k_tok1<NT>, dim3(colblocks), dim3(256), lds, st, ctx, mask, x, attn_ptrs(h, h->lo[l].row),
+                         attn_ptrs(h, h->lo[l].col), B, T, C, d.Epad, (l == 0 && h->debug_stop == 1) ? 1 : 0);
+    }
+    if (l == 0 && (h->debug_stop == 1 || h->debug_stop == 2)) break;
+    {
+      Scope sc(h, st, PK_TOK2);
+      const size_t lds = (size_t)16384 * sizeof(float);
+      if (int rc = set_lds(h, k_tok2<NT>, lds)) return rc;
+      const bool more = l + 1 < nl;
+      hipLaunchKernelGGL(k_tok2<NT>, dim3(colblocks), dim3(256), lds, st, x, mask, ffn_ptrs(h, h->lo[l]),
+                         more ? attn_ptrs(h, h->lo[l + 1].row) : none, Q, K, V, B, T, C, d.Epad, more ? 1 : 0);
+    }
+  }
+  HIPCHK(h, hipGetLastError());
+  return NNJ_OK;
+}
+
+int run_encoder(nnj_handle* h, const uint8_t* codes, const uint8_t* mask, float* x, float* scratch, int B, int T,
+                int C, hipStream_t st) {
+  return T <= 32 ? launch_encoder<1>(h, codes, mask, x, scratch, B, T, C, st)
+                 : launch_encoder<2>(h, codes, mask, x, scratch, B, T, C, st);
+}
+
+// ------------------------------------------------------------------ NJ-loop launches
+int launch_row_xf(nnj_handle* h, const float* S, float* U, float* Kp, float* beta, long bstride, int slots,
+                  int rows, int B, int C, hipStream_t st) {
+  Scope sc(h, st, PK_ROW_XF);
+  const int nt32 = (C + 31) / 32;
+  const size_t lds = 2 * 4096 * sizeof(float);
+  hipLaunchKernelGGL(k_row_xf, dim3((unsigned)((nt32 + 3) / 4), (unsigned)rows, (unsigned)B), dim3(256), lds, st, S,
+                     U, Kp, beta, scorer_ptrs(h), bstride, slots, C, nt32);
+  return NNJ_OK;
+}
+
+// scores of the pairs of `mode` into score_part (and alpha scratch)
+int launch_pair_scores(nnj_handle* h, const RowSet& rs, const int* ij_prev, const uint8_t* mask, float* base,
+                       const LoopWs& w, int mode, int n, int B, int C, PairGeom& g, hipStream_t st) {
+  g = pair_geom(mode, n, B, C);
+  const ScorerW sw = scorer_ptrs(h);
+  const int has_ctx = n > 2 ? 1 : 0;
+  const dim3 grid((unsigned)g.nsc, (unsigned)g.pg, (unsigned)B);
+  if (has_ctx) {
+    {
+      Scope sc(h, st, PK_PAIR_ALPHA);
+      const size_t lds = 3 * 4096 * sizeof(float);
+      if (g.tpw == 2)
+        hipLaunchKernelGGL(k_pair_alpha<2>, grid, dim3(256), lds, st, rs, sw, ij_prev, base + w.alpha_part, mode, n, C,
+                           g.npairs, g.ppad, g.cs);
+      else
+        hipLaunchKernelGGL(k_pair_alpha<1>, grid, dim3(256), lds, st, rs, sw, ij_prev, base + w.alpha_part, mode, n, C,
+                           g.npairs, g.ppad, g.cs);
+    }
+    {
+      Scope sc(h, st, PK_ALPHA_SOFTMAX);
+      hipLaunchKernelGGL(k_alpha_softmax, dim3((unsigned)(g.ppad / 4), (unsigned)B), dim3(256), 0, st, rs, sw, ij_prev,
+                         base + w.alpha_part, base + w.alpha, mode, n, C, g.npairs, g.ppad, g.nsc);
+    }
+  }
+  {
+    Scope sc(h, st, PK_PAIR_SCORE);
+    const size_t lds = 5 * 4096 * sizeof(float);
+    if (g.tpw == 2) {
+      if (int rc = set_lds(h, k_pair_score<2>, lds)) return rc;
+      hipLaunchKernelGGL(k_pair_score<2>, grid, dim3(256), lds, st, rs, sw, ij_prev, base + w.alpha, mask,
+                         base + w.score_part, mode, n, C, g.npairs, g.ppad, g.cs, has_ctx);
+    } else {
+      if (int rc = set_lds(h, k_pair_score<1>, lds)) return rc;
+      hipLaunchKernelGGL(k_pair_score<1>, grid, dim3(256), lds, st, rs, sw, ij_prev, base + w.alpha, mask,
+                         base + w.score_part, mode, n, C, g.npairs, g.ppad, g.cs, has_ctx);
+    }
+  }
+  return NNJ_OK;
+}
+
+int launch_aggregate(nnj_handle* h, const RowSet& rs, const int* ij, float* base, const LoopWs& w, float* S_out,
+                     float* U_out, float* Kp_out, float* beta_out, long out_bstride, int out_slots, int in_place,
+                     int n, int B, int C, hipStream_t st) {
+  const ScorerW sw = scorer_ptrs(h);
+  const int nch = (C + 15) / 16;
+  if (n > 2) {
+    Scope sc(h, st, PK_AGG_ALPHA);
+    hipLaunchKernelGGL(k_agg_alpha, dim3((unsigned)nch, (unsigned)B), dim3(256), 0, st, rs, sw, ij, base + w.agg_part, n, C);
+  }
+  {
+    Scope sc(h, st, PK_AGG_FINISH);
+    const size_t lds = (3 * 4096 + 64) * sizeof(float);
+    if (int rc = set_lds(h, k_agg_finish, lds)) return rc;
+    hipLaunchKernelGGL(k_agg_finish, dim3((unsigned)((C + 127) / 128), (unsigned)B), dim3(256), lds, st, rs, sw, ij,
+                       base + w.agg_part, nch, S_out, U_out, Kp_out, beta_out, out_bstride, out_slots, in_place, n, C);
+  }
+  return NNJ_OK;
+}
+
+// dense-state helper for the API-compatible entry points: transforms of all n rows
+RowSet dense_rowset(nnj_handle* h, const float* state, float* base, const LoopWs& w, int B, int n, int C,
+                    hipStream_t st) {
+  RowSet rs;
+  rs.S = state; rs.U = base + w.U; rs.Kp = base + w.Kp; rs.beta_part = base + w.beta;
+  rs.bstride = (long)n * C * 64; rs.live = nullptr; rs.live_stride = 0; rs.ntile32 = (C + 31) / 32;
+  launch_row_xf(h, state, base + w.U, base + w.Kp, base + w.beta, rs.bstride, n, n, B, C, st);
+  return rs;
+}
+
+int need_ws(nnj_handle* h, void* ws, size_t ws_bytes, int B, int T, int C) {
+  if (!ws) return fail(h, NNJ_ERR_ARG, "workspace pointer is null");
+  const size_t need = ws_floats(B, T, C) * sizeof(float);
+  if (ws_bytes < need) return fail(h, NNJ_ERR_WORKSPACE, "workspace too small: %zu < %zu bytes", ws_bytes, need);
+  if ((uintptr_t)ws % 256) return fail(h, NNJ_ERR_ARG, "workspace must be 256-byte aligned");
+  return NNJ_OK;
+}
+
+int ready(nnj_handle* h) {
+  if (!h) return fail(nullptr, NNJ_ERR_ARG, "null handle");
+  if (!h->have_w) return fail(h, NNJ_ERR_NO_WEIGHTS, "weights not loaded");
+  HIPCHK(h, hipSetDevice(h->cfg.device));
+  return NNJ_OK;
+}
+
+}  // namespace
+
+// ====================================================================== C ABI
+extern "C" {
+
+int nnj_abi_version(void) { return NNJ_ABI_VERSION; }
+
+int nnj_num_params(const nnj_config* cfg, size_t* n) {
+  if (!cfg || !n) return fail(nullptr, NNJ_ERR_ARG, "nnj_num_params: null argument");
+  *n = count_params(*cfg);
+  return NNJ_OK;
+}
+
+int nnj_create(const nnj_config* cfg, nnj_handle** out) {
+  if (!cfg || !out) return fail(nullptr, NNJ_ERR_ARG, "nnj_create: null argument");
+  if (cfg->embed_dim != NNJ_D || cfg->num_heads != NNJ_NHEAD || cfg->patch_size != 1 || cfg->vocab_size != 4 ||
+      cfg->num_layers < 0)
+    return fail(nullptr, NNJ_ERR_UNSUPPORTED,
+                "this build covers embed_dim=64, num_enc_heads=8, patch_size=1, vocab_size=4 (got %d,%d,%d,%d)",
+                cfg->embed_dim, cfg->num_heads, cfg->patch_size, cfg->vocab_size);
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail(nullptr, NNJ_ERR_NO_DEVICE, "no HIP device visible");
+  if (cfg->device < 0 || cfg->device >= ndev) return fail(nullptr, NNJ_ERR_ARG, "device %d out of range (%d devices)", cfg->device, ndev);
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, cfg->device) != hipSuccess) return fail(nullptr, NNJ_ERR_HIP, "hipGetDeviceProperties failed");
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(nullptr, NNJ_ERR_NO_DEVICE, "device %d is %s; libnnj_hip.so is built for gfx950 only", cfg->device, prop.gcnArchName);
+  nnj_handle* h = new nnj_handle();
+  h->cfg = *cfg;
+  *out = h;
+  return NNJ_OK;
+}
+
+int nnj_destroy(nnj_handle* h) {
+  if (!h) return NNJ_OK;
+  hipSetDevice(h->cfg.device);
+  if (h->d_w) hipFree(h->d_w);
+  for (hipEvent_t e : h->ev) hipEventDestroy(e);
+  delete h;
+  return NNJ_OK;
+}
+
+const char* nnj_last_error(const nnj_handle* h) { return h ? h->err : g_err; }
+
+int nnj_load_weights(nnj_handle* h, const float* p, size_t n) {
+  if (!h || !p) return fail(h, NNJ_ERR_ARG, "nnj_load_weights: null argument");
+  const size_t need = count_params(h->cfg);
+  if (n != need) return fail(h, NNJ_ERR_ARG, "nnj_load_weights: got %zu floats, config needs %zu", n, need);
+  HIPCHK(h, hipSetDevice(h->cfg.device));
+  const size_t D = NNJ_D, F = NNJ_F;
+  size_t o = 0;
+  auto take = [&](size_t k) { size_t r = o; o += k; return r; };
+  h->lo.assign(h->cfg.num_layers, LayerOff());
+  for (int l = 0; l < h->cfg.num_layers; ++l) {
+    LayerOff& L = h->lo[l];
+    for (int a = 0; a < 2; ++a) {
+      size_t* t = a == 0 ? L.row : L.col;
+      for (int k = 0; k < 4; ++k) { t[2 * k] = take(D * D); t[2 * k + 1] = take(D); }
+      t[8] = take(D); t[9] = take(D);
+    }
+    L.W1 = take(F * D); L.b1 = take(F); L.W2 = take(D * F); L.b2 = take(D); L.ln_w = take(D); L.ln_b = take(D);
+  }
+  h->oE0 = take(D * 4); h->oe0 = take(D); h->oE2 = take(D * D); h->oe2 = take(D);
+  h->oWh = take(D * D); h->obh = take(D); h->oWg = take(D * D); h->obg = take(D);
+  h->oWgq = take(D * D); h->obgq = take(D); h->oWgk = take(D * D); h->obgk = take(D);
+  h->oS0 = take(D * D); h->os0 = take(D); h->os2w = take(D); h->os2b = take(1);
+  if (o != need) return fail(h, NNJ_ERR_ARG, "nnj_load_weights: internal layout mismatch");
+  h->n_packed = need;
+  // derived tensors, computed in double and rounded once (see nnj_scorer.hpp header)
+  const size_t base = align_up(need, 64);
+  h->oA = base; h->oa0 = base + D * D; h->ou = h->oa0 + D; h->olut = h->ou + D;
+  const size_t total = h->olut + 6 * D;
+  std::vector<float> host(total, 0.f);
+  memcpy(host.data(), p, need * sizeof(float));
+  const float *Wq = p + h->oWgq, *bq = p + h->obgq, *Wk = p + h->oWgk, *bk = p + h->obgk;
+  for (size_t d1 = 0; d1 < D; ++d1) {
+    for (size_t d2 = 0; d2 < D; ++d2) {
+      double s = 0;
+      for (size_t e = 0; e < D; ++e) s += (double)Wq[e * D + d1] * (double)Wk[e * D + d2];
+      host[h->oA + d1 * D + d2] = (float)s;
+    }
+    double s0 = 0;
+    for (size_t e = 0; e < D; ++e) s0 += (double)Wq[e * D + d1] * (double)bk[e];
+    host[h->oa0 + d1] = (float)s0;
+    double su = 0;
+    for (size_t e = 0; e < D; ++e) su += (double)bq[e] * (double)Wk[e * D + d1];
+    host[h->ou + d1] = (float)su;
+  }
+  double t0 = 0;
+  for (size_t e = 0; e < D; ++e) t0 += (double)bq[e] * (double)bk[e];
+  h->t0 = (float)t0;
+  h->s2b = p[h->os2b];
+  // embed LUT of the six site vectors (model.py:39-43 on phydata.py:38-46)
+  static const int onehot[6][4] = {{1,0,0,0},{0,1,0,0},{0,0,1,0},{0,0,0,1},{1,1,1,1},{0,0,0,0}};
+  const float *E0 = p + h->oE0, *e0 = p + h->oe0, *E2 = p + h->oE2, *e2 = p + h->oe2;
+  for (int code = 0; code < 6; ++code) {
+    double t1[NNJ_D];
+    for (size_t j = 0; j < D; ++j) {
+      double s = e0[j];
+      for (int v = 0; v < 4; ++v) s += (double)E0[j * 4 + v] * onehot[code][v];
+      t1[j] = 0.5 * s * (1.0 + erf(s * 0.70710678118654752440));
+    }
+    for (size_t f = 0; f < D; ++f) {
+      double s = e2[f];
+      for (size_t j = 0; j < D; ++j) s += (double)E2[f * D + j] * t1[j];
+      host[h->olut + code * D + f] = (float)s;
+    }
+  }
+  if (h->d_w) { hipFree(h->d_w); h->d_w = nullptr; }
+  HIPCHK(h, hipMalloc(&h->d_w, total * sizeof(float)));
+  HIPCHK(h, hipMemcpy(h->d_w, host.data(), total * sizeof(float), hipMemcpyHostToDevice));
+  h->have_w = true;
+  return NNJ_OK;
+}
+
+int nnj_workspace_bytes(const nnj_handle* h, int32_t B, int32_t T, int32_t L, size_t* bytes) {
+  if (!h || !bytes || B <= 0 || T < 1 || L <= 0) return fail(const_cast<nnj_handle*>(h), NNJ_ERR_ARG, "nnj_workspace_bytes: bad argument");
+  *bytes = ws_floats(B, T, L) * sizeof(float);
+  return NNJ_OK;
+}
+
+int nnj_encode(nnj_handle* h, const uint8_t* codes, const float* onehot, const uint8_t* mask, float* state_out,
+               int32_t B, int32_t T, int32_t L, void* ws, size_t ws_bytes, void* stream) {
+  if (int rc = ready(h)) return rc;
+  if (onehot) return fail(h, NNJ_ERR_UNSUPPORTED, "nnj_encode: float one-hot input is not covered; pass 1-byte site codes");
+  if (!codes || !state_out) return fail(h, NNJ_ERR_ARG, "nnj_encode: null argument");
+  if (int rc = check_shape(h, B, T, L)) return rc;
+  if (int rc = need_ws(h, ws, ws_bytes, B, T, L)) return rc;
+  float* base = static_cast<float*>(ws);
+  const size_t state = align_up((size_t)B * T * L * 64, 64);
+  return run_encoder(h, codes, mask, state_out, base + state, B, T, L, static_cast<hipStream_t>(stream));
+}
+
+int nnj_pair_scores_full(nnj_handle* h, const float* state, const uint8_t* mask, float* logits_out, int32_t B,
+                         int32_t n, int32_t L, void* ws, size_t ws_bytes, void* stream) {
+  if (int rc = ready(h)) return rc;
+  if (!state || !logits_out || n < 2) return fail(h, NNJ_ERR_ARG, "nnj_pair_scores_full: bad argument");
+  if (int rc = check_shape(h, B, n, L)) return rc;
+  if (int rc = need_ws(h, ws, ws_bytes, B, n, L)) return rc;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  float* base = static_cast<float*>(ws) + align_up((size_t)B * n * L * 64, 64);
+  const LoopWs w = loop_ws(B, n, L);
+  RowSet rs = dense_rowset(h, state, base, w, B, n, L, st);
+  PairGeom g;
+  int* ij = reinterpret_cast<int*>(base + w.ij);
+  if (int rc = launch_pair_scores(h, rs, ij, mask, base, w, PAIRS_FULL, n, B, L, g, st)) return rc;
+  {
+    Scope sc(h, st, PK_ASSEMBLE);
+    hipLaunchKernelGGL(k_assemble_argmax, dim3((unsigned)B), dim3(256), 0, st, base + w.score_part, g.nsc, g.ppad,
+                       (const float*)nullptr, (const int*)nullptr, logits_out, (float*)nullptr, 0L, (const int*)nullptr,
+                       0L, (int*)nullptr, 0L, (float*)nullptr, 0L, ij, (int)PAIRS_FULL, n);
+  }
+  HIPCHK(h, hipGetLastError());
+  return NNJ_OK;
+}
+
+int nnj_pair_scores_incr(nnj_handle* h, const float* state, const uint8_t* mask, const int32_t* ij_prev,
+                         const float* logits_prev, float* logits_out, int32_t B, int32_t n, int32_t L, void* ws,
+                         size_t ws_bytes, void* stream) {
+  if (int rc = ready(h)) return rc;
+  if (!state || !ij_prev || !logits_prev || !logits_out || n < 2) return fail(h, NNJ_ERR_ARG, "nnj_pair_scores_incr: bad argument");
+  if (int rc = check_shape(h, B, n + 1, L)) return rc;
+  if (int rc = need_ws(h, ws, ws_bytes, B, n + 1, L)) return rc;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  float* base = static_cast<float*>(ws) + align_up((size_t)B * (n + 1) * L * 64, 64);
+  const LoopWs w = loop_ws(B, n + 1, L);
+  RowSet rs = dense_rowset(h, state, base, w, B, n, L, st);
+  PairGeom g;
+  int* ij = reinterpret_cast<int*>(base + w.ij);
+  if (int rc = launch_pair_scores(h, rs, ij_prev, mask, base, w, PAIRS_INCR, n, B, L, g, st)) return rc;
+  {
+    Scope sc(h, st, PK_ASSEMBLE);
+    hipLaunchKernelGGL(k_assemble_argmax, dim3((unsigned)B), dim3(256), 0, st, base + w.score_part, g.nsc, g.ppad,
+                       logits_prev, ij_prev, logits_out, (float*)nullptr, 0L, (const int*)nullptr, 0L, (int*)nullptr, 0L,
+                       (float*)nullptr, 0L, ij, (int)PAIRS_INCR, n);
+  }
+  HIPCHK(h, hipGetLastError());
+  return NNJ_OK;
+}
+
+int nnj_score_index_map(nnj_handle* h, const int32_t* ij_prev, int64_t* idx_out, int32_t B, int32_t n, void* stream) {
+  if (!h) return fail(nullptr, NNJ_ERR_ARG, "null handle");
+  HIPCHK(h, hipSetDevice(h->cfg.device));
+  if (!ij_prev || !idx_out || B <= 0 || n < 2) return fail(h, NNJ_ERR_ARG, "nnj_score_index_map: bad argument");
+  const long total = (long)B * (n * (n - 1) / 2);
+  hipLaunchKernelGGL(k_index_map, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     ij_prev, reinterpret_cast<long long*>(idx_out), B, n);
+  HIPCHK(h, hipGetLastError());
+  return NNJ_OK;
+}
+
+int nnj_aggregate(nnj_handle* h, const float* state, const int32_t* ij, float* out_row, int32_t B, int32_t n,
+                  int32_t L, void* ws, size_t ws_bytes, void* stream) {
+  if (int rc = ready(h)) return rc;
+  if (!state || !ij || !out_row || n < 2) return fail(h, NNJ_ERR_ARG, "nnj_aggregate: bad argument");
+  if (int rc = check_shape(h, B, n, L)) return rc;
+  if (int rc = need_ws(h, ws, ws_bytes, B, n, L)) return rc;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  float* base = static_cast<float*>(ws) + align_up((size_t)B * n * L * 64, 64);
+  const LoopWs w = loop_ws(B, n, L);
+  RowSet rs = dense_rowset(h, state, base, w, B, n, L, st);
+  if (int rc = launch_aggregate(h, rs, ij, base, w, out_row, nullptr, nullptr, nullptr, (long)L * 64, 1, 0, n, B, L, st)) return rc;
+  HIPCHK(h, hipGetLastError());
+  return NNJ_OK;
+}
+
+int nnj_env_step(nnj_handle* h, const float* state, const int32_t* ij, float* state_out, int32_t B, int32_t n,
+                 int32_t L, void* ws, size_t ws_bytes, void* stream) {
+  if (int rc = ready(h)) return rc;
+  if (!state || !ij || !state_out || n < 3) return fail(h, NNJ_ERR_ARG, "nnj_env_step: bad argument (n must be >= 3)");
+  if (int rc = check_shape(h, B, n, L)) return rc;
+  if (int rc = need_ws(h, ws, ws_bytes, B, n, L)) return rc;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  float* base = static_cast<float*>(ws) + align_up((size_t)B * n * L * 64, 64);
+  const LoopWs w = loop_ws(B, n, L);
+  RowSet rs = dense_rowset(h, state, base, w, B, n, L, st);
+  float* merged = base + w.merged;
+  if (int rc = launch_aggregate(h, rs, ij, base, w, merged, nullptr, nullptr, nullptr, (long)L * 64, 1, 0, n, B, L, st)) return rc;
+  {
+    Scope sc(h, st, PK_MISC);
+    const long row_f4 = (long)L * 16;
+    hipLaunchKernelGGL(k_compact_rows, dim3(16, (unsigned)(n - 1), (unsigned)B), dim3(256), 0, st, state, merged, ij,
+                       state_out, n, row_f4);
+  }
+  HIPCHK(h, hipGetLastError());
+  return NNJ_OK;
+}
+
+int nnj_select_pair(nnj_handle* h, const float* logits, int32_t* ij_out, float* top2_gap, int32_t B, int32_t n,
+                    void* stream) {
+  if (!h) return fail(nullptr, NNJ_ERR_ARG, "null handle");
+  HIPCHK(h, hipSetDevice(h->cfg.device));
+  if (!logits || !ij_out || B <= 0 || n < 2) return fail(h, NNJ_ERR_ARG, "nnj_select_pair: bad argument");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  Scope sc(h, st, PK_ASSEMBLE);
+  hipLaunchKernelGGL(k_select_pair, dim3((unsigned)B), dim3(256), 0, st, logits, ij_out, top2_gap, n);
+  HIPCHK(h, hipGetLastError());
+  return NNJ_OK;
+}
+
+int nnj_rollout_argmax(nnj_handle* h, const uint8_t* codes, const uint8_t* mask, int32_t B, int32_t T, int32_t L,
+                       const int32_t* forced, int32_t* merges_out, float* trace, float* gap, float* state_out,
+                       void* ws, size_t ws_bytes, void* stream) {
+  if (int rc = ready(h)) return rc;
+  if (!codes || !merges_out || T < 2) return fail(h, NNJ_ERR_ARG, "nnj_rollout_argmax: bad argument");
+  if (int rc = check_shape(h, B, T, L)) return rc;
+  if (int rc = need_ws(h, ws, ws_bytes, B, T, L)) return rc;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int C = L;
+  float* S = static_cast<float*>(ws);
+  const size_t state = align_up((size_t)B * T * C * 64, 64);
+  float* base = S + state;
+  if (int rc = run_encoder(h, codes, mask, S, base, B, T, C, st)) return rc;      // finetune_rl_search.py:108-112
+  if (state_out) HIPCHK(h, hipMemcpyAsync(state_out, S, (size_t)B * T * C * 64 * sizeof(float), hipMemcpyDeviceToDevice, st));
+  const LoopWs w = loop_ws(B, T, C);
+  int* live = reinterpret_cast<int*>(base + w.live);
+  int* ij = reinterpret_cast<int*>(base + w.ij);
+  {
+    Scope sc(h, st, PK_MISC);
+    hipLaunchKernelGGL(k_init_live, dim3((unsigned)((B * T + 255) / 256)), dim3(256), 0, st, live, T, B, T);
+  }
+  launch_row_xf(h, S, base + w.U, base + w.Kp, base + w.beta, (long)T * C * 64, T, T, B, C, st);
+  RowSet rs;
+  rs.S = S; rs.U = base + w.U; rs.Kp = base + w.Kp; rs.beta_part = base + w.beta;
+  rs.bstride = (long)T * C * 64; rs.live = live; rs.live_stride = T; rs.ntile32 = (C + 31) / 32;
+  size_t total = 0;
+  for (int n = T; n >= 2; --n) total += (size_t)n * (n - 1) / 2;
+  float* lg[2] = {base + w.logits0, base + w.logits1};
+  size_t off = 0;
+  for (int step = 0, n = T; n >= 2; ++step, --n) {
+    const int mode = step == 0 ? PAIRS_FULL : PAIRS_INCR;
+    PairGeom g;
+    if (int rc = launch_pair_scores(h, rs, ij, mask, base, w, mode, n, B, C, g, st)) return rc;   // :121-126
+    {
+      Scope sc(h, st, PK_ASSEMBLE);                                                                 // :140-160
+      hipLaunchKernelGGL(k_assemble_argmax, dim3((unsigned)B), dim3(256), 0, st, base + w.score_part, g.nsc, g.ppad,
+                         (const float*)lg[(step + 1) & 1], (const int*)ij, lg[step & 1], trace ? trace + off : nullptr,
+                         (long)total, forced ? forced + 2 * step : nullptr, (long)(T - 1) * 2, merges_out + 2 * step,
+                         (long)(T - 1) * 2, gap ? gap + step : nullptr, (long)(T - 1), ij, mode, n);
+    }
+    off += (size_t)n * (n - 1) / 2;
+    if (n > 2) {                                                                                    // env.step :164
+      if (int rc = launch_aggregate(h, rs, ij, base, w, S, base + w.U, base + w.Kp, base + w.beta, rs.bstride, T, 1, n,
+                                    B, C, st)) return rc;
+      Scope sc(h, st, PK_MISC);
+      hipLaunchKernelGGL(k_update_live, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, st, live, T, (const int*)ij, B, n);
+    }
+  }
+  HIPCHK(h, hipGetLastError());
+  return NNJ_OK;
+}
+
+int nnj_debug_encoder_stop(nnj_handle* h, int32_t stage) {
+  if (!h) return NNJ_ERR_ARG;
+  h->debug_stop = stage;
+  return NNJ_OK;
+}
+
+int nnj_profile_enable(nnj_handle* h, int32_t on) {
+  if (!h) return fail(nullptr, NNJ_ERR_ARG, "null handle");
+  HIPCHK(h, hipSetDevice(h->cfg.device));
+  h->prof = on != 0;
+  if (h->prof && h->ev.empty()) {
+    h->ev.resize(16384);
+    h->ev_kind.assign(8192, 0);
+    for (auto& e : h->ev) HIPCHK(h, hipEventCreate(&e));
+  }
+  h->ev_used = 0;
+  for (int k = 0; k < PK_COUNT; ++k) { h->prof_ms[k] = 0; h->prof_n[k] = 0; }
+  return NNJ_OK;
+}
+
+int nnj_profile_kinds(void) { return PK_COUNT; }
+const char* nnj_profile_kind_name(int32_t k) { return (k >= 0 && k < PK_COUNT) ? kProfNames[k] : ""; }
+
+int nnj_profile_read(nnj_handle* h, double* ms_out, int64_t* launches_out, int32_t cap) {
+  if (!h || !ms_out || !launches_out || cap < PK_COUNT) return fail(h, NNJ_ERR_ARG, "nnj_profile_read: bad argument");
+  HIPCHK(h, hipSetDevice(h->cfg.device));
+  for (size_t i = 0; i + 1 < h->ev_used; i += 2) {
+    HIPCHK(h, hipEventSynchronize(h->ev[i + 1]));
+    float ms = 0.f;
+    HIPCHK(h, hipEventElapsedTime(&ms, h->ev[i], h->ev[i + 1]));
+    const int k = h->ev_kind[i / 2];
+    h->prof_ms[k] += ms;
+    h->prof_n[k] += 1;
+  }
+  h->ev_used = 0;
+  for (int k = 0; k < PK_COUNT; ++k) {
+    ms_out[k] = h->prof_ms[k]; launches_out[k] = h->prof_n[k];
+    h->prof_ms[k] = 0; h->prof_n[k] = 0;
+  }
+  return NNJ_OK;
+}
+
+}  // extern "C"

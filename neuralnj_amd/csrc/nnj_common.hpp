@@ -1,0 +1,215 @@
+// nnj_common.hpp -- device helpers shared by the gfx950 kernels of libnnj_hip.so.
+//
+// Register layout used by every token-local stage ("feature-major tile"):
+//   a wave owns NT tiles of 32 tokens; lane l serves token (l & 31) of each tile and
+//   lane-half hh = l >> 5.  A 64-feature vector of a token lives in two f32x16
+//   accumulators a[0], a[1]; element reg = 4*g + t of a[mt] is feature
+//        f = 32*mt + 8*g + 4*hh + t.
+//   This is exactly the C/D layout of v_mfma_f32_32x32x2_f32 (col = lane&31,
+//   row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)), so the output of one linear layer is
+//   directly the B operand of the next one (no LDS round trip), and it is also the
+//   natural order of 16-byte loads: chunk (2*(4*mt+g) + hh) of the token's row.
+//
+// OUT^T[out x tokens] = W[out x in] * IN^T[in x tokens]:  A = W from LDS (one
+// ds_read_b128 feeds 4 MFMAs), B = IN from registers.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define NNJ_D 64          // embed_dim the kernels are specialised for
+#define NNJ_NHEAD 8           // heads
+#define NNJ_DH 8          // head dim
+#define NNJ_F 256         // FFN hidden
+
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// exp via v_exp_f32: relative error ~1e-7*|x|; every use here is exp(x), x <= 0 (softmax
+// terms, sigmoid, erfc tail), so the absolute error stays below fp32 rounding of the sums.
+__device__ __forceinline__ float nnj_exp(float x) { return __expf(x); }
+__device__ __forceinline__ float sigmoidf_(float x) {
+  // 1/(1+e^-x) without overflow on either side
+  const float e = nnj_exp(-fabsf(x));
+  const float r = 1.0f / (1.0f + e);
+  return x >= 0.f ? r : e * r;
+}
+// nn.GELU() default (exact erf form).  erfc by Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7,
+// a few fp32 ulps of the result), written so that 1+erf(x) for x<0 has no cancellation.
+__device__ __forceinline__ float gelu_erf(float x) {
+  const float ax = fabsf(x) * 0.70710678118654752440f;
+  const float t = 1.0f / (1.0f + 0.3275911f * ax);
+  float p = 1.061405429f;
+  p = p * t - 1.453152027f;
+  p = p * t + 1.421413741f;
+  p = p * t - 0.284496736f;
+  p = p * t + 0.254829592f;
+  const float erfc_abs = p * t * nnj_exp(-ax * ax);       // erfc(|x|/sqrt2)
+  const float one_plus_erf = x >= 0.f ? 2.0f - erfc_abs : erfc_abs;
+  return 0.5f * x * one_plus_erf;
+}
+
+// ---- LDS weight image: W[out][in] row-major, 16-byte chunks XOR-swizzled by row so
+// that a ds_read_b128 whose 16-lane groups read 16 different rows at the same logical
+// chunk is bank-conflict free.  IN must be a multiple of 64 floats.
+__device__ __forceinline__ int wswz(int row, int chunk) { return chunk ^ (row & 15); }
+
+// cooperative copy of a [rows][IN] fp32 matrix from global to the swizzled LDS image
+template <int IN>
+__device__ __forceinline__ void stage_weight(float* lds, const float* __restrict__ g, int rows,
+                                             int tid, int nthreads) {
+  constexpr int CH = IN / 4;
+  for (int i = tid; i < rows * CH; i += nthreads) {
+    const int r = i / CH, c = i % CH;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(g + (size_t)r * IN + 4 * c);
+    *reinterpret_cast<f32x4*>(lds + r * IN + 4 * wswz(r, c)) = v;
+  }
+}
+// sub-block variant: rows [r0, r0+rows) and input columns [c0, c0+INSUB) of a [*, IN] matrix
+template <int IN, int INSUB>
+__device__ __forceinline__ void stage_weight_sub(float* lds, const float* __restrict__ g, int r0, int rows,
+                                                 int c0, int tid, int nthreads) {
+  constexpr int CH = INSUB / 4;
+  for (int i = tid; i < rows * CH; i += nthreads) {
+    const int r = i / CH, c = i % CH;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(g + (size_t)(r0 + r) * IN + c0 + 4 * c);
+    *reinterpret_cast<f32x4*>(lds + r * INSUB + 4 * wswz(r, c)) = v;
+  }
+}
+
+// ---- linear layer on feature-major tiles.
+//   out[nt][mt] (MT tiles of 32 out-features) = bias + W * in,   in has KT tiles.
+//   W: swizzled LDS image [32*MT][32*KT]; bias: pointer readable with 16-byte loads
+//   (LDS or global), may be nullptr.
+template <int MT, int KT, int NT>
+__device__ __forceinline__ void linear_T(f32x16 (&out)[NT][MT], const f32x16 (&in)[NT][KT],
+                                         const float* W, const float* bias, int lane) {
+  const int row = lane & 31, hh = lane >> 5;
+  constexpr int IN = 32 * KT;
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+      if (bias) b4 = *reinterpret_cast<const f32x4*>(bias + 32 * mt + 8 * g + 4 * hh);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        out[nt][mt][4 * g + 0] = b4[0]; out[nt][mt][4 * g + 1] = b4[1];
+        out[nt][mt][4 * g + 2] = b4[2]; out[nt][mt][4 * g + 3] = b4[3];
+      }
+    }
+    const int wrow = 32 * mt + row;
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int chunk = (32 * kt + 8 * g + 4 * hh) >> 2;
+        const f32x4 a = *reinterpret_cast<const f32x4*>(W + wrow * IN + 4 * wswz(wrow, chunk));
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) out[nt][mt] = mfma32(a[t], in[nt][kt][4 * g + t], out[nt][mt]);
+        }
+      }
+    }
+  }
+}
+
+// accumulate variant: out += W * in (no bias init)
+template <int MT, int KT, int NT>
+__device__ __forceinline__ void linear_T_acc(f32x16 (&out)[NT][MT], const f32x16 (&in)[NT][KT],
+                                             const float* W, int lane) {
+  const int row = lane & 31, hh = lane >> 5;
+  constexpr int IN = 32 * KT;
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int wrow = 32 * mt + row;
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int chunk = (32 * kt + 8 * g + 4 * hh) >> 2;
+        const f32x4 a = *reinterpret_cast<const f32x4*>(W + wrow * IN + 4 * wswz(wrow, chunk));
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) out[nt][mt] = mfma32(a[t], in[nt][kt][4 * g + t], out[nt][mt]);
+        }
+      }
+    }
+  }
+}
+
+// ---- token I/O: 64 features of one token <-> two accumulators (zeros when !valid)
+__device__ __forceinline__ void load_token64(f32x16 (&a)[2], const float* p, bool valid, int hh) {
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (valid) v = *reinterpret_cast<const f32x4*>(p + 32 * mt + 8 * g + 4 * hh);
+      a[mt][4 * g + 0] = v[0]; a[mt][4 * g + 1] = v[1]; a[mt][4 * g + 2] = v[2]; a[mt][4 * g + 3] = v[3];
+    }
+}
+__device__ __forceinline__ void store_token64(const f32x16 (&a)[2], float* p, bool valid, int hh) {
+  if (!valid) return;
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      f32x4 v = {a[mt][4 * g + 0], a[mt][4 * g + 1], a[mt][4 * g + 2], a[mt][4 * g + 3]};
+      *reinterpret_cast<f32x4*>(p + 32 * mt + 8 * g + 4 * hh) = v;
+    }
+}
+
+// LayerNorm over the 64 features of the lane's token (eps 1e-5, biased variance);
+// gamma/beta readable with 16-byte loads.
+__device__ __forceinline__ void layer_norm64(f32x16 (&y)[2], const f32x16 (&x)[2],
+                                             const float* gamma, const float* beta, int hh) {
+  float s = 0.f;
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s += x[mt][r];
+  s += __shfl_xor(s, 32);
+  const float mean = s * (1.0f / 64.0f);
+  float v = 0.f;
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { const float d = x[mt][r] - mean; v += d * d; }
+  v += __shfl_xor(v, 32);
+  const float inv = 1.0f / sqrtf(v * (1.0f / 64.0f) + 1e-5f);
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const f32x4 gm = *reinterpret_cast<const f32x4*>(gamma + 32 * mt + 8 * g + 4 * hh);
+      const f32x4 bt = *reinterpret_cast<const f32x4*>(beta + 32 * mt + 8 * g + 4 * hh);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) y[mt][4 * g + t] = (x[mt][4 * g + t] - mean) * inv * gm[t] + bt[t];
+    }
+}
+
+// flat index of pair (i,j), i<j, among combinations(range(n),2)
+__host__ __device__ __forceinline__ int pair_index(int n, int i, int j) {
+  return i * n - i * (i + 1) / 2 + (j - i - 1);
+}
+__host__ __device__ __forceinline__ int num_pairs(int n) { return n * (n - 1) / 2; }
+// inverse: flat p -> (i,j)
+__device__ __forceinline__ void pair_from_index(int n, int p, int& i, int& j) {
+  // rows before i hold i*n - i(i+1)/2 pairs; solve by float estimate then fix up
+  int ii = (int)((2.0f * n - 1.0f - sqrtf((2.0f * n - 1.0f) * (2.0f * n - 1.0f) - 8.0f * (float)p)) * 0.5f);
+  if (ii < 0) ii = 0;
+  if (ii > n - 2) ii = n - 2;
+  while (ii > 0 && ii * n - ii * (ii + 1) / 2 > p) --ii;
+  while (ii < n - 2 && (ii + 1) * n - (ii + 1) * (ii + 2) / 2 <= p) ++ii;
+  i = ii;
+  j = p - (ii * n - ii * (ii + 1) / 2) + ii + 1;
+}

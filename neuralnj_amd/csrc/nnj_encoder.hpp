@@ -1,0 +1,474 @@
+// nnj_encoder.hpp -- gfx950 kernels of the axial MSA encoder
+// (restates reference model.py:67-88, msa_modules.py:62-151, axial_attention.py:6-255).
+//
+// Tiling: one wave owns one alignment column (b, c) and all R rows of it ("column
+// wave", tokens = rows, NT = ceil(R/32) tiles of 32 tokens on the lanes); a workgroup
+// is 4 waves = 4 adjacent columns, so every row contributes 1 KiB contiguous bytes.
+// Token-local stages chain in registers (nnj_common.hpp); weights sit in LDS.
+//
+//   k_embed_qkv : embed (6-entry LUT of the site codes) -> x ; LN -> q,k,v (row attn, layer 0)
+//   k_row_attn  : tied row attention, flash style, head dim E = R*8, per (b, h, 64 queries)
+//   k_tok1      : ctx -> out_proj -> +x ; LN -> q,k,v -> column attention -> out_proj -> +x
+//   k_tok2      : LN -> fc1 -> GELU -> fc2 -> +x ; [LN -> q,k,v of the next layer's row attn]
+//
+// HBM layouts: x [B,R,C,64]; Q/K/V/ctx head-major [B,8,C,Epad] with e = r*8 + d,
+// Epad = roundup(R*8,16) (zero padded) -- a (b,h) slice is a plain [C x Epad] matrix.
+#pragma once
+#include "nnj_common.hpp"
+
+struct AttnW {            // pointers into the packed device weights (row-major [out][in])
+  const float *Wk, *bk, *Wv, *bv, *Wq, *bq, *Wo, *bo, *ln_w, *ln_b;
+};
+struct FfnW {
+  const float *W1, *b1, *W2, *b2, *ln_w, *ln_b;
+};
+
+// ------------------------------------------------------------------ QKV epilogue
+// Writes one of q/k/v (feature-major registers of the wave's column) to the
+// head-major buffer.  Rows r >= R inside the zero-padded Epad range are written as 0.
+template <int NT>
+__device__ __forceinline__ void store_headmajor(const f32x16 (&v)[NT][2], float* dst, int b, int c, int C,
+                                                int R, int Epad, float scale, int lane) {
+  const int tok = lane & 31, hh = lane >> 5;
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int r = 32 * nt + tok;
+    if (r * 8 >= Epad) continue;
+    const bool live = r < R;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int h = 4 * mt + g;
+        f32x4 o = {0.f, 0.f, 0.f, 0.f};
+        if (live) {
+          o[0] = v[nt][mt][4 * g + 0] * scale; o[1] = v[nt][mt][4 * g + 1] * scale;
+          o[2] = v[nt][mt][4 * g + 2] * scale; o[3] = v[nt][mt][4 * g + 3] * scale;
+        }
+        *reinterpret_cast<f32x4*>(dst + (((size_t)b * NNJ_NHEAD + h) * C + c) * Epad + r * 8 + 4 * hh) = o;
+      }
+  }
+}
+
+// LN + q,k,v projections of the row attention, written head-major.
+// q is pre-multiplied by head_dim^-0.5 / sqrt(R) and zeroed at padded columns
+// (reference axial_attention.py:31-33,77-82).
+template <int NT>
+__device__ __forceinline__ void row_qkv_stage(const f32x16 (&x)[NT][2], const AttnW& w, const float* Wq_l,
+                                              const float* Wk_l, const float* Wv_l, float* Q, float* K,
+                                              float* V, int b, int c, int C, int R, int Epad, bool padded,
+                                              int lane) {
+  const int hh = lane >> 5;
+  f32x16 y[NT][2];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) layer_norm64(y[nt], x[nt], w.ln_w, w.ln_b, hh);
+  const float qscale = padded ? 0.0f : (rsqrtf((float)NNJ_DH) / sqrtf((float)R));
+  f32x16 o[NT][2];
+  linear_T<2, 2, NT>(o, y, Wq_l, w.bq, lane);
+  store_headmajor<NT>(o, Q, b, c, C, R, Epad, qscale, lane);
+  linear_T<2, 2, NT>(o, y, Wk_l, w.bk, lane);
+  store_headmajor<NT>(o, K, b, c, C, R, Epad, 1.0f, lane);
+  linear_T<2, 2, NT>(o, y, Wv_l, w.bv, lane);
+  store_headmajor<NT>(o, V, b, c, C, R, Epad, 1.0f, lane);
+}
+
+// ------------------------------------------------------------------ k_embed_qkv
+// codes uint8 [B,R,L] (patch_size 1: C == L); lut [6][64] = embed MLP of the six site
+// vectors (reference model.py:39-43,76-77 evaluated on phydata.py:38-46's vectors).
+template <int NT>
+__global__ __launch_bounds__(256) void k_embed_qkv(const uint8_t* __restrict__ codes,
+                                                   const float* __restrict__ lut,
+                                                   const uint8_t* __restrict__ mask, float* __restrict__ x,
+                                                   float* __restrict__ Q, float* __restrict__ K,
+                                                   float* __restrict__ V, AttnW w, int B, int R, int C,
+                                                   int Epad, int do_qkv) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Wq_l = smem;
+  float* Wk_l = smem + 4096;
+  float* Wv_l = smem + 8192;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (do_qkv) {
+    stage_weight<64>(Wq_l, w.Wq, 64, tid, 256);
+    stage_weight<64>(Wk_l, w.Wk, 64, tid, 256);
+    stage_weight<64>(Wv_l, w.Wv, 64, tid, 256);
+  }
+  __syncthreads();
+  const long col = (long)blockIdx.x * 4 + wave;   // (b, c) flattened
+  if (col >= (long)B * C) return;
+  const int b = (int)(col / C), c = (int)(col % C);
+  const int tok = lane & 31, hh = lane >> 5;
+  f32x16 xr[NT][2];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int r = 32 * nt + tok;
+    const bool valid = r < R;
+    int code = 5;
+    if (valid) code = codes[((size_t)b * R + r) * C + c];
+    if (code > 5) code = 5;
+    load_token64(xr[nt], lut + code * 64, valid, hh);
+    store_token64(xr[nt], x + (((size_t)b * R + r) * C + c) * 64, valid, hh);
+  }
+  if (do_qkv) {
+    const bool padded = mask && mask[(size_t)b * C + c];
+    row_qkv_stage<NT>(xr, w, Wq_l, Wk_l, Wv_l, Q, K, V, b, c, C, R, Epad, padded, lane);
+  }
+}
+
+// ------------------------------------------------------------------ k_row_attn
+// Tied row attention for one (b, h) and 64 query columns: standard attention over the
+// C columns with head dimension Epad (reference axial_attention.py:97-114), online
+// softmax, fp32 MFMA 16x16x4.  Computes S^T = K Q^T so that the probabilities come out
+// in the A-operand layout of the P*V product.
+//   LDS: K tile [32][ld], V tile [32][ld], ld = roundup(Epad-4,32)+4 (ld % 32 == 4
+//   makes both the float2 K reads and the scalar V reads conflict free).
+#define RA_NTE_MAX 25     // Epad <= 400  (R <= 50)
+__global__ __launch_bounds__(256) void k_row_attn(const float* __restrict__ Q, const float* __restrict__ K,
+                                                  const float* __restrict__ V,
+                                                  const uint8_t* __restrict__ mask, float* __restrict__ ctx,
+                                                  int B, int C, int Epad, int ld, float fill) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Kl = smem;
+  float* Vl = smem + 32 * ld;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // XCD-aware mapping: all query tiles of one (b,h) share blockIdx % 8 (one L2)
+  const int nq = (C + 63) / 64;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int bh = (slot / nq) * 8 + xcd;
+  const int qt = slot % nq;
+  if (bh >= B * NNJ_NHEAD) return;           // whole workgroup exits together
+  const int b = bh / NNJ_NHEAD;
+  const size_t base = (size_t)bh * C * Epad;
+  const int l15 = lane & 15, kq = lane >> 4;
+  const int nte = Epad / 16, ns = Epad / 8;
+  const int q0 = qt * 64 + wave * 16;
+  const int qi = q0 + l15;               // this lane's query (B operand column)
+  const bool qvalid = qi < C;
+
+  // Q fragment: lane (query, kq) holds Q[query][8s + 2kq + u]
+  float qf[2 * RA_NTE_MAX * 2];          // 100 floats (s < ns)
+#pragma unroll
+  for (int s = 0; s < 2 * RA_NTE_MAX; ++s) {
+    float2 v = make_float2(0.f, 0.f);
+    if (s < ns && qvalid) v = *reinterpret_cast<const float2*>(Q + base + (size_t)qi * Epad + 8 * s + 2 * kq);
+    qf[2 * s] = v.x; qf[2 * s + 1] = v.y;
+  }
+  f32x4 O[RA_NTE_MAX];
+#pragma unroll
+  for (int t = 0; t < RA_NTE_MAX; ++t) O[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float m_run = -INFINITY, l_run = 0.f;
+
+  const int nkt = (C + 31) / 32;
+  for (int kt = 0; kt < nkt; ++kt) {
+    const int j0 = kt * 32;
+    __syncthreads();                      // previous tile fully consumed
+    // stage K,V tiles: rows j0..j0+31 (zero beyond C), Epad floats each, 16-byte pieces
+    const int ch_per_row = Epad / 4;
+    for (int i = tid; i < 32 * ch_per_row; i += 256) {
+      const int r = i / ch_per_row, ch = i % ch_per_row;
+      f32x4 kv = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
+      if (j0 + r < C) {
+        kv = *reinterpret_cast<const f32x4*>(K + base + (size_t)(j0 + r) * Epad + 4 * ch);
+        vv = *reinterpret_cast<const f32x4*>(V + base + (size_t)(j0 + r) * Epad + 4 * ch);
+      }
+      *reinterpret_cast<f32x4*>(Kl + r * ld + 4 * ch) = kv;
+      *reinterpret_cast<f32x4*>(Vl + r * ld + 4 * ch) = vv;
+    }
+    __syncthreads();
+
+    // S^T[key x query]: two 16-key tiles; A = K (lane: key l15, kq), B = Q regs
+    f32x4 st[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int s = 0; s < 2 * RA_NTE_MAX; ++s) {
+      if (s < ns) {
+#pragma unroll
+        for (int t2 = 0; t2 < 2; ++t2) {
+          const float2 a = *reinterpret_cast<const float2*>(Kl + (16 * t2 + l15) * ld + 8 * s + 2 * kq);
+          st[t2] = mfma16(a.x, qf[2 * s], st[t2]);
+          st[t2] = mfma16(a.y, qf[2 * s + 1], st[t2]);
+        }
+      }
+    }
+    // st[t2][reg] = S[query = l15][key = j0 + 16*t2 + 4*kq + reg]
+    float tmax = -INFINITY;
+#pragma unroll
+    for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = j0 + 16 * t2 + 4 * kq + r;
+        float s = st[t2][r];
+        if (key >= C) s = -INFINITY;                       // beyond the alignment: not a key
+        else if (mask && mask[(size_t)b * C + key]) s = fill;  // padded key (axial_attention.py:99-103)
+        st[t2][r] = s;
+        tmax = fmaxf(tmax, s);
+      }
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 16));
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+    const float m_new = fmaxf(m_run, tmax);
+    const float sc = nnj_exp(m_run - m_new);                // 0 on the first tile (m_run = -inf)
+    float psum = 0.f;
+#pragma unroll
+    for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float p = nnj_exp(st[t2][r] - m_new);
+        st[t2][r] = p;
+        psum += p;
+      }
+    psum += __shfl_xor(psum, 16);
+    psum += __shfl_xor(psum, 32);
+    l_run = l_run * sc + psum;
+    m_run = m_new;
+    // rescale O rows: row (4*kq + reg) of the C/D layout is query 4*kq+reg -> its scale
+    // lives in the lanes with (lane & 15) == that query
+    float scr[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) scr[r] = __shfl(sc, 4 * kq + r);
+    // O[query x e] += P[query x key] V[key x e]; A = P regs, B = V from LDS
+#pragma unroll
+    for (int t = 0; t < RA_NTE_MAX; ++t) {
+      if (t < nte) {
+        f32x4 o = O[t];
+        o[0] *= scr[0]; o[1] *= scr[1]; o[2] *= scr[2]; o[3] *= scr[3];
+#pragma unroll
+        for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float vb = Vl[(16 * t2 + 4 * kq + r) * ld + 16 * t + l15];
+            o = mfma16(st[t2][r], vb, o);
+          }
+        O[t] = o;
+      }
+    }
+  }
+  // normalise and store: O[t][reg] is (query q0 + 4*kq + reg, e = 16 t + l15)
+  float linv[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) linv[r] = 1.0f / __shfl(l_run, 4 * kq + r);
+#pragma unroll
+  for (int t = 0; t < RA_NTE_MAX; ++t) {
+    if (t < nte) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int qrow = q0 + 4 * kq + r;
+        if (qrow < C) ctx[base + (size_t)qrow * Epad + 16 * t + l15] = O[t][r] * linv[r];
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------ k_tok1
+// Row-attention output projection + residual, then the whole column-attention block
+// (reference msa_modules.py:109-125 around axial_attention.py:119-138 and 141-255).
+//   LDS: W[0..3] four 64x64 weight images (Wo_row -> later Wo_col, Wq, Wk, Wv) 64 KiB
+//        + per wave K,V of one head-half [64][32] x 2 = 16 KiB  (x4 waves)
+template <int NT>
+__global__ __launch_bounds__(256) void k_tok1(const float* __restrict__ ctx, const uint8_t* __restrict__ mask,
+                                              float* __restrict__ x, AttnW wr, AttnW wc, int B, int R, int C,
+                                              int Epad, int skip_col) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* W0 = smem;               // Wo_row, later Wo_col
+  float* Wq_l = smem + 4096;
+  float* Wk_l = smem + 8192;
+  float* Wv_l = smem + 12288;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float* kvl = smem + 16384 + wave * 4096;   // [2][64][32]
+  stage_weight<64>(W0, wr.Wo, 64, tid, 256);
+  stage_weight<64>(Wq_l, wc.Wq, 64, tid, 256);
+  stage_weight<64>(Wk_l, wc.Wk, 64, tid, 256);
+  stage_weight<64>(Wv_l, wc.Wv, 64, tid, 256);
+  __syncthreads();
+  const long col = (long)blockIdx.x * 4 + wave;
+  const bool active = col < (long)B * C;
+  const int b = active ? (int)(col / C) : 0, c = active ? (int)(col % C) : 0;
+  const int tok = lane & 31, hh = lane >> 5;
+  const bool padded = active && mask && mask[(size_t)b * C + c];
+
+  f32x16 xr[NT][2];
+  if (active) {
+    // ---- row attention: out_proj(context) + residual
+    f32x16 cx[NT][2];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int r = 32 * nt + tok;
+      const bool valid = r < R;
+      load_token64(xr[nt], x + (((size_t)b * R + r) * C + c) * 64, valid, hh);
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int h = 4 * mt + g;
+          f32x4 v = {0.f, 0.f, 0.f, 0.f};
+          if (valid) v = *reinterpret_cast<const f32x4*>(ctx + (((size_t)b * NNJ_NHEAD + h) * C + c) * Epad + r * 8 + 4 * hh);
+          cx[nt][mt][4 * g + 0] = v[0]; cx[nt][mt][4 * g + 1] = v[1];
+          cx[nt][mt][4 * g + 2] = v[2]; cx[nt][mt][4 * g + 3] = v[3];
+        }
+    }
+    f32x16 o[NT][2];
+    linear_T<2, 2, NT>(o, cx, W0, wr.bo, lane);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) xr[nt][mt] += o[nt][mt];
+  }
+  __syncthreads();                           // everyone is done with Wo_row
+  stage_weight<64>(W0, wc.Wo, 64, tid, 256);
+  __syncthreads();
+  if (!active) return;
+  if (skip_col) {                            // debug tap: state after the row-attention block
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int r = 32 * nt + tok;
+      store_token64(xr[nt], x + (((size_t)b * R + r) * C + c) * 64, r < R, hh);
+    }
+    return;
+  }
+
+  // ---- column attention
+  f32x16 y[NT][2];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) layer_norm64(y[nt], xr[nt], wc.ln_w, wc.ln_b, hh);
+  f32x16 cx[NT][2];
+  if (R == 1) {
+    // single position: output = out_proj(v_proj(x)) (axial_attention.py:198-209)
+    linear_T<2, 2, NT>(cx, y, Wv_l, wc.bv, lane);
+  } else {
+    const float scaling = rsqrtf((float)NNJ_DH);      // axial_attention.py:214
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {                  // heads 4*hf .. 4*hf+3
+      f32x16 qh[NT][1], kh[NT][1], vh[NT][1];
+      linear_T<1, 2, NT>(qh, y, Wq_l + hf * 32 * 64, wc.bq + 32 * hf, lane);
+      linear_T<1, 2, NT>(kh, y, Wk_l + hf * 32 * 64, wc.bk + 32 * hf, lane);
+      linear_T<1, 2, NT>(vh, y, Wv_l + hf * 32 * 64, wc.bv + 32 * hf, lane);
+      // publish k,v of this head-half for all rows of the column (wave-private LDS)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int r = 32 * nt + tok;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          f32x4 k4 = {kh[nt][0][4 * g], kh[nt][0][4 * g + 1], kh[nt][0][4 * g + 2], kh[nt][0][4 * g + 3]};
+          f32x4 v4 = {vh[nt][0][4 * g], vh[nt][0][4 * g + 1], vh[nt][0][4 * g + 2], vh[nt][0][4 * g + 3]};
+          *reinterpret_cast<f32x4*>(kvl + r * 32 + 8 * g + 4 * hh) = k4;
+          *reinterpret_cast<f32x4*>(kvl + 2048 + r * 32 + 8 * g + 4 * hh) = v4;
+        }
+      }
+      // per (token, head): online softmax over the R keys of the column
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const float q0 = qh[nt][0][4 * g] * scaling, q1 = qh[nt][0][4 * g + 1] * scaling,
+                      q2 = qh[nt][0][4 * g + 2] * scaling, q3 = qh[nt][0][4 * g + 3] * scaling;
+          float m = -INFINITY, l = 0.f, a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+          for (int j = 0; j < R; ++j) {
+            const f32x4 kj = *reinterpret_cast<const f32x4*>(kvl + j * 32 + 8 * g + 4 * hh);
+            float s = q0 * kj[0] + q1 * kj[1] + q2 * kj[2] + q3 * kj[3];
+            s += __shfl_xor(s, 32);
+            if (padded) s = -10000.0f;             // every key of a padded column (axial_attention.py:220-224)
+            const float mn = fmaxf(m, s);
+            const float sc = nnj_exp(m - mn);
+            const float p = nnj_exp(s - mn);
+            const f32x4 vj = *reinterpret_cast<const f32x4*>(kvl + 2048 + j * 32 + 8 * g + 4 * hh);
+            l = l * sc + p;
+            a0 = a0 * sc + p * vj[0]; a1 = a1 * sc + p * vj[1];
+            a2 = a2 * sc + p * vj[2]; a3 = a3 * sc + p * vj[3];
+            m = mn;
+          }
+          const float inv = 1.0f / l;
+          cx[nt][hf][4 * g] = a0 * inv; cx[nt][hf][4 * g + 1] = a1 * inv;
+          cx[nt][hf][4 * g + 2] = a2 * inv; cx[nt][hf][4 * g + 3] = a3 * inv;
+        }
+    }
+  }
+  f32x16 o[NT][2];
+  linear_T<2, 2, NT>(o, cx, W0, wc.bo, lane);
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int r = 32 * nt + tok;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) xr[nt][mt] += o[nt][mt];
+    store_token64(xr[nt], x + (((size_t)b * R + r) * C + c) * 64, r < R, hh);
+  }
+}
+
+// ------------------------------------------------------------------ k_tok2
+// FFN block (reference msa_modules.py:147-151 inside 109-125), then optionally the
+// next layer's row-attention LN + q,k,v.
+//   LDS: 64 KiB: [W1 half 128x64 | W2 half 64x128], reused for Wq,Wk,Wv.
+template <int NT>
+__global__ __launch_bounds__(256) void k_tok2(float* __restrict__ x, const uint8_t* __restrict__ mask,
+                                              FfnW wf, AttnW wn, float* __restrict__ Q, float* __restrict__ K,
+                                              float* __restrict__ V, int B, int R, int C, int Epad,
+                                              int do_qkv) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* W1l = smem;            // [128][64]
+  float* W2l = smem + 8192;     // [64][128]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const long col = (long)blockIdx.x * 4 + wave;
+  const bool active = col < (long)B * C;
+  const int b = active ? (int)(col / C) : 0, c = active ? (int)(col % C) : 0;
+  const int tok = lane & 31, hh = lane >> 5;
+
+  // FFN per 32-token tile (keeps the live set under 256 VGPRs: x, out, 128 hidden units)
+  f32x16 xr[NT][2], out[NT][1][2], y[NT][1][2];
+  if (active) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int r = 32 * nt + tok;
+      load_token64(xr[nt], x + (((size_t)b * R + r) * C + c) * 64, r < R, hh);
+      layer_norm64(y[nt][0], xr[nt], wf.ln_w, wf.ln_b, hh);
+    }
+    // out starts as the fc2 bias
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 b4 = *reinterpret_cast<const f32x4*>(wf.b2 + 32 * mt + 8 * g + 4 * hh);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          out[nt][0][mt][4 * g] = b4[0]; out[nt][0][mt][4 * g + 1] = b4[1];
+          out[nt][0][mt][4 * g + 2] = b4[2]; out[nt][0][mt][4 * g + 3] = b4[3];
+        }
+      }
+  }
+#pragma unroll 1
+  for (int half = 0; half < 2; ++half) {
+    __syncthreads();
+    stage_weight<64>(W1l, wf.W1 + (size_t)half * 128 * 64, 128, tid, 256);
+    stage_weight_sub<256, 128>(W2l, wf.W2, 0, 64, half * 128, tid, 256);
+    __syncthreads();
+    if (active) {
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        f32x16 hdn[1][4];
+        linear_T<4, 2, 1>(hdn, y[nt], W1l, wf.b1 + half * 128, lane);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) hdn[0][mt][r] = gelu_erf(hdn[0][mt][r]);
+        linear_T_acc<2, 4, 1>(out[nt], hdn, W2l, lane);
+        __builtin_amdgcn_sched_barrier(0);     // keep the two token tiles' live ranges apart
+      }
+    }
+  }
+  if (active) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int r = 32 * nt + tok;
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) xr[nt][mt] += out[nt][0][mt];
+      store_token64(xr[nt], x + (((size_t)b * R + r) * C + c) * 64, r < R, hh);
+    }
+  }
+  if (!do_qkv) return;
+  __syncthreads();
+  float* Wq_l = smem;
+  float* Wk_l = smem + 4096;
+  float* Wv_l = smem + 8192;
+  stage_weight<64>(Wq_l, wn.Wq, 64, tid, 256);
+  stage_weight<64>(Wk_l, wn.Wk, 64, tid, 256);
+  stage_weight<64>(Wv_l, wn.Wv, 64, tid, 256);
+  __syncthreads();
+  if (!active) return;
+  const bool padded = mask && mask[(size_t)b * C + c];
+  row_qkv_stage<NT>(xr, wn, Wq_l, Wk_l, Wv_l, Q, K, V, b, c, C, R, Epad, padded, lane);
+}

@@ -1,0 +1,647 @@
+// nnj_scorer.hpp -- gfx950 kernels of the neural NJ loop: pair scorer, merged-row
+// aggregate, score-table assemble + argmax (restates reference model.py:90-209,
+// environment.py:760-835, utils.py:213-251, finetune_rl_search.py:140-160).
+//
+// Algebra (exact in real arithmetic, fp32 rounding differs from the reference by O(eps)):
+//   h   = W_h (x_i - x_j) + b_h          = U_i - U_j + b_h,          U_r  = W_h S_r
+//   q.k = (W_q x + b_q).(W_k S_r + b_k)  = x . K'_r + beta_r,        K'_r = A S_r + a0,
+//         A = W_q^T W_k, a0 = W_q^T b_k, beta_r = u . sum_c S_r[c] + C * t0,
+//         u = W_k^T b_q, t0 = b_q . b_k
+// so the per-pair W_h and W_q GEMMs of the reference become per-ROW transforms that are
+// cached next to each row (U, K', beta partials) and computed once when a row is born.
+//
+// Rows live in slots: S/U/Kp [B][slots][C][64]; `live[b][p]` maps the reference's row
+// position p (0..n-1, sorted) to a slot; a merge writes the new row into slot(live[i])
+// and deletes position j (reference environment.py:764-768).
+#pragma once
+#include "nnj_common.hpp"
+
+struct ScorerW {
+  const float *Wh, *bh;        // h_linear_last (weight [64][64], bias)
+  const float *Wg, *bg;        // g_linear_last
+  const float *A, *a0, *u;     // derived: W_q^T W_k, W_q^T b_k, W_k^T b_q
+  float t0;                    // b_q . b_k
+  const float *S0, *s0, *s2w;  // s_out.0 weight/bias, s_out.2 weight
+  float s2b;                   // s_out.2 bias
+};
+
+struct RowSet {                // where the rows of one call live
+  const float* S;              // [B][slots][C][64]
+  const float* U;
+  const float* Kp;
+  const float* beta_part;      // [B][slots][ntile32]
+  long bstride;                // floats between batch elements (slots*C*64)
+  const int* live;             // [B][live_stride] position -> slot, or nullptr = identity
+  int live_stride;
+  int ntile32;                 // ceil(C/32)
+};
+
+__device__ __forceinline__ int slot_of(const RowSet& rs, int b, int pos) {
+  return rs.live ? rs.live[b * rs.live_stride + pos] : pos;
+}
+
+enum { PAIRS_FULL = 0, PAIRS_INCR = 1 };
+
+// pair -> (position i, position j); returns false for padding lanes / the self pair
+__device__ __forceinline__ bool pair_of(int mode, int n, int p, int npairs, const int* ij_prev, int b,
+                                        int& pi, int& pj) {
+  pi = 0; pj = 1;
+  if (p >= npairs) return false;
+  if (mode == PAIRS_FULL) { pair_from_index(n, p, pi, pj); return true; }
+  const int ip = ij_prev[2 * b];
+  if (p == ip) return false;             // the reference scores (i,i) but never reads it (model.py:186-197)
+  pi = p < ip ? p : ip;
+  pj = p < ip ? ip : p;
+  return true;
+}
+
+// ---- stage the per-site images of all n rows into LDS (swizzled [64][64] images)
+// img_a <- A-operand source rows (Kp for phase A), img_s <- S, img_u <- U,
+// img_t <- S transposed [d][r] (optional)
+__device__ __forceinline__ void stage_site(const RowSet& rs, int b, int n, int C, int c, const float* srcA,
+                                           float* img_a, float* img_s, float* img_u, float* img_t,
+                                           int tid) {
+  for (int i = tid; i < 64 * 16; i += 256) {
+    const int r = i >> 4, ch = i & 15;
+    f32x4 va = {0.f, 0.f, 0.f, 0.f}, vs = va, vu = va;
+    if (r < n) {
+      const size_t off = (size_t)b * rs.bstride + ((size_t)slot_of(rs, b, r) * C + c) * 64 + 4 * ch;
+      vs = *reinterpret_cast<const f32x4*>(rs.S + off);
+      vu = *reinterpret_cast<const f32x4*>(rs.U + off);
+      if (img_a) va = *reinterpret_cast<const f32x4*>(srcA + off);
+    }
+    const int sw = 4 * wswz(r, ch);
+    *reinterpret_cast<f32x4*>(img_s + r * 64 + sw) = vs;
+    *reinterpret_cast<f32x4*>(img_u + r * 64 + sw) = vu;
+    if (img_a) *reinterpret_cast<f32x4*>(img_a + r * 64 + sw) = va;
+    if (img_t) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int d = 4 * ch + e;
+        img_t[d * 64 + 4 * wswz(d, r >> 2) + (r & 3)] = vs[e];
+      }
+    }
+  }
+}
+
+// gate: x = z*x_i + (1-z)*x_j, z = sigmoid(U_i - U_j + b_h)  (model.py:105-108)
+__device__ __forceinline__ void gate_tile(f32x16 (&x)[2], const float* img_s, const float* img_u,
+                                          const float* bh, int pi, int pj, int hh) {
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int ch = 2 * (4 * mt + g) + hh;
+      const f32x4 si = *reinterpret_cast<const f32x4*>(img_s + pi * 64 + 4 * wswz(pi, ch));
+      const f32x4 sj = *reinterpret_cast<const f32x4*>(img_s + pj * 64 + 4 * wswz(pj, ch));
+      const f32x4 ui = *reinterpret_cast<const f32x4*>(img_u + pi * 64 + 4 * wswz(pi, ch));
+      const f32x4 uj = *reinterpret_cast<const f32x4*>(img_u + pj * 64 + 4 * wswz(pj, ch));
+      const f32x4 b4 = *reinterpret_cast<const f32x4*>(bh + 4 * ch);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const float z = sigmoidf_(ui[t] - uj[t] + b4[t]);
+        x[mt][4 * g + t] = z * si[t] + (1.0f - z) * sj[t];
+      }
+    }
+}
+
+// ------------------------------------------------------------------ k_pair_alpha
+// Phase A: alpha_part[b][sc][pair][r] = sum_{c in chunk sc} x_pair[c,:] . K'_r[c,:]
+// grid (nsc, pair groups, B); 4 waves x TPW tiles of 32 pairs.
+template <int TPW>
+__global__ __launch_bounds__(256) void k_pair_alpha(RowSet rs, ScorerW w, const int* __restrict__ ij_prev,
+                                                    float* __restrict__ alpha_part, int mode, int n, int C,
+                                                    int npairs, int ppad, int cs) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* img_k = smem;
+  float* img_s = smem + 4096;
+  float* img_u = smem + 8192;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5;
+  const int sc = blockIdx.x, pg = blockIdx.y, b = blockIdx.z;
+  const int c0 = sc * cs, c1 = min(C, c0 + cs);
+  int pi[TPW], pj[TPW];
+  bool any = false;
+#pragma unroll
+  for (int tt = 0; tt < TPW; ++tt) {
+    const int p = ((pg * 4 + wave) * TPW + tt) * 32 + (lane & 31);
+    pair_of(mode, n, p, npairs, ij_prev, b, pi[tt], pj[tt]);
+    any = any || (((pg * 4 + wave) * TPW + tt) * 32 < npairs);
+  }
+  f32x16 acc[TPW][1][2];
+#pragma unroll
+  for (int tt = 0; tt < TPW; ++tt)
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[tt][0][mt][r] = 0.f;
+  for (int c = c0; c < c1; ++c) {
+    __syncthreads();
+    stage_site(rs, b, n, C, c, rs.Kp, img_k, img_s, img_u, nullptr, tid);
+    __syncthreads();
+    if (any) {
+#pragma unroll
+      for (int tt = 0; tt < TPW; ++tt) {
+        f32x16 x[1][2];
+        gate_tile(x[0], img_s, img_u, w.bh, pi[tt], pj[tt], hh);
+        linear_T_acc<2, 2, 1>(acc[tt], x, img_k, lane);
+      }
+    }
+  }
+#pragma unroll
+  for (int tt = 0; tt < TPW; ++tt) {
+    const int p = ((pg * 4 + wave) * TPW + tt) * 32 + (lane & 31);
+    if (p < ppad) {
+      float* dst = alpha_part + (((size_t)b * gridDim.x + sc) * ppad + p) * 64;
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          f32x4 v = {acc[tt][0][mt][4 * g], acc[tt][0][mt][4 * g + 1], acc[tt][0][mt][4 * g + 2],
+                     acc[tt][0][mt][4 * g + 3]};
+          *reinterpret_cast<f32x4*>(dst + 32 * mt + 8 * g + 4 * hh) = v;
+        }
+    }
+  }
+}
+
+// ------------------------------------------------------------------ k_alpha_softmax
+// alpha[b][pair][r] = softmax_r( (sum_sc part + beta_r) / sqrt(64*C) ), rows i, j of the
+// pair and r >= n excluded (model.py:118-146).  One wave per pair, lane = r.
+__global__ __launch_bounds__(256) void k_alpha_softmax(RowSet rs, ScorerW w, const int* __restrict__ ij_prev,
+                                                       const float* __restrict__ alpha_part,
+                                                       float* __restrict__ alpha, int mode, int n, int C,
+                                                       int npairs, int ppad, int nsc) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int p = blockIdx.x * 4 + wave, b = blockIdx.y;
+  if (p >= ppad) return;
+  int pi, pj;
+  const bool valid = pair_of(mode, n, p, npairs, ij_prev, b, pi, pj);
+  float a = 0.f;
+  for (int sc = 0; sc < nsc; ++sc) a += alpha_part[(((size_t)b * nsc + sc) * ppad + p) * 64 + lane];
+  float beta = 0.f;
+  if (lane < n) {
+    const float* bp = rs.beta_part + ((size_t)b * (rs.bstride / ((long)C * 64)) + slot_of(rs, b, lane)) * rs.ntile32;
+    for (int t = 0; t < rs.ntile32; ++t) beta += bp[t];
+    beta += (float)C * w.t0;
+  }
+  a = (a + beta) * (1.0f / sqrtf(64.0f * (float)C));
+  const bool in = valid && lane < n && lane != pi && lane != pj;
+  float v = in ? a : -INFINITY;
+  float mx = v;
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+  float e = in ? expf(v - mx) : 0.f;
+  float s = e;
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o);
+  alpha[((size_t)b * ppad + p) * 64 + lane] = (s > 0.f) ? e / s : 0.f;
+}
+
+// ------------------------------------------------------------------ k_pair_score
+// Phase B: per (pair, site): x_g = sum_r alpha_r S_r ; g = W_g x_g + b_g ; w = sigmoid(g);
+// x = (1-w) x + w x_g ; s = s_out(x) ; score_part[b][sc][pair] = sum_{c in chunk} mask_c s
+// (model.py:148-153, 93-97).  has_ctx = (n > 2) (model.py:111).
+template <int TPW>
+__global__ __launch_bounds__(256) void k_pair_score(RowSet rs, ScorerW w, const int* __restrict__ ij_prev,
+                                                    const float* __restrict__ alpha,
+                                                    const uint8_t* __restrict__ mask,
+                                                    float* __restrict__ score_part, int mode, int n, int C,
+                                                    int npairs, int ppad, int cs, int has_ctx) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* img_t = smem;            // S_c transposed [d][r]
+  float* img_s = smem + 4096;
+  float* img_u = smem + 8192;
+  float* Wg_l = smem + 12288;
+  float* S0_l = smem + 16384;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5;
+  const int sc = blockIdx.x, pg = blockIdx.y, b = blockIdx.z;
+  const int c0 = sc * cs, c1 = min(C, c0 + cs);
+  stage_weight<64>(Wg_l, w.Wg, 64, tid, 256);
+  stage_weight<64>(S0_l, w.S0, 64, tid, 256);
+  int pi[TPW], pj[TPW];
+  bool any = false;
+  f32x16 al[TPW][1][2];
+  float score[TPW];
+#pragma unroll
+  for (int tt = 0; tt < TPW; ++tt) {
+    const int tile = (pg * 4 + wave) * TPW + tt;
+    const int p = tile * 32 + (lane & 31);
+    pair_of(mode, n, p, npairs, ij_prev, b, pi[tt], pj[tt]);
+    any = any || (tile * 32 < npairs);
+    score[tt] = 0.f;
+    const bool ld = has_ctx && p < ppad;
+    load_token64(al[tt][0], alpha + ((size_t)b * ppad + p) * 64, ld, hh);
+  }
+  // s_out.2 weights for this lane's 32 features
+  float s2w[2][16];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(w.s2w + 32 * mt + 8 * g + 4 * hh);
+      s2w[mt][4 * g] = v[0]; s2w[mt][4 * g + 1] = v[1]; s2w[mt][4 * g + 2] = v[2]; s2w[mt][4 * g + 3] = v[3];
+    }
+  for (int c = c0; c < c1; ++c) {
+    __syncthreads();
+    stage_site(rs, b, n, C, c, nullptr, nullptr, img_s, img_u, has_ctx ? img_t : nullptr, tid);
+    __syncthreads();
+    const float mc = (mask && mask[(size_t)b * C + c]) ? 0.f : 1.f;   // seq_mask (model.py:96)
+    if (any) {
+#pragma unroll
+      for (int tt = 0; tt < TPW; ++tt) {
+        f32x16 x[1][2];
+        gate_tile(x[0], img_s, img_u, w.bh, pi[tt], pj[tt], hh);
+        if (has_ctx) {
+          f32x16 xg[1][2], g[1][2];
+          linear_T<2, 2, 1>(xg, al[tt], img_t, nullptr, lane);
+          linear_T<2, 2, 1>(g, xg, Wg_l, w.bg, lane);
+#pragma unroll
+          for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const float wg = sigmoidf_(g[0][mt][r]);
+              x[0][mt][r] = (1.0f - wg) * x[0][mt][r] + wg * xg[0][mt][r];
+            }
+        }
+        f32x16 s1[1][2];
+        linear_T<2, 2, 1>(s1, x, S0_l, w.s0, lane);
+        float s = 0.f;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) s += gelu_erf(s1[0][mt][r]) * s2w[mt][r];
+        s += __shfl_xor(s, 32);
+        score[tt] += (s + w.s2b) * mc;
+      }
+    }
+  }
+  if (hh == 0) {
+#pragma unroll
+    for (int tt = 0; tt < TPW; ++tt) {
+      const int p = ((pg * 4 + wave) * TPW + tt) * 32 + (lane & 31);
+      if (p < ppad) score_part[((size_t)b * gridDim.x + sc) * ppad + p] = score[tt];
+    }
+  }
+}
+
+// ------------------------------------------------------------------ row transforms
+// Tokens = sites.  For one row tile held feature-major in registers, write
+// U = W_h S, K' = A S + a0 and the beta partial of the wave's 32 sites.
+__device__ __forceinline__ void row_transforms(const f32x16 (&s)[1][2], const float* Wh_l, const float* A_l,
+                                               const ScorerW& w, float* U_row, float* Kp_row, float* beta_dst,
+                                               int c, bool valid, int lane) {
+  const int hh = lane >> 5;
+  f32x16 o[1][2];
+  linear_T<2, 2, 1>(o, s, Wh_l, nullptr, lane);
+  store_token64(o[0], U_row + (size_t)c * 64, valid, hh);
+  linear_T<2, 2, 1>(o, s, A_l, w.a0, lane);
+  store_token64(o[0], Kp_row + (size_t)c * 64, valid, hh);
+  float d = 0.f;
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const f32x4 u4 = *reinterpret_cast<const f32x4*>(w.u + 32 * mt + 8 * g + 4 * hh);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) d += u4[t] * s[0][mt][4 * g + t];
+    }
+  if (!valid) d = 0.f;
+#pragma unroll
+  for (int o2 = 32; o2 >= 1; o2 >>= 1) d += __shfl_xor(d, o2);
+  if (lane == 0) *beta_dst = d;
+}
+
+// k_row_xf: transforms of existing rows. grid (ceil(C/128), rows, B); wave = 32 sites.
+__global__ __launch_bounds__(256) void k_row_xf(const float* __restrict__ S, float* __restrict__ U,
+                                                float* __restrict__ Kp, float* __restrict__ beta_part,
+                                                ScorerW w, long bstride, int slots, int C, int ntile32) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Wh_l = smem;
+  float* A_l = smem + 4096;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  stage_weight<64>(Wh_l, w.Wh, 64, tid, 256);
+  stage_weight<64>(A_l, w.A, 64, tid, 256);
+  __syncthreads();
+  const int tile = blockIdx.x * 4 + wave, row = blockIdx.y, b = blockIdx.z;
+  if (tile >= ntile32) return;
+  const int c = tile * 32 + (lane & 31);
+  const bool valid = c < C;
+  const size_t roff = (size_t)b * bstride + (size_t)row * C * 64;
+  f32x16 s[1][2];
+  load_token64(s[0], S + roff + (size_t)c * 64, valid, lane >> 5);
+  row_transforms(s, Wh_l, A_l, w, U + roff, Kp + roff, beta_part + ((size_t)b * slots + row) * ntile32 + tile,
+                 c, valid, lane);
+}
+
+// ------------------------------------------------------------------ merged-row aggregate
+// k_agg_alpha: alpha partials of the ONE merged pair per batch element (VALU stream).
+// part[b][chunk][r] = sum_{c in chunk} x[c,:] . K'_r[c,:]; chunk = 16 sites.
+__global__ __launch_bounds__(256) void k_agg_alpha(RowSet rs, ScorerW w, const int* __restrict__ ij,
+                                                   float* __restrict__ part, int n, int C) {
+  __shared__ __attribute__((aligned(16))) float xl[1024];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int chunk = blockIdx.x, b = blockIdx.y;
+  const int pi = ij[2 * b], pj = ij[2 * b + 1];
+  const size_t bo = (size_t)b * rs.bstride;
+  const size_t oi = bo + (size_t)slot_of(rs, b, pi) * C * 64, oj = bo + (size_t)slot_of(rs, b, pj) * C * 64;
+  const int e = tid * 4;                       // element within the chunk: site e/64, feature e%64
+  const int c = chunk * 16 + (e >> 6);
+  f32x4 x = {0.f, 0.f, 0.f, 0.f};
+  if (c < C) {
+    const size_t off = (size_t)c * 64 + (e & 63);
+    const f32x4 si = *reinterpret_cast<const f32x4*>(rs.S + oi + off);
+    const f32x4 sj = *reinterpret_cast<const f32x4*>(rs.S + oj + off);
+    const f32x4 ui = *reinterpret_cast<const f32x4*>(rs.U + oi + off);
+    const f32x4 uj = *reinterpret_cast<const f32x4*>(rs.U + oj + off);
+    const f32x4 b4 = *reinterpret_cast<const f32x4*>(w.bh + (e & 63));
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const float z = sigmoidf_(ui[t] - uj[t] + b4[t]);
+      x[t] = z * si[t] + (1.0f - z) * sj[t];
+    }
+  }
+  *reinterpret_cast<f32x4*>(xl + e) = x;
+  __syncthreads();
+  const int nch = gridDim.x;
+  for (int r = wave; r < n; r += 4) {
+    const size_t orow = bo + (size_t)slot_of(rs, b, r) * C * 64 + (size_t)chunk * 16 * 64;
+    float acc = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int ee = (k * 64 + lane) * 4;
+      const int cc = chunk * 16 + (ee >> 6);
+      if (cc < C) {
+        const f32x4 kv = *reinterpret_cast<const f32x4*>(rs.Kp + orow + ee);
+        const f32x4 xv = *reinterpret_cast<const f32x4*>(xl + ee);
+        acc += xv[0] * kv[0] + xv[1] * kv[1] + xv[2] * kv[2] + xv[3] * kv[3];
+      }
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) acc += __shfl_xor(acc, o);
+    if (lane == 0) part[((size_t)b * nch + chunk) * 64 + r] = acc;
+  }
+}
+
+// k_agg_finish: softmax of the merged pair's alpha, x_g, gate, new row; writes the row
+// (and, when U_out != nullptr, its cached transforms).  Tokens = sites; grid (ceil(C/128), B).
+//   out_row(b) = out_base + b*out_bstride + out_slot(b)*C*64 where out_slot = live[pi]
+//   (in place, environment.py:764-768) or 0 for the dense one-row output of nnj_aggregate.
+__global__ __launch_bounds__(256) void k_agg_finish(RowSet rs, ScorerW w, const int* __restrict__ ij,
+                                                    const float* __restrict__ part, int nch, float* S_out,
+                                                    float* U_out, float* Kp_out, float* beta_out,
+                                                    long out_bstride, int out_slots, int in_place, int n, int C) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Wg_l = smem;
+  float* Wh_l = smem + 4096;
+  float* A_l = smem + 8192;
+  float* al = smem + 12288;       // alpha[64]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5;
+  const int b = blockIdx.y;
+  const int pi = ij[2 * b], pj = ij[2 * b + 1];
+  stage_weight<64>(Wg_l, w.Wg, 64, tid, 256);
+  if (U_out) {
+    stage_weight<64>(Wh_l, w.Wh, 64, tid, 256);
+    stage_weight<64>(A_l, w.A, 64, tid, 256);
+  }
+  const bool has_ctx = n > 2;                       // model.py:111
+  if (wave == 0) {
+    float a = -INFINITY;
+    const bool in = has_ctx && lane < n && lane != pi && lane != pj;
+    if (in) {
+      float s = 0.f;
+      for (int ch = 0; ch < nch; ++ch) s += part[((size_t)b * nch + ch) * 64 + lane];
+      const float* bp = rs.beta_part + ((size_t)b * (rs.bstride / ((long)C * 64)) + slot_of(rs, b, lane)) * rs.ntile32;
+      float beta = 0.f;
+      for (int t = 0; t < rs.ntile32; ++t) beta += bp[t];
+      beta += (float)C * w.t0;
+      a = (s + beta) * (1.0f / sqrtf(64.0f * (float)C));
+    }
+    float mx = a;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    float e = in ? expf(a - mx) : 0.f;
+    float s = e;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o);
+    al[lane] = (s > 0.f) ? e / s : 0.f;
+  }
+  __syncthreads();
+  const int tile = blockIdx.x * 4 + wave;
+  if (tile * 32 >= C) return;
+  const int c = tile * 32 + (lane & 31);
+  const bool valid = c < C;
+  const size_t bo = (size_t)b * rs.bstride;
+  const int slot_i = slot_of(rs, b, pi), slot_j = slot_of(rs, b, pj);
+  f32x16 x[1][2], xg[1][2];
+  {
+    f32x16 si[2], sj[2], ui[2], uj[2];
+    load_token64(si, rs.S + bo + ((size_t)slot_i * C + c) * 64, valid, hh);
+    load_token64(sj, rs.S + bo + ((size_t)slot_j * C + c) * 64, valid, hh);
+    load_token64(ui, rs.U + bo + ((size_t)slot_i * C + c) * 64, valid, hh);
+    load_token64(uj, rs.U + bo + ((size_t)slot_j * C + c) * 64, valid, hh);
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 b4 = *reinterpret_cast<const f32x4*>(w.bh + 32 * mt + 8 * g + 4 * hh);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const float z = sigmoidf_(ui[mt][4 * g + t] - uj[mt][4 * g + t] + b4[t]);
+          x[0][mt][4 * g + t] = z * si[mt][4 * g + t] + (1.0f - z) * sj[mt][4 * g + t];
+        }
+      }
+  }
+  if (has_ctx) {
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) xg[0][mt][r] = 0.f;
+    for (int r = 0; r < n; ++r) {
+      const float a = al[r];
+      if (a == 0.f) continue;                        // rows i, j carry exactly zero weight
+      f32x16 sr[2];
+      load_token64(sr, rs.S + bo + ((size_t)slot_of(rs, b, r) * C + c) * 64, valid, hh);
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) xg[0][mt] += a * sr[mt];
+    }
+    f32x16 g[1][2];
+    linear_T<2, 2, 1>(g, xg, Wg_l, w.bg, lane);
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float wg = sigmoidf_(g[0][mt][r]);
+        x[0][mt][r] = (1.0f - wg) * x[0][mt][r] + wg * xg[0][mt][r];
+      }
+  }
+  const int oslot = in_place ? slot_i : 0;
+  const size_t oo = (size_t)b * out_bstride + (size_t)oslot * C * 64;
+  store_token64(x[0], S_out + oo + (size_t)c * 64, valid, hh);
+  if (U_out)
+    row_transforms(x, Wh_l, A_l, w, U_out + oo, Kp_out + oo,
+                   beta_out + ((size_t)b * out_slots + oslot) * rs.ntile32 + tile, c, valid, lane);
+}
+
+// ------------------------------------------------------------------ table assemble + argmax
+// One workgroup per batch element.  new/first scores = fixed-order sum of score parts;
+// table via the old->new index map (utils.py:227-247) from logits_prev; argmax with
+// first-maximal-index tie break (finetune_rl_search.py:145); flat -> (i,j)
+// (environment.py:457-462).
+__global__ __launch_bounds__(256) void k_assemble_argmax(const float* __restrict__ score_part, int nsc, int ppad,
+                                                         const float* __restrict__ logits_prev,
+                                                         const int* ij_prev,
+                                                         float* __restrict__ logits_out,
+                                                         float* __restrict__ trace_out, long trace_bstride,
+                                                         const int* __restrict__ forced, long forced_bstride,
+                                                         int* __restrict__ merges_out, long merges_bstride,
+                                                         float* __restrict__ gap_out, long gap_bstride,
+                                                         int* ij_cur, int mode, int n) {
+  __shared__ float newsc[64];
+  __shared__ float red_v[256];
+  __shared__ int red_i[256];
+  const int tid = threadIdx.x, b = blockIdx.x;
+  const int np = num_pairs(n), np_prev = num_pairs(n + 1);
+  int ip = 0, jp = 0;
+  if (mode == PAIRS_INCR) {
+    ip = ij_prev[2 * b]; jp = ij_prev[2 * b + 1];
+    if (tid < n) {
+      float s = 0.f;
+      for (int sc = 0; sc < nsc; ++sc) s += score_part[((size_t)b * nsc + sc) * ppad + tid];
+      newsc[tid] = s;
+    }
+    __syncthreads();
+  }
+  float best = -INFINITY;
+  int besti = 0x7fffffff;
+  for (int p = tid; p < np; p += 256) {
+    float v;
+    if (mode == PAIRS_FULL) {
+      v = 0.f;
+      for (int sc = 0; sc < nsc; ++sc) v += score_part[((size_t)b * nsc + sc) * ppad + p];
+    } else {
+      int ii, jj;
+      pair_from_index(n, p, ii, jj);
+      if (ii == ip) v = newsc[jj];
+      else if (jj == ip) v = newsc[ii];
+      else v = logits_prev[(size_t)b * np_prev + pair_index(n + 1, ii + (ii >= jp), jj + (jj >= jp))];
+    }
+    logits_out[(size_t)b * np + p] = v;
+    if (trace_out) trace_out[(size_t)b * trace_bstride + p] = v;
+    if (v > best || (v == best && p < besti)) { best = v; besti = p; }
+  }
+  red_v[tid] = best; red_i[tid] = besti;
+  __syncthreads();
+  for (int s = 128; s >= 1; s >>= 1) {
+    if (tid < s) {
+      const float v2 = red_v[tid + s]; const int i2 = red_i[tid + s];
+      if (v2 > red_v[tid] || (v2 == red_v[tid] && i2 < red_i[tid])) { red_v[tid] = v2; red_i[tid] = i2; }
+    }
+    __syncthreads();
+  }
+  const int bi = red_i[0];
+  const float bv = red_v[0];
+  __syncthreads();
+  // second best for the top-2 gap
+  float second = -INFINITY;
+  for (int p = tid; p < np; p += 256)
+    if (p != bi) second = fmaxf(second, logits_out[(size_t)b * np + p]);
+  red_v[tid] = second;
+  __syncthreads();
+  for (int s = 128; s >= 1; s >>= 1) {
+    if (tid < s) red_v[tid] = fmaxf(red_v[tid], red_v[tid + s]);
+    __syncthreads();
+  }
+  if (tid == 0) {
+    int ci, cj;
+    pair_from_index(n, bi, ci, cj);
+    if (merges_out) { merges_out[(size_t)b * merges_bstride] = ci; merges_out[(size_t)b * merges_bstride + 1] = cj; }
+    if (gap_out) gap_out[(size_t)b * gap_bstride] = np > 1 ? bv - red_v[0] : 0.f;
+    if (forced) { ci = forced[(size_t)b * forced_bstride]; cj = forced[(size_t)b * forced_bstride + 1]; }
+    ij_cur[2 * b] = ci; ij_cur[2 * b + 1] = cj;
+  }
+}
+
+// argmax of a given table (finetune_rl_search.py:145,159-160): ij_out [B][2], gap [B] optional
+__global__ __launch_bounds__(256) void k_select_pair(const float* __restrict__ logits, int* __restrict__ ij_out,
+                                                     float* __restrict__ gap_out, int n) {
+  __shared__ float red_v[256];
+  __shared__ int red_i[256];
+  const int tid = threadIdx.x, b = blockIdx.x;
+  const int np = num_pairs(n);
+  const float* l = logits + (size_t)b * np;
+  float best = -INFINITY;
+  int besti = 0x7fffffff;
+  for (int p = tid; p < np; p += 256) {
+    const float v = l[p];
+    if (v > best || (v == best && p < besti)) { best = v; besti = p; }
+  }
+  red_v[tid] = best; red_i[tid] = besti;
+  __syncthreads();
+  for (int s = 128; s >= 1; s >>= 1) {
+    if (tid < s) {
+      const float v2 = red_v[tid + s]; const int i2 = red_i[tid + s];
+      if (v2 > red_v[tid] || (v2 == red_v[tid] && i2 < red_i[tid])) { red_v[tid] = v2; red_i[tid] = i2; }
+    }
+    __syncthreads();
+  }
+  const int bi = red_i[0];
+  const float bv = red_v[0];
+  __syncthreads();
+  float second = -INFINITY;
+  for (int p = tid; p < np; p += 256)
+    if (p != bi) second = fmaxf(second, l[p]);
+  red_v[tid] = second;
+  __syncthreads();
+  for (int s = 128; s >= 1; s >>= 1) {
+    if (tid < s) red_v[tid] = fmaxf(red_v[tid], red_v[tid + s]);
+    __syncthreads();
+  }
+  if (tid == 0) {
+    int ci, cj;
+    pair_from_index(n, bi, ci, cj);
+    ij_out[2 * b] = ci; ij_out[2 * b + 1] = cj;
+    if (gap_out) gap_out[b] = np > 1 ? bv - red_v[0] : 0.f;
+  }
+}
+
+// live list: drop position j (merged row stays in position i's slot) -- environment.py:764-768
+__global__ void k_update_live(int* __restrict__ live, int live_stride, const int* __restrict__ ij, int B, int n) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const int pj = ij[2 * b + 1];
+  int* l = live + (size_t)b * live_stride;
+  for (int p = pj; p < n - 1; ++p) l[p] = l[p + 1];
+}
+__global__ void k_init_live(int* __restrict__ live, int live_stride, int B, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * live_stride) return;
+  live[i] = i % live_stride;
+}
+
+// utils.get_score_indices_to_prev on the device (utils.py:213-251): idx int64 [B][P(n)]
+__global__ void k_index_map(const int* __restrict__ ij_prev, long long* __restrict__ idx, int B, int n) {
+  const int np = num_pairs(n);
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)B * np) return;
+  const int b = (int)(i / np), p = (int)(i % np);
+  const int ip = ij_prev[2 * b], jp = ij_prev[2 * b + 1];
+  int ii, jj;
+  pair_from_index(n, p, ii, jj);
+  long long v;
+  if (ii == ip) v = num_pairs(n + 1) + jj;
+  else if (jj == ip) v = num_pairs(n + 1) + ii;
+  else v = pair_index(n + 1, ii + (ii >= jp), jj + (jj >= jp));
+  idx[i] = v;
+}
+
+// dense compaction for the API-compatible env.step: out[b][t] = (t == i ? merged : state[b][src])
+__global__ void k_compact_rows(const float* __restrict__ state, const float* __restrict__ merged,
+                               const int* __restrict__ ij, float* __restrict__ out, int n, long row_f4) {
+  const int t = blockIdx.y, b = blockIdx.z;     // output row t in [0, n-1)
+  const int pi = ij[2 * b], pj = ij[2 * b + 1];
+  const int src = t < pj ? t : t + 1;
+  const f32x4* s = (t == pi) ? reinterpret_cast<const f32x4*>(merged) + (size_t)b * row_f4
+                             : reinterpret_cast<const f32x4*>(state) + ((size_t)b * n + src) * row_f4;
+  f32x4* d = reinterpret_cast<f32x4*>(out) + ((size_t)b * (n - 1) + t) * row_f4;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < row_f4; i += (long)gridDim.x * blockDim.x) d[i] = s[i];
+}

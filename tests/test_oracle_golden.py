@@ -1,0 +1,79 @@
+"""Pins the CPU oracle (oracle/nnj_oracle.c) to vectors captured from the reference
+itself (tests/golden/gen_golden.py).  CPU only."""
+import numpy as np
+import pytest
+
+from helpers import (assert_logits_close, golden_names, load_golden, onehot_f32, split_trace)
+from oracle_lib import Oracle
+
+SMALL = golden_names(max_taxa=20)
+BIG = golden_names(min_taxa=21)
+
+
+def _check(name, precision="f32"):
+    z, cfgs, packed = load_golden(name)
+    o = Oracle(cfgs, packed, precision)
+    oh, mask = onehot_f32(z["codes"]), z["mask"]
+    B, T, L = z["codes"].shape
+    if "sub_embed" in z.files:
+        enc, taps = o.encode(oh, mask, taps=True)
+        np.testing.assert_allclose(taps[0], z["sub_embed"], atol=2e-6)
+        for i, k in enumerate(("sub_l0_row", "sub_l0_col", "sub_l0_ffn")):
+            np.testing.assert_allclose(taps[i + 1], z[k].transpose(2, 0, 1, 3), atol=3e-5)
+    # teacher-forced: the oracle follows the reference's merges, every table must match
+    r = o.rollout_argmax(oh, mask, forced_merges=z["merges"], want_state=True)
+    if "enc" in z.files:
+        np.testing.assert_allclose(r["state"], z["enc"], atol=1e-4 * np.abs(z["enc"]).max())
+    else:
+        np.testing.assert_allclose(r["state"][:, ::7, ::61, :], z["enc_slice"],
+                                   atol=1e-4 * np.abs(z["enc_slice"]).max())
+        assert abs(r["state"].astype(np.float64).sum() - float(z["enc_checksum"])) \
+            <= 1e-5 * float(z["enc_abs_checksum"])
+    assert_logits_close(r["logits"], z["logits"], rel=1e-4)
+    # argmax of each table: must agree wherever the reference's own top-2 gap is decisive
+    scale = np.abs(z["logits"]).max()
+    decisive = z["top2_gap"] > 4e-4 * scale
+    assert (r["merges"][decisive] == z["merges"][decisive]).all()
+    return o, z, oh, mask
+
+
+@pytest.mark.parametrize("name", SMALL)
+def test_oracle_matches_reference_small(name):
+    o, z, oh, mask = _check(name)
+    # free-running rollout reproduces the reference's merge list when no step is a near-tie
+    scale = np.abs(z["logits"]).max()
+    if (z["top2_gap"][:, :-1] > 4e-4 * scale).all():
+        r = o.rollout_argmax(oh, mask)
+        assert (r["merges"] == z["merges"]).all()
+
+
+@pytest.mark.parametrize("name", BIG[:2])
+def test_oracle_matches_reference_50x1024(name):
+    _check(name)
+
+
+@pytest.mark.parametrize("name", SMALL[:3])
+def test_oracle_f64_agrees(name):
+    _check(name, "f64")
+
+
+def test_component_entry_points_consistent():
+    """decode_full / decode_incr / env_step / select_pair compose to the rollout."""
+    z, cfgs, packed = load_golden("synth_b2_t8_l128_s1")
+    o = Oracle(cfgs, packed)
+    oh, mask = onehot_f32(z["codes"]), z["mask"]
+    B, T, L = z["codes"].shape
+    state = o.encode(oh, mask)
+    ref_tables = split_trace(z["logits"], T)
+    logits = o.pair_scores_full(state, mask)
+    assert_logits_close(logits, ref_tables[0])
+    for step, n in enumerate(range(T, 2, -1)):
+        ij, _ = o.select_pair(logits, n)
+        assert (ij == z["merges"][:, step]).all()
+        state = o.env_step(state, ij)
+        idx = o.score_index_map(ij, n - 1)
+        logits_new, new = o.pair_scores_incr(state, mask, ij, logits, want_new=True)
+        cat = np.concatenate([logits, new], 1)
+        assert np.array_equal(np.take_along_axis(cat, idx, 1), logits_new)
+        assert_logits_close(logits_new, ref_tables[step + 1])
+        logits = logits_new
