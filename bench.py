@@ -1,0 +1,195 @@
+#!/usr/bin/env python3
+"""Throughput benchmark of the Argmax hot path (encoder + neural NJ loop) on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W        (N=1)
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A step = one device-resident Argmax rollout (nnj_rollout_argmax) of one batch of
+synthetic 50-taxa x 1024-site MSAs per GPU, site codes already in HBM, merge lists
+copied back to the host at the end of the step.  Batches of independent MSAs are sharded
+over the ranks with no data-path collective (weak scaling: 256 MSAs per GPU).
+Rank 0 prints ONE JSON line (contract in the task statement); extra objects:
+  roofline     : dominant kernel (by HIP-event time inside the timed region)
+  cpu_baseline : the CPU oracle ("port") timed on this host's cores on a bounded sample
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+from neuralnj_amd import synth, utils, weights  # noqa: E402
+from neuralnj_amd._lib import Nnj  # noqa: E402
+
+PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 / 16x16x4_f32
+PEAK_HBM_GBS = 8000.0
+
+
+def kernel_models(B, T, L, layers):
+    """ALGORITHMIC FLOPs and HBM bytes PER LAUNCH of each kernel kind: SURVEY.md section 8(d)'s
+    per-tree formulas split by kernel x the B trees one launch processes.
+    For the per-step NJ kernels (48 launches of different n per rollout) the figure is the
+    mean over n = T-1..2."""
+    C, D, F = L, 64, 256
+    N = T * C
+    E = ((T * 8 + 15) // 16) * 16
+    P = T * (T - 1) // 2
+    row = C * D * 4
+    m = {}
+    m["k_row_attn"] = dict(flops=B * 4.0 * C * C * T * D, bytes=B * 4.0 * 8 * C * E * 4)
+    m["k_tok1"] = dict(flops=B * (N * 10.0 * D * D + 4.0 * T * T * C * D), bytes=B * 3.0 * N * D * 4)
+    m["k_tok2"] = dict(flops=B * N * (4.0 * D * F + 6.0 * D * D), bytes=B * 5.0 * N * D * 4)
+    m["k_embed_qkv"] = dict(flops=B * N * (6.0 * D * D + 8.0 * D + 2.0 * D * D), bytes=B * (N + 4.0 * N * D * 4))
+    # reference per (pair, site): W_h 2D^2, W_q 2D^2, alpha 2nD | x_g 2nD, W_g 2D^2, s_out 2D^2+2D
+    m["k_pair_alpha"] = dict(flops=B * P * C * (4.0 * D * D + 2.0 * T * D), bytes=B * 3.0 * T * row)
+    m["k_pair_score"] = dict(flops=B * P * C * (2.0 * T * D + 4.0 * D * D + 2.0 * D), bytes=B * 2.0 * T * row)
+    ns = list(range(T - 1, 1, -1))
+    m["k_pair_alpha_incr"] = dict(flops=B * sum(n * C * (4.0 * D * D + 2.0 * n * D) for n in ns if n > 2) / max(1, len([n for n in ns if n > 2])),
+                                  bytes=B * sum(3.0 * n * row for n in ns) / len(ns))
+    m["k_pair_score_incr"] = dict(flops=B * sum(n * C * (2.0 * n * D + 4.0 * D * D + 2.0 * D) for n in ns) / len(ns),
+                                  bytes=B * sum(2.0 * n * row for n in ns) / len(ns))
+    return m
+
+
+def cpu_baseline(cfgs, packed, T, L, budget_s=20.0):
+    """Times the CPU oracle (oracle/nnj_oracle.c, kind "port") on all host cores."""
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    from oracle_lib import Oracle
+    o = Oracle(cfgs, packed)
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = o.set_threads(min(cores, 16))    # the GPU box's CPU share per GPU
+    codes = synth.synth_codes(1, T, L, seed=4242, gap_frac=0.2)
+    oh = synth.codes_to_onehot(codes).astype(np.float32)
+    mask = np.zeros((1, L), dtype=bool)
+    n, t0 = 0, time.time()
+    while True:
+        o.rollout_argmax(oh, mask)
+        n += 1
+        el = time.time() - t0
+        if el >= budget_s or n >= 6:
+            break
+    return dict(value=n / el, unit="trees/sec", cores=cores, kind="port",
+                sample=f"{n} single-MSA Argmax rollouts of {T} taxa x {L} sites, fp32 OpenMP oracle, {el:.1f} s")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=256, help="MSAs per GPU per step")
+    ap.add_argument("--taxa", type=int, default=50)
+    ap.add_argument("--sites", type=int, default=1024)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel HIP events")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        dist = dist_mod
+        dist.init_process_group("nccl", device_id=dev)
+
+    cfgs = utils.shipped_config()
+    packed = weights.pack(cfgs, weights.seeded_state(cfgs, 0, "sharp"))
+    # weights: rank 0's copy is broadcast once over RCCL so every rank provably runs the same model
+    wt = torch.from_numpy(packed).to(dev)
+    if dist is not None:
+        dist.broadcast(wt, src=0)
+    g = Nnj(cfgs, dev)
+    g.load_weights(wt.cpu().numpy())
+
+    B, T, L = args.batch, args.taxa, args.sites
+    codes = torch.from_numpy(synth.synth_codes(B, T, L, seed=1000 + rank, gap_frac=0.2)).to(dev)
+    mask = torch.zeros((B, L), dtype=torch.uint8, device=dev)
+    g.workspace(B, T, L)
+
+    def step():
+        r = g.rollout_argmax(codes, mask)
+        return r["merges"].cpu()          # merge lists to the host (ends the step)
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    if not args.no_profile:
+        g.profile_enable(True)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        merges = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    prof = {} if args.no_profile else g.profile_read()
+    if not args.no_profile:
+        g.profile_enable(False)
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        # merge lists of all shards gathered on every rank (the only result exchange of the path)
+        gathered = [torch.empty_like(merges, device=dev) for _ in range(world)]
+        dist.all_gather(gathered, merges.to(dev))
+    trees = world * B * args.steps
+    out = {
+        "metric": "trees/sec (Argmax) on 50-taxa x 1024-site MSAs",
+        "value": trees / elapsed, "unit": "trees/sec", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"Batch={B} synthetic {T}x{L} MSAs per GPU, Argmax rollout (BASELINE configs[2]; "
+                               f"configs[3] when sharded over 8 GPUs)",
+                   "batch_per_gpu": B, "taxa": T, "sites": L, "gap_frac": 0.2, "model": "dim64 heads8 layers6 patch1",
+                   "weights": "seeded random (no checkpoint ships with the reference)"},
+    }
+    if rank == 0:
+        roof = None
+        if prof:
+            models = kernel_models(B, T, L, int(cfgs.model.num_enc_layers))
+            name, (ms, cnt) = max(prof.items(), key=lambda kv: kv[1][0])
+            total_ms = sum(v[0] for v in prof.values())
+            if name in models and cnt > 0:
+                avg_s = ms / cnt / 1e3
+                ach = models[name]["flops"] / avg_s / 1e12
+                traffic = None
+                tpath = os.path.join(REPO, "profiles", "traffic.json")
+                if os.path.exists(tpath):
+                    traffic = json.load(open(tpath)).get(name, {}).get("hbm_bytes_per_launch")
+                roof = {"kernel": name, "bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS,
+                        "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
+                        "avg_launch_ms": ms / cnt, "launches": cnt,
+                        "share_of_kernel_time": ms / total_ms if total_ms else None,
+                        "algorithmic_flops_per_launch": models[name]["flops"],
+                        "algorithmic_bytes_per_launch": models[name]["bytes"]}
+            out["kernel_ms_per_step"] = {k: round(v[0] / args.steps, 3) for k, v in prof.items() if v[1]}
+        out["roofline"] = roof
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cfgs, packed, T, L)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -17,11 +17,13 @@ namespace {
 
 enum ProfKind {
   PK_EMBED_QKV = 0, PK_ROW_ATTN, PK_TOK1, PK_TOK2, PK_ROW_XF, PK_PAIR_ALPHA, PK_ALPHA_SOFTMAX,
-  PK_PAIR_SCORE, PK_ASSEMBLE, PK_AGG_ALPHA, PK_AGG_FINISH, PK_MISC, PK_COUNT
+  PK_PAIR_SCORE, PK_ASSEMBLE, PK_AGG_ALPHA, PK_AGG_FINISH, PK_MISC, PK_PAIR_ALPHA_INCR, PK_PAIR_SCORE_INCR,
+  PK_COUNT
 };
 const char* const kProfNames[PK_COUNT] = {
     "k_embed_qkv", "k_row_attn", "k_tok1", "k_tok2", "k_row_xf", "k_pair_alpha", "k_alpha_softmax",
-    "k_pair_score", "k_assemble_argmax", "k_agg_alpha", "k_agg_finish", "misc"};
+    "k_pair_score", "k_assemble_argmax", "k_agg_alpha", "k_agg_finish", "misc", "k_pair_alpha_incr",
+    "k_pair_score_incr"};
 
 char g_err[512] = "";
 
@@ -277,7 +279,7 @@ int launch_pair_scores(nnj_handle* h, const RowSet& rs, const int* ij_prev, cons
   const dim3 grid((unsigned)g.nsc, (unsigned)g.pg, (unsigned)B);
   if (has_ctx) {
     {
-      Scope sc(h, st, PK_PAIR_ALPHA);
+      Scope sc(h, st, mode == PAIRS_FULL ? PK_PAIR_ALPHA : PK_PAIR_ALPHA_INCR);
       const size_t lds = 3 * 4096 * sizeof(float);
       if (g.tpw == 2)
         hipLaunchKernelGGL(k_pair_alpha<2>, grid, dim3(256), lds, st, rs, sw, ij_prev, base + w.alpha_part, mode, n, C,
@@ -293,7 +295,7 @@ int launch_pair_scores(nnj_handle* h, const RowSet& rs, const int* ij_prev, cons
     }
   }
   {
-    Scope sc(h, st, PK_PAIR_SCORE);
+    Scope sc(h, st, mode == PAIRS_FULL ? PK_PAIR_SCORE : PK_PAIR_SCORE_INCR);
     const size_t lds = 5 * 4096 * sizeof(float);
     if (g.tpw == 2) {
       if (int rc = set_lds(h, k_pair_score<2>, lds)) return rc;

@@ -1,0 +1,206 @@
+"""PhyInferEnv: host mirror of the environment surface the Argmax path touches
+(reference environment.py:444-898).  Tree bookkeeping is re-stated minimally: a subtree
+is a small object with the attributes the reference's callers read (seq_indices,
+left_tree_data/right_tree_data, name, log_score); Newick / topology strings follow
+reference environment.py:263-304 exactly (", " separators, 0.12345 dummy lengths)."""
+from __future__ import annotations
+
+import itertools
+from typing import List
+
+import numpy as np
+import torch
+
+DUMMY_BRANCH = 0.12345          # reference environment.py:288
+NO_SCORE = -111111              # reference environment.py:686
+
+CHARACTERS_MAPS = {
+    "DNA_WITH_GAP": {"A": [1., 0., 0., 0.], "C": [0., 1., 0., 0.], "G": [0., 0., 1., 0.],
+                     "T": [0., 0., 0., 1.], "-": [1., 1., 1., 1.], "N": [1., 1., 1., 1.]},
+}
+CHARACTERS_MAPS["DNA"] = {k: v for k, v in CHARACTERS_MAPS["DNA_WITH_GAP"].items() if k != "-"}
+
+
+class PhyloTree:
+    """Rooted binary subtree; children ordered by their smallest leaf index
+    (reference environment.py:79-83)."""
+
+    def __init__(self, at_root, left_tree_data=None, right_tree_data=None, root_seq_data=None, name="",
+                 device="cpu"):
+        self.at_root = at_root
+        self.name = name
+        self.log_score = None
+        if root_seq_data is not None:
+            self.left_tree_data = self.right_tree_data = None
+            self.seq_indices = list(root_seq_data)
+            self.log_score = 0
+        else:
+            if left_tree_data["tree"].seq_indices[0] > right_tree_data["tree"].seq_indices[0]:
+                left_tree_data, right_tree_data = right_tree_data, left_tree_data
+            self.left_tree_data, self.right_tree_data = left_tree_data, right_tree_data
+            self.seq_indices = sorted(left_tree_data["tree"].seq_indices + right_tree_data["tree"].seq_indices)
+        self.min_seq_index = self.seq_indices[0]
+
+    @property
+    def is_leaf(self):
+        return self.left_tree_data is None
+
+    @property
+    def is_internal(self):
+        return self.left_tree_data is not None
+
+
+class UnrootedPhyloTree(PhyloTree):
+    """Final tree; same children, plus topo_repr (reference environment.py:203-221)."""
+
+    def __init__(self, rooted: PhyloTree):
+        self.at_root = True
+        self.name = rooted.name
+        self.left_tree_data, self.right_tree_data = rooted.left_tree_data, rooted.right_tree_data
+        self.seq_indices = rooted.seq_indices
+        self.min_seq_index = rooted.min_seq_index
+        self.log_score = rooted.log_score
+        self.topo_repr = format_rtree_topology(self, True, None)
+
+
+def format_rtree_topology(tree, at_root=False, sequence_keys=None):
+    if tree.left_tree_data is None:
+        k = sequence_keys[tree.seq_indices[0]] if sequence_keys else tree.seq_indices[0]
+        return f"{k}"
+    left = format_rtree_topology(tree.left_tree_data["tree"], False, sequence_keys)
+    right = format_rtree_topology(tree.right_tree_data["tree"], False, sequence_keys)
+    return f"({left}, {right});" if at_root else f"({left}, {right})"
+
+
+def format_rtree(tree, at_root=False, branch_length=None, sequence_keys=None):
+    b = branch_length if branch_length is not None else DUMMY_BRANCH
+    if tree.left_tree_data is None:
+        return f"{sequence_keys[tree.seq_indices[0]]}:{b}"
+    left = format_rtree(tree.left_tree_data["tree"], False, tree.left_tree_data["branch_length"], sequence_keys)
+    right = format_rtree(tree.right_tree_data["tree"], False, tree.right_tree_data["branch_length"], sequence_keys)
+    return f"({left}, {right});" if at_root else f"({left}, {right}):{b}"
+
+
+class PhylogeneticTreeState:
+    def __init__(self, subtrees: List[PhyloTree]):
+        self.subtrees = subtrees
+        self.num_trees = len(subtrees)
+        self.is_done = self.num_trees == 1
+        self.last_state = isinstance(subtrees[0], UnrootedPhyloTree)
+        self.is_initial = all(t.left_tree_data is None for t in subtrees) and not self.last_state
+        self.log_score = subtrees[0].log_score if self.last_state else None
+
+
+class PhyInferEnv:
+    def __init__(self, cfg, device):
+        self.device = device
+        self.chars_dict = CHARACTERS_MAPS[cfg.env.sequence_type]
+        self.states = None
+        self.state_tensor = None
+        self.init_state_tensor = None
+        self.label_trees = None
+        self.batch_action_set_step = []
+
+    # ------------------------------------------------------------------ reference API
+    def init_states(self, batch_seqs, seq_keys, seq_arrays, label_trees=None, step_action=False):
+        if label_trees is not None:
+            raise NotImplementedError("label trees (supervised training) are outside the Argmax hot path")
+        self.batch_seqs = batch_seqs
+        self.seq_keys = seq_keys
+        T = len(batch_seqs[0])
+        self.tree_pairs_dict, self.action_indices_dict = {}, {}
+        for n in range(2, T + 1):
+            pairs = list(itertools.combinations(range(n), 2))
+            self.tree_pairs_dict[n] = pairs
+            self.action_indices_dict[n] = {p: i for i, p in enumerate(pairs)}
+        self.batch_size = len(batch_seqs)
+        self.states = [
+            PhylogeneticTreeState([PhyloTree(False, root_seq_data=[i], name=seq_keys[b][i], device=self.device)
+                                   for i in range(len(batch_seqs[b]))])
+            for b in range(self.batch_size)]
+        self.init_state_tensor = seq_arrays
+        self.state_tensor = None
+
+    def _merge_host(self, b, i, j):
+        """Tree half of one merge for batch element b; returns True when the tree is complete."""
+        st = self.states[b]
+        unrooted = st.num_trees == 2
+        new_tree = PhyloTree(unrooted, {"tree": st.subtrees[i], "branch_length": None},
+                             {"tree": st.subtrees[j], "branch_length": None})
+        if unrooted:
+            # optimize_branch_length_no_br (reference environment.py:674-686): dummy lengths, sentinel score
+            keys = self.seq_keys[b]
+            new_tree.log_score = NO_SCORE
+            ut = UnrootedPhyloTree(new_tree)
+            ut.utree_op_str = format_rtree(new_tree, True, None, keys)
+            ut.rtree_op_tuple = ut.utree_op_tuple = _newick_tuple(new_tree, keys)
+            self.states[b] = PhylogeneticTreeState([ut])
+            return True
+        trees = st.subtrees
+        trees[i] = new_tree
+        trees.pop(j)
+        self.states[b] = PhylogeneticTreeState(trees)
+        return False
+
+    def step(self, actions, edge_actions=None, parallel=True, branch_optimize=False, agent=None,
+             step_action=False):
+        if branch_optimize:
+            raise NotImplementedError("RAxML branch-length optimisation is outside the Argmax hot path")
+        n = self.states[0].num_trees
+        pairs = self.tree_pairs_dict[n]
+        acts = actions.tolist() if hasattr(actions, "tolist") else list(actions)
+        ij = [pairs[int(a)] for a in acts]
+        done = False
+        for b, (i, j) in enumerate(ij):
+            done = self._merge_host(b, i, j)
+        if not done:
+            # tensor half (reference environment.py:760-835) on the device
+            if agent is None:
+                raise NotImplementedError("the mean-aggregate fallback (agent=None) is not part of the hot path")
+            dev = self.state_tensor.device
+            ij_t = torch.tensor(ij, dtype=torch.long, device=dev)
+            new = agent.aggregate(None, None, (ij_t[:, 0], ij_t[:, 1]), batchwise_ij_indices=True)
+            base = []
+            for (i, j) in ij:
+                idx = list(range(n))
+                idx[i] = n
+                idx.pop(j)
+                base.append(idx)
+            base = torch.tensor(base, dtype=torch.long, device=dev)
+            cat = torch.cat((self.state_tensor, new), dim=1)
+            self.state_tensor = torch.gather(cat, 1, base[:, :, None, None].expand(-1, -1, cat.size(2), cat.size(3)))
+        return done
+
+    def apply_merges(self, merges):
+        """Fast path: replay a device-produced merge list [B,T-1,2] on the host trees."""
+        merges = np.asarray(merges)
+        for b in range(merges.shape[0]):
+            for (i, j) in merges[b]:
+                self._merge_host(b, int(i), int(j))
+
+    def evaluate_loglikelihood(self, get_all_tree=False):
+        scores = [s.log_score for s in self.states]
+        assert all(s.is_done for s in self.states)
+        t = torch.from_numpy(np.array(scores))
+        if get_all_tree:
+            return (t, [s.subtrees[0].rtree_op_tuple for s in self.states],
+                    [s.subtrees[0].utree_op_tuple for s in self.states],
+                    [s.subtrees[0].utree_op_str for s in self.states])
+        best = self.states[scores.index(max(scores))].subtrees[0]
+        return t, best.rtree_op_tuple, best.utree_op_tuple, best.utree_op_str
+
+    def dump_end_trees(self):
+        trees = [s.subtrees[0] for s in self.states]
+        return trees, [t.log_score for t in trees]
+
+    def get_current_trees(self):
+        return [[format_rtree_topology(t, True, None) for t in s.subtrees] for s in self.states]
+
+
+def _newick_tuple(tree, keys):
+    """Nested (left, len, right, len) tuples, the shape raxmlpy.treestr_to_tuples yields for
+    the dummy-length Newick (reference RAxMLpy/raxmlpy/core.py:21-26)."""
+    if tree.left_tree_data is None:
+        return keys[tree.seq_indices[0]]
+    return (_newick_tuple(tree.left_tree_data["tree"], keys), DUMMY_BRANCH,
+            _newick_tuple(tree.right_tree_data["tree"], keys), DUMMY_BRANCH)

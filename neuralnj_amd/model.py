@@ -1,0 +1,146 @@
+"""PhyloATTN: host mirror of the reference's model.py surface over libnnj_hip.so.
+
+Same constructor argument (`cfgs.model.*`), same `state_dict()` keys and shapes as the
+reference's PhyloATTN (reference model.py:11-60), so a reference checkpoint loads with
+`load_state_dict(ckpt['model_state_dict'], strict=True)`.  The parameters are plain
+containers: every forward computation -- encode_zxr (model.py:67-88), decode_zxr
+(model.py:158-209), aggregate (model.py:102-155) -- runs in the HIP library on the GPU.
+There is no torch implementation of the maths here and no CPU fallback.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn as nn
+
+from . import weights as _weights
+from ._lib import Nnj
+
+
+class _AttnParams(nn.Module):          # holds {k,v,q,out}_proj like the reference's attention modules
+    def __init__(self, d):
+        super().__init__()
+        self.k_proj = nn.Linear(d, d)
+        self.v_proj = nn.Linear(d, d)
+        self.q_proj = nn.Linear(d, d)
+        self.out_proj = nn.Linear(d, d)
+
+
+class _FfnParams(nn.Module):
+    def __init__(self, d, f):
+        super().__init__()
+        self.fc1 = nn.Linear(d, f)
+        self.fc2 = nn.Linear(f, d)
+
+
+class _Residual(nn.Module):            # `.layer` + `.layer_norm`, as NormalizedResidualBlock names them
+    def __init__(self, layer, d):
+        super().__init__()
+        self.layer = layer
+        self.layer_norm = nn.LayerNorm(d)
+
+
+class _AxialLayerParams(nn.Module):
+    def __init__(self, d, f):
+        super().__init__()
+        self.row_self_attention = _Residual(_AttnParams(d), d)
+        self.column_self_attention = _Residual(_AttnParams(d), d)
+        self.feed_forward_layer = _Residual(_FfnParams(d, f), d)
+
+
+class PhyloATTN(nn.Module):
+    def __init__(self, cfgs):
+        super().__init__()
+        m = cfgs.model
+        self.cfgs = cfgs
+        self.vocab_size = m.vocab_size
+        self.patch_size = m.patch_size
+        self.patch_num = m.fixed_length // m.patch_size if "fixed_length" in m else 0
+        self.embed_dim = d = m.embed_dim
+        self.num_enc_heads = m.num_enc_heads
+        self.num_enc_layers = m.num_enc_layers
+        self.dropout = 0.4                      # identity in eval; kept for parity of the attribute
+        self.seq_emb_layers = nn.ModuleList([_AxialLayerParams(d, 4 * d) for _ in range(m.num_enc_layers)])
+        self.embed = nn.Sequential(nn.Linear(m.vocab_size * m.patch_size, d), nn.GELU(), nn.Linear(d, d))
+        self.h_linear_last = nn.Linear(d, d)
+        self.g_linear_last = nn.Linear(d, d)
+        self.g_attn_q = nn.Linear(d, d)
+        self.g_attn_k = nn.Linear(d, d)
+        self.s_out = nn.Sequential(nn.Linear(d, d), nn.GELU(), nn.Linear(d, 1))
+        self._ctx = None
+        self._packed_version = None
+        self.batch_input = None
+        self.seq_mask = None
+
+    def model_params(self):
+        return list(self.parameters())
+
+    # ------------------------------------------------------------------ device context
+    def _device(self):
+        return next(self.parameters()).device
+
+    def _context(self) -> Nnj:
+        dev = self._device()
+        if dev.type != "cuda":
+            raise RuntimeError("PhyloATTN (neuralnj_amd) computes on the GPU only: call .to('cuda') first; "
+                               "there is no CPU path")
+        if self._ctx is None or self._ctx.device != dev:
+            self._ctx = Nnj(self.cfgs, dev)
+            self._packed_version = None
+        version = sum(p._version for p in self.parameters()) + 7919 * id(self._ctx)
+        if version != self._packed_version:
+            sd = {k: v.detach() for k, v in self.state_dict().items()}
+            self._ctx.load_weights(_weights.pack(self.cfgs, sd))
+            self._packed_version = version
+        return self._ctx
+
+    # ------------------------------------------------------------------ reference API
+    @staticmethod
+    def onehot_to_codes(batch_input: torch.Tensor) -> torch.Tensor:
+        """[B,T,L,4] one-hot (int8/float) -> [B,T,L] uint8 site codes (0..3, 4 = gap, 5 = pad)."""
+        x = batch_input
+        s = x.sum(-1)
+        codes = torch.where(s == 4, torch.full_like(s, 4), torch.where(s == 0, torch.full_like(s, 5),
+                                                                      x.argmax(-1).to(s.dtype)))
+        lut = torch.tensor([[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, 0], [0, 0, 0, 1], [1, 1, 1, 1], [0, 0, 0, 0]],
+                           dtype=x.dtype, device=x.device)
+        if not torch.equal(lut[codes.long()], x):
+            raise ValueError("encode_zxr: input is not made of the six site vectors of the reference's CHARS_DICT")
+        return codes.to(torch.uint8)
+
+    def encode_zxr(self, batch_input, batch_seq_mask=None):
+        ctx = self._context()
+        if batch_input.dim() != 4 or batch_input.shape[-1] != self.vocab_size:
+            raise ValueError("encode_zxr expects [B, rows, cols, vocab] one-hot input")
+        num_cols = batch_input.shape[2]
+        self.patch_num = math.ceil(num_cols / self.patch_size)
+        codes = self.onehot_to_codes(batch_input.to(ctx.device))
+        return ctx.encode(codes, batch_seq_mask)
+
+    def decode_zxr(self, batch_input, batch_seq_mask=None, indices_to_prev_info=None):
+        ctx = self._context()
+        actions_ij_prev, _score_indices_to_prev, logits_prev = indices_to_prev_info
+        self.batch_input = batch_input
+        self.seq_mask = None if batch_seq_mask is None else ~batch_seq_mask[:, None, :: self.patch_size]
+        if logits_prev is None:
+            scores = ctx.pair_scores_full(batch_input, batch_seq_mask)
+        else:
+            # the old->new index map (utils.get_score_indices_to_prev) is recomputed on the device
+            scores = ctx.pair_scores_incr(batch_input, batch_seq_mask, actions_ij_prev, logits_prev)
+        return {"logits": scores, "distance": scores}
+
+    def aggregate(self, x_i, x_j, ij_indices, batchwise_ij_indices=False):
+        if not batchwise_ij_indices:
+            raise NotImplementedError("only the env.step form (batchwise_ij_indices=True) is exposed; "
+                                      "pair scoring goes through decode_zxr")
+        if self.batch_input is None:
+            raise RuntimeError("aggregate() needs the state stashed by a preceding decode_zxr()")
+        ctx = self._context()
+        ii, jj = ij_indices
+        ij = torch.stack([torch.as_tensor(ii), torch.as_tensor(jj)], dim=1)
+        return ctx.aggregate(self.batch_input, ij)
+
+    # fast path used by neuralnj_amd.rollout
+    def rollout_argmax(self, codes, mask=None, **kw):
+        return self._context().rollout_argmax(codes, mask, **kw)

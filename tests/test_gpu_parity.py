@@ -1,0 +1,229 @@
+"""Parity of the HIP path (through the C ABI of libnnj_hip.so) against the CPU oracle, the
+golden vectors captured from the reference, and size-independent properties at the
+BASELINE sizes.  Tolerance: pair scores within 1e-4 of the table's scale (BASELINE.json:
+"pairwise-distance floats within 1e-4 relative"); merge lists exact wherever the
+reference's own top-2 gap is decisive (> 4e-4 of the scale), i.e. RF = 0."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import assert_logits_close, golden_names, load_golden, onehot_f32, split_trace
+from neuralnj_amd import synth, utils, weights
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def ctx_cache():
+    from neuralnj_amd._lib import Nnj
+    cache = {}
+
+    def get(cfgs, packed):
+        key = (int(cfgs.model.num_enc_layers), weights.digest(packed))
+        if key not in cache:
+            g = Nnj(cfgs, "cuda:0")
+            g.load_weights(packed)
+            cache[key] = g
+        return cache[key]
+    yield get
+    for g in cache.values():
+        g.close()
+
+
+def _oracle(cfgs, packed):
+    from oracle_lib import Oracle
+    return Oracle(cfgs, packed)
+
+
+@pytest.mark.parametrize("name", golden_names())
+def test_rollout_matches_reference_golden(name, ctx_cache):
+    """Teacher-forced along the reference's merges: every per-step table within tolerance of
+    what the reference computed; argmax equal on decisive steps; free run reproduces the
+    reference's merge list when no step is a near-tie."""
+    z, cfgs, packed = load_golden(name)
+    g = ctx_cache(cfgs, packed)
+    codes, mask = torch.from_numpy(z["codes"]), torch.from_numpy(z["mask"])
+    r = g.rollout_argmax(codes, mask, forced_merges=z["merges"], want_trace=True, want_state=True)
+    logits = r["logits"].cpu().numpy()
+    assert_logits_close(logits, z["logits"], RTOL)
+    st = r["state"].cpu().numpy()
+    if "enc" in z.files:
+        np.testing.assert_allclose(st, z["enc"], atol=RTOL * np.abs(z["enc"]).max())
+    else:
+        np.testing.assert_allclose(st[:, ::7, ::61, :], z["enc_slice"], atol=RTOL * np.abs(z["enc_slice"]).max())
+        assert abs(st.astype(np.float64).sum() - float(z["enc_checksum"])) <= 1e-5 * float(z["enc_abs_checksum"])
+    scale = np.abs(z["logits"]).max()
+    decisive = z["top2_gap"] > 4 * RTOL * scale
+    merges = r["merges"].cpu().numpy()
+    assert (merges[decisive] == z["merges"][decisive]).all()
+    np.testing.assert_allclose(r["top2_gap"].cpu().numpy()[decisive], z["top2_gap"][decisive], atol=2 * RTOL * scale)
+    if decisive[:, :-1].all():
+        free = g.rollout_argmax(codes, mask)["merges"].cpu().numpy()
+        assert np.array_equal(free, z["merges"])          # identical topology: RF = 0
+
+
+@pytest.mark.parametrize("name", ["synth_b1_t8_l128_s0", "synth_b1_t8_l128_s2", "tiny_b2_t3_l64_s5"])
+def test_encoder_taps_match_oracle(name, ctx_cache):
+    z, cfgs, packed = load_golden(name)
+    g = ctx_cache(cfgs, packed)
+    o = _oracle(cfgs, packed)
+    enc, taps = o.encode(onehot_f32(z["codes"]), z["mask"], taps=True)
+    codes, mask = torch.from_numpy(z["codes"]), torch.from_numpy(z["mask"])
+    try:
+        for stop, ref in ((1, taps[1]), (2, taps[2]), (0, enc)):
+            g.debug_encoder_stop(stop)
+            out = g.encode(codes, mask).cpu().numpy()
+            np.testing.assert_allclose(out, ref, atol=2e-5 * max(1.0, np.abs(ref).max()))
+    finally:
+        g.debug_encoder_stop(0)
+
+
+@pytest.mark.parametrize("name", ["synth_b2_t8_l128_s1", "padded_b2_t8_l128_s3", "plain_b1_t12_l96_s4",
+                                  "synth_b1_t20_l256_s1"])
+def test_entry_points_match_oracle_step_by_step(name, ctx_cache):
+    """The reference's call sequence (decode_zxr / argmax / env.step) through the separate
+    C-ABI entry points, each compared with the oracle on the same inputs."""
+    z, cfgs, packed = load_golden(name)
+    g = ctx_cache(cfgs, packed)
+    o = _oracle(cfgs, packed)
+    B, T, L = z["codes"].shape
+    mask = z["mask"]
+    tm = torch.from_numpy(mask)
+    state = o.encode(onehot_f32(z["codes"]), mask)
+    logits = o.pair_scores_full(state, mask)
+    got = g.pair_scores_full(torch.from_numpy(state), tm).cpu().numpy()
+    assert_logits_close(got, logits, RTOL, "pair_scores_full")
+    for step, n in enumerate(range(T, 2, -1)):
+        ij, gap = o.select_pair(logits, n)
+        gij, ggap = g.select_pair(torch.from_numpy(logits), n)
+        assert np.array_equal(gij.cpu().numpy(), ij)                        # integer work: exact
+        np.testing.assert_allclose(ggap.cpu().numpy(), gap, rtol=0, atol=0)
+        agg = o.aggregate(state, ij)
+        np.testing.assert_allclose(g.aggregate(torch.from_numpy(state), ij).cpu().numpy(), agg,
+                                   atol=RTOL * np.abs(agg).max())
+        nstate = o.env_step(state, ij)
+        gs = g.env_step(torch.from_numpy(state), ij).cpu().numpy()
+        np.testing.assert_allclose(gs, nstate, atol=RTOL * np.abs(nstate).max())
+        untouched = np.ones(n - 1, bool)
+        for b in range(B):                                                    # copied rows: bit exact
+            untouched[:] = True
+            untouched[ij[b, 0]] = False
+            assert np.array_equal(gs[b, untouched], nstate[b, untouched])
+        assert np.array_equal(g.score_index_map(ij, n - 1).cpu().numpy(), o.score_index_map(ij, n - 1))
+        nl = o.pair_scores_incr(nstate, mask, ij, logits)
+        gl = g.pair_scores_incr(torch.from_numpy(nstate), tm, ij, torch.from_numpy(logits)).cpu().numpy()
+        assert_logits_close(gl, nl, RTOL, f"pair_scores_incr n={n - 1}")
+        # cached entries are copied, not recomputed: bit exact
+        idx = o.score_index_map(ij, n - 1)
+        old = idx < logits.shape[1]
+        assert np.array_equal(gl[old], np.take_along_axis(logits, np.minimum(idx, logits.shape[1] - 1), 1)[old])
+        state, logits = nstate, nl
+
+
+def test_seeded_random_inputs_vs_oracle(ctx_cache):
+    """Fresh seeded inputs (not fixtures): HIP rollout vs oracle, ragged shapes."""
+    cfgs = utils.shipped_config()
+    packed = weights.pack(cfgs, weights.seeded_state(cfgs, 21, "sharp"))
+    g = ctx_cache(cfgs, packed)
+    o = _oracle(cfgs, packed)
+    for (B, T, L, seed) in ((3, 5, 36, 1), (1, 2, 64, 2), (2, 33, 100, 3), (1, 17, 260, 4), (1, 50, 128, 5)):
+        codes = synth.synth_codes_tree(B, T, L, seed)
+        mask = np.zeros((B, L), bool)
+        if seed % 2:
+            codes[:, :, L - 8:] = 5
+            mask[:, L - 8:] = True
+        free = g.rollout_argmax(torch.from_numpy(codes), torch.from_numpy(mask), want_trace=True)
+        merges = free["merges"].cpu().numpy()
+        ref = o.rollout_argmax(synth.codes_to_onehot(codes).astype(np.float32), mask, forced_merges=merges)
+        assert_logits_close(free["logits"].cpu().numpy(), ref["logits"], RTOL, f"{B}x{T}x{L}")
+        scale = np.abs(ref["logits"]).max()
+        decisive = ref["top2_gap"] > 4 * RTOL * scale
+        assert (ref["merges"][decisive] == merges[decisive]).all()
+        assert (merges[:, :, 0] < merges[:, :, 1]).all()
+        assert (merges[:, :, 1] < np.arange(T, 1, -1)[None, :]).all()
+
+
+def test_full_size_batch_properties(ctx_cache):
+    """BASELINE configs[2] size (256 x 50 x 1024): size-independent properties.
+    (1) identical MSAs in one batch give identical merge lists and tables, bit for bit;
+    (2) a permuted batch gives the permuted result; (3) teacher-forcing the free run's own
+    merges reproduces its tables bit for bit; (4) a sample of trees equals the oracle."""
+    cfgs = utils.shipped_config()
+    packed = weights.pack(cfgs, weights.seeded_state(cfgs, 0, "sharp"))
+    g = ctx_cache(cfgs, packed)
+    B, T, L = 256, 50, 1024
+    base = synth.synth_codes_tree(32, T, L, seed=77)
+    codes = np.concatenate([base] * 8, 0)                      # every MSA appears 8 times
+    tc = torch.from_numpy(codes)
+    r = g.rollout_argmax(tc, None, want_trace=True)
+    merges, logits = r["merges"].cpu().numpy(), r["logits"].cpu().numpy()
+    for k in range(1, 8):
+        assert np.array_equal(merges[:32], merges[32 * k:32 * (k + 1)])
+        assert np.array_equal(logits[:32], logits[32 * k:32 * (k + 1)])
+    perm = np.random.default_rng(0).permutation(B)
+    rp = g.rollout_argmax(torch.from_numpy(codes[perm]), None)
+    assert np.array_equal(rp["merges"].cpu().numpy(), merges[perm])
+    rf = g.rollout_argmax(tc, None, forced_merges=merges, want_trace=True)
+    assert np.array_equal(rf["logits"].cpu().numpy(), logits)
+    assert np.array_equal(rf["merges"].cpu().numpy(), merges)
+    o = _oracle(cfgs, packed)
+    sample = [0, 13, 31]
+    ref = o.rollout_argmax(synth.codes_to_onehot(codes[sample]).astype(np.float32), None, forced_merges=merges[sample])
+    assert_logits_close(logits[sample], ref["logits"], RTOL, "full-size sample")
+    scale = np.abs(ref["logits"]).max()
+    decisive = ref["top2_gap"] > 4 * RTOL * scale
+    assert (ref["merges"][decisive] == merges[sample][decisive]).all()
+
+
+def test_mask_none_equals_all_false(ctx_cache):
+    z, cfgs, packed = load_golden("synth_b2_t8_l128_s0")
+    g = ctx_cache(cfgs, packed)
+    codes = torch.from_numpy(z["codes"])
+    a = g.rollout_argmax(codes, None, want_trace=True)
+    b = g.rollout_argmax(codes, torch.zeros(2, 128, dtype=torch.bool), want_trace=True)
+    assert torch.equal(a["logits"], b["logits"]) and torch.equal(a["merges"], b["merges"])
+
+
+def test_unsupported_shapes_fail_loudly(ctx_cache):
+    cfgs = utils.shipped_config()
+    packed = weights.pack(cfgs, weights.seeded_state(cfgs, 0, "sharp"))
+    g = ctx_cache(cfgs, packed)
+    with pytest.raises(RuntimeError, match="50 rows"):
+        g.rollout_argmax(torch.zeros(1, 51, 64, dtype=torch.uint8))
+    with pytest.raises(RuntimeError, match="multiple of 4"):
+        g.encode(torch.zeros(1, 4, 30, dtype=torch.uint8))
+    from neuralnj_amd._lib import Nnj
+    g2 = Nnj(cfgs, "cuda:0")
+    with pytest.raises(RuntimeError, match="weights not loaded"):
+        g2.encode(torch.zeros(1, 4, 32, dtype=torch.uint8))
+    g2.close()
+
+
+def test_model_env_api_follows_reference_call_sequence():
+    """model.PhyloATTN / environment.PhyInferEnv used exactly like the reference's
+    reinforce_rollout uses them, and the fast path: same merge list and Newick as golden."""
+    from neuralnj_amd.environment import PhyInferEnv
+    from neuralnj_amd.model import PhyloATTN
+    from neuralnj_amd.rollout import argmax_rollout, reinforce_rollout_argmax
+    z, cfgs, packed = load_golden("synth_b2_t8_l128_s0")
+    agent = PhyloATTN(cfgs)
+    sd = weights.seeded_state(cfgs, int(z["wseed"]), str(z["style"]))
+    agent.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    agent = agent.to("cuda:0")
+    B, T, L = z["codes"].shape
+    batch = {"data": torch.from_numpy(synth.codes_to_onehot(z["codes"])),
+             "seqs": [synth.codes_to_seqs(z["codes"][b]) for b in range(B)],
+             "seq_keys": [list(k) for k in z["keys"]],
+             "seq_weights": torch.from_numpy((~z["mask"]).astype(np.float32))}
+    env = PhyInferEnv(cfgs, "cuda:0")
+    scores, best, merges = reinforce_rollout_argmax(batch, agent, env)
+    assert np.array_equal(merges, z["merges"])
+    assert [s.subtrees[0].utree_op_str for s in env.states] == [str(x) for x in z["newick"]]
+    assert best == str(z["best_tree"])
+    env2 = PhyInferEnv(cfgs, "cuda:0")
+    _, best2, merges2 = argmax_rollout(batch, agent, env2)
+    assert np.array_equal(merges2, z["merges"]) and best2 == best
+    with pytest.raises(ValueError):
+        agent.encode_zxr(torch.full((1, 3, 8, 4), 2, dtype=torch.int8), torch.zeros(1, 8, dtype=torch.bool))
