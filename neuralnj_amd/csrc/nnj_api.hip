@@ -144,6 +144,18 @@ EncDims enc_dims(int B, int T, int C) {
 struct PairGeom { int npairs, tpw, pg, ppad, nsc, cs; };
 PairGeom pair_geom(int mode, int n, int B, int C) {
   PairGeom g;
+  if (mode == PAIRS_INCR) {
+    // wave-private kernels: grid (nsc_blocks, B), 4 partial sets per block; nsc counts PARTIALS
+    g.npairs = n; g.tpw = 1; g.pg = 1; g.ppad = 64;
+    int blocks = (1024 + B - 1) / B;
+    const int max_blocks = (C + 31) / 32;
+    if (blocks > max_blocks) blocks = max_blocks;
+    if (blocks < 1) blocks = 1;
+    g.cs = (C + blocks - 1) / blocks;
+    blocks = (C + g.cs - 1) / g.cs;
+    g.nsc = blocks * 4;
+    return g;
+  }
   g.npairs = mode == PAIRS_FULL ? n * (n - 1) / 2 : n;
   g.tpw = mode == PAIRS_FULL ? 2 : 1;
   const int tiles = (g.npairs + 31) / 32;
@@ -276,17 +288,54 @@ int launch_pair_scores(nnj_handle* h, const RowSet& rs, const int* ij_prev, cons
   g = pair_geom(mode, n, B, C);
   const ScorerW sw = scorer_ptrs(h);
   const int has_ctx = n > 2 ? 1 : 0;
+  if (mode == PAIRS_INCR) {
+    const dim3 grid((unsigned)(g.nsc / 4), (unsigned)B);
+    const bool big = n > 32;
+    if (has_ctx) {
+      {
+        Scope sc(h, st, PK_PAIR_ALPHA_INCR);
+        if (big) {
+          const size_t lds = (size_t)4 * 2 * 2 * 2048 * sizeof(float);
+          if (int rc = set_lds(h, k_inc_alpha<2>, lds)) return rc;
+          hipLaunchKernelGGL(k_inc_alpha<2>, grid, dim3(256), lds, st, rs, sw, ij_prev, base + w.alpha_part, n, C, g.cs);
+        } else {
+          const size_t lds = (size_t)4 * 2 * 1 * 2048 * sizeof(float);
+          if (int rc = set_lds(h, k_inc_alpha<1>, lds)) return rc;
+          hipLaunchKernelGGL(k_inc_alpha<1>, grid, dim3(256), lds, st, rs, sw, ij_prev, base + w.alpha_part, n, C, g.cs);
+        }
+      }
+      {
+        Scope sc(h, st, PK_ALPHA_SOFTMAX);
+        hipLaunchKernelGGL(k_alpha_softmax, dim3((unsigned)(g.ppad / 4), (unsigned)B), dim3(256), 0, st, rs, sw, ij_prev,
+                           base + w.alpha_part, base + w.alpha, mode, n, C, g.npairs, g.ppad, g.nsc);
+      }
+    }
+    {
+      Scope sc(h, st, PK_PAIR_SCORE_INCR);
+      const size_t lds = (size_t)(8192 + 4 * 64 * 68) * sizeof(float);
+      if (big) {
+        if (int rc = set_lds(h, k_inc_score<2, true>, lds)) return rc;
+        hipLaunchKernelGGL((k_inc_score<2, true>), grid, dim3(256), lds, st, rs, sw, ij_prev, base + w.alpha, mask,
+                           base + w.score_part, n, C, g.cs);
+      } else if (has_ctx) {
+        if (int rc = set_lds(h, k_inc_score<1, true>, lds)) return rc;
+        hipLaunchKernelGGL((k_inc_score<1, true>), grid, dim3(256), lds, st, rs, sw, ij_prev, base + w.alpha, mask,
+                           base + w.score_part, n, C, g.cs);
+      } else {
+        if (int rc = set_lds(h, k_inc_score<1, false>, lds)) return rc;
+        hipLaunchKernelGGL((k_inc_score<1, false>), grid, dim3(256), lds, st, rs, sw, ij_prev, base + w.alpha, mask,
+                           base + w.score_part, n, C, g.cs);
+      }
+    }
+    return NNJ_OK;
+  }
   const dim3 grid((unsigned)g.nsc, (unsigned)g.pg, (unsigned)B);
   if (has_ctx) {
     {
-      Scope sc(h, st, mode == PAIRS_FULL ? PK_PAIR_ALPHA : PK_PAIR_ALPHA_INCR);
+      Scope sc(h, st, PK_PAIR_ALPHA);
       const size_t lds = 3 * 4096 * sizeof(float);
-      if (g.tpw == 2)
-        hipLaunchKernelGGL(k_pair_alpha<2>, grid, dim3(256), lds, st, rs, sw, ij_prev, base + w.alpha_part, mode, n, C,
-                           g.npairs, g.ppad, g.cs);
-      else
-        hipLaunchKernelGGL(k_pair_alpha<1>, grid, dim3(256), lds, st, rs, sw, ij_prev, base + w.alpha_part, mode, n, C,
-                           g.npairs, g.ppad, g.cs);
+      hipLaunchKernelGGL(k_pair_alpha<2>, grid, dim3(256), lds, st, rs, sw, ij_prev, base + w.alpha_part, mode, n, C,
+                         g.npairs, g.ppad, g.cs);
     }
     {
       Scope sc(h, st, PK_ALPHA_SOFTMAX);
@@ -295,17 +344,11 @@ int launch_pair_scores(nnj_handle* h, const RowSet& rs, const int* ij_prev, cons
     }
   }
   {
-    Scope sc(h, st, mode == PAIRS_FULL ? PK_PAIR_SCORE : PK_PAIR_SCORE_INCR);
+    Scope sc(h, st, PK_PAIR_SCORE);
     const size_t lds = 5 * 4096 * sizeof(float);
-    if (g.tpw == 2) {
-      if (int rc = set_lds(h, k_pair_score<2>, lds)) return rc;
-      hipLaunchKernelGGL(k_pair_score<2>, grid, dim3(256), lds, st, rs, sw, ij_prev, base + w.alpha, mask,
-                         base + w.score_part, mode, n, C, g.npairs, g.ppad, g.cs, has_ctx);
-    } else {
-      if (int rc = set_lds(h, k_pair_score<1>, lds)) return rc;
-      hipLaunchKernelGGL(k_pair_score<1>, grid, dim3(256), lds, st, rs, sw, ij_prev, base + w.alpha, mask,
-                         base + w.score_part, mode, n, C, g.npairs, g.ppad, g.cs, has_ctx);
-    }
+    if (int rc = set_lds(h, k_pair_score<2>, lds)) return rc;
+    hipLaunchKernelGGL(k_pair_score<2>, grid, dim3(256), lds, st, rs, sw, ij_prev, base + w.alpha, mask,
+                       base + w.score_part, mode, n, C, g.npairs, g.ppad, g.cs, has_ctx);
   }
   return NNJ_OK;
 }

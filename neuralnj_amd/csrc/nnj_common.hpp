@@ -55,6 +55,20 @@ __device__ __forceinline__ float gelu_erf(float x) {
   return 0.5f * x * one_plus_erf;
 }
 
+// ---- LDS-DMA: 16 bytes per lane HBM -> LDS with no register staging (global_load_lds_dwordx4).
+// LDS destination = wave-uniform base + lane*16; the per-lane SOURCE address is free.
+// (The builtins exist only in the device pass; the host pass of hipcc sees empty bodies.)
+__device__ __forceinline__ void lds_dma16(const float* gsrc, float* lds_base_uniform) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  __builtin_amdgcn_global_load_lds(gsrc, lds_base_uniform, 16, 0, 0);
+#endif
+}
+__device__ __forceinline__ void wait_vmem_all() {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+}
+
 // ---- LDS weight image: W[out][in] row-major, 16-byte chunks XOR-swizzled by row so
 // that a ds_read_b128 whose 16-lane groups read 16 different rows at the same logical
 // chunk is bank-conflict free.  IN must be a multiple of 64 floats.
@@ -87,11 +101,11 @@ __device__ __forceinline__ void stage_weight_sub(float* lds, const float* __rest
 //   out[nt][mt] (MT tiles of 32 out-features) = bias + W * in,   in has KT tiles.
 //   W: swizzled LDS image [32*MT][32*KT]; bias: pointer readable with 16-byte loads
 //   (LDS or global), may be nullptr.
-template <int MT, int KT, int NT>
+template <int MT, int KT, int NT, int LDW = 32 * KT, bool SWZ = true>
 __device__ __forceinline__ void linear_T(f32x16 (&out)[NT][MT], const f32x16 (&in)[NT][KT],
                                          const float* W, const float* bias, int lane) {
   const int row = lane & 31, hh = lane >> 5;
-  constexpr int IN = 32 * KT;
+  constexpr int IN = LDW;
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
@@ -110,7 +124,7 @@ __device__ __forceinline__ void linear_T(f32x16 (&out)[NT][MT], const f32x16 (&i
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int chunk = (32 * kt + 8 * g + 4 * hh) >> 2;
-        const f32x4 a = *reinterpret_cast<const f32x4*>(W + wrow * IN + 4 * wswz(wrow, chunk));
+        const f32x4 a = *reinterpret_cast<const f32x4*>(W + wrow * IN + 4 * (SWZ ? wswz(wrow, chunk) : chunk));
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
 #pragma unroll
@@ -122,11 +136,11 @@ __device__ __forceinline__ void linear_T(f32x16 (&out)[NT][MT], const f32x16 (&i
 }
 
 // accumulate variant: out += W * in (no bias init)
-template <int MT, int KT, int NT>
+template <int MT, int KT, int NT, int LDW = 32 * KT>
 __device__ __forceinline__ void linear_T_acc(f32x16 (&out)[NT][MT], const f32x16 (&in)[NT][KT],
                                              const float* W, int lane) {
   const int row = lane & 31, hh = lane >> 5;
-  constexpr int IN = 32 * KT;
+  constexpr int IN = LDW;
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
     const int wrow = 32 * mt + row;

@@ -284,6 +284,251 @@ __global__ __launch_bounds__(256) void k_pair_score(RowSet rs, ScorerW w, const 
   }
 }
 
+// ------------------------------------------------------------------ incremental NJ step
+// The n-1 new pairs (m, r) of a step, m = position of the freshly merged row.  Lane = partner
+// row r (NT tiles of 32), so every lane streams ITS OWN rows S_r, U_r straight from HBM
+// (16-byte pieces) and all lanes share S_m, U_m.  Each wave owns whole sites (c = c0+wave,
+// +4, ...): no workgroup barrier in the loop, four sites in flight per CU, the next site's
+// loads are issued before the current site's MFMAs.
+struct IncLane {
+  int m, slot_m;
+  int r[2], slot_r[2];
+  bool valid[2], r_first[2];     // r_first: r < m, i.e. the pair is (r, m) not (m, r)
+};
+template <int NT>
+__device__ __forceinline__ IncLane inc_lane(const RowSet& rs, const int* ij_prev, int b, int n, int lane) {
+  IncLane L;
+  L.m = ij_prev[2 * b];
+  L.slot_m = slot_of(rs, b, L.m);
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int r = 32 * nt + (lane & 31);
+    L.r[nt] = r;
+    L.valid[nt] = r < n && r != L.m;
+    L.slot_r[nt] = slot_of(rs, b, r < n ? r : 0);
+    L.r_first[nt] = r < L.m;
+  }
+  return L;
+}
+template <int NT>
+struct IncRaw { f32x16 sr[NT][2], ur[NT][2]; };      // this lane's rows (prefetched one site ahead)
+struct IncShared { f32x16 sm[2], um[2]; };            // the merged row m (same for all lanes; loaded just in time)
+
+__device__ __forceinline__ void inc_load_shared(IncShared& sh, const RowSet& rs, const IncLane& L, size_t bo, int C,
+                                                int c, int hh) {
+  const size_t om = bo + ((size_t)L.slot_m * C + c) * 64;
+  load_token64(sh.sm, rs.S + om, true, hh);
+  load_token64(sh.um, rs.U + om, true, hh);
+}
+template <int NT>
+__device__ __forceinline__ void inc_load(IncRaw<NT>& raw, const RowSet& rs, const IncLane& L, size_t bo, int n,
+                                         int C, int c, int hh) {
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const size_t o = bo + ((size_t)L.slot_r[nt] * C + c) * 64;
+    load_token64(raw.sr[nt], rs.S + o, L.r[nt] < n, hh);
+    load_token64(raw.ur[nt], rs.U + o, L.r[nt] < n, hh);
+  }
+}
+// x = z*x_i + (1-z)*x_j with (i,j) = sort(m, r)  (model.py:105-108, 186-197)
+template <int NT>
+__device__ __forceinline__ void inc_gate(f32x16 (&x)[NT][2], const IncRaw<NT>& raw, const IncShared& sh,
+                                         const IncLane& L, const float* bh, int hh) {
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const f32x4 b4 = *reinterpret_cast<const f32x4*>(bh + 32 * mt + 8 * g + 4 * hh);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int k = 4 * g + t;
+          const float d = sh.um[mt][k] - raw.ur[nt][mt][k];
+          const float z = sigmoidf_((L.r_first[nt] ? -d : d) + b4[t]);
+          const float a = L.r_first[nt] ? raw.sr[nt][mt][k] : sh.sm[mt][k];
+          const float c2 = L.r_first[nt] ? sh.sm[mt][k] : raw.sr[nt][mt][k];
+          x[nt][mt][k] = z * a + (1.0f - z) * c2;
+        }
+    }
+}
+
+// Phase A: alpha partials.  grid (nsc, B).  K' image of a site goes HBM -> LDS by LDS-DMA
+// (global_load_lds_dwordx4, swizzle applied on the per-lane SOURCE address), double buffered
+// per wave.  part[b][sc*4+wave][pair r][r'].
+template <int NT>
+__global__ __launch_bounds__(256) void k_inc_alpha(RowSet rs, ScorerW w, const int* __restrict__ ij_prev,
+                                                   float* __restrict__ alpha_part, int n, int C, int cs) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63, hh = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int sc = blockIdx.x, b = blockIdx.y;
+  const int c0 = sc * cs, c1 = min(C, c0 + cs);
+  float* kbuf = smem + wave * (2 * NT * 2048);            // two images of [32*NT][64]
+  const IncLane L = inc_lane<NT>(rs, ij_prev, b, n, lane);
+  const size_t bo = (size_t)b * rs.bstride;
+  // LDS-DMA geometry: instruction i fills image rows 4i..4i+3; this lane supplies row 4i+(lane>>4),
+  // physical chunk lane&15, i.e. logical chunk (lane&15) ^ (row&15)
+  const float* kp_b = rs.Kp + bo;
+  unsigned gsrc[8 * NT];
+#pragma unroll
+  for (int i = 0; i < 8 * NT; ++i) {
+    const int row = 4 * i + (lane >> 4);
+    const int logical = (lane & 15) ^ (row & 15);
+    gsrc[i] = (unsigned)slot_of(rs, b, row < n ? row : 0) * (unsigned)(C * 64) + 4u * logical;
+  }
+  f32x16 acc[NT][NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int mt = 0; mt < NT; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[nt][mt][r] = 0.f;
+  IncRaw<NT> raw;
+  int c = c0 + wave;
+  int cur = 0;
+  if (c < c1) {
+    inc_load<NT>(raw, rs, L, bo, n, C, c, hh);
+#pragma unroll
+    for (int i = 0; i < 8 * NT; ++i)
+      lds_dma16(kp_b + gsrc[i] + (unsigned)(c * 64), kbuf + i * 256);
+  }
+  for (; c < c1; c += 4) {
+    IncShared sh;
+    inc_load_shared(sh, rs, L, bo, C, c, hh);
+    wait_vmem_all();                                       // this site's rows and K' image have landed
+    f32x16 x[NT][2];
+    inc_gate<NT>(x, raw, sh, L, w.bh, hh);
+    const int cn = c + 4 < c1 ? c + 4 : c;                 // prefetch the next site behind the MFMAs
+    {                                                      // (last iteration: harmless reload of this site)
+      inc_load<NT>(raw, rs, L, bo, n, C, cn, hh);
+      float* nb = kbuf + (cur ^ 1) * (NT * 2048);
+#pragma unroll
+      for (int i = 0; i < 8 * NT; ++i)
+        lds_dma16(kp_b + gsrc[i] + (unsigned)(cn * 64), nb + i * 256);
+    }
+    linear_T_acc<NT, 2, NT>(acc, x, kbuf + cur * (NT * 2048), lane);
+    cur ^= 1;
+  }
+  const int part = sc * 4 + wave, nparts = gridDim.x * 4;
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    float* dst = alpha_part + (((size_t)b * nparts + part) * 64 + L.r[nt]) * 64;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (mt < NT) v = (f32x4){acc[nt][mt < NT ? mt : 0][4 * g], acc[nt][mt < NT ? mt : 0][4 * g + 1],
+                                  acc[nt][mt < NT ? mt : 0][4 * g + 2], acc[nt][mt < NT ? mt : 0][4 * g + 3]};
+        *reinterpret_cast<f32x4*>(dst + 32 * mt + 8 * g + 4 * hh) = v;
+      }
+  }
+}
+
+// Phase B: scores of the new pairs.  The transposed site image S_c^T (A operand of
+// x_g^T = S_c^T alpha^T) is written by the wave itself from the rows its lanes hold.
+// part[b][sc*4+wave][pair r].
+template <int NT, bool CTX>
+__global__ __launch_bounds__(256) void k_inc_score(RowSet rs, ScorerW w, const int* __restrict__ ij_prev,
+                                                   const float* __restrict__ alpha,
+                                                   const uint8_t* __restrict__ mask,
+                                                   float* __restrict__ score_part, int n, int C, int cs) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Wg_l = smem;
+  float* S0_l = smem + 4096;
+  const int tid = threadIdx.x, lane = tid & 63, hh = lane >> 5, tok = lane & 31;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  float* img_t = smem + 8192 + wave * (64 * 68);          // [64 d][68]: row stride 68 floats, no swizzle
+  const int sc = blockIdx.x, b = blockIdx.y;
+  const int c0 = sc * cs, c1 = min(C, c0 + cs);
+  stage_weight<64>(Wg_l, w.Wg, 64, tid, 256);
+  stage_weight<64>(S0_l, w.S0, 64, tid, 256);
+  __syncthreads();
+  constexpr bool has_ctx = CTX;                            // CTX = (n > 2), model.py:111
+  const IncLane L = inc_lane<NT>(rs, ij_prev, b, n, lane);
+  const size_t bo = (size_t)b * rs.bstride;
+  // alpha[pair][r'] (only r' < 32*NT can be non-zero) is re-read per site from L1/L2: keeping it
+  // in registers next to the prefetched rows would spill
+  float score[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) score[nt] = 0.f;
+  IncRaw<NT> raw;
+  int c = c0 + wave;
+  if (c < c1) inc_load<NT>(raw, rs, L, bo, n, C, c, hh);
+  for (; c < c1; c += 4) {
+    f32x16 x[NT][2];
+    {
+      IncShared sh;
+      inc_load_shared(sh, rs, L, bo, C, c, hh);
+      inc_gate<NT>(x, raw, sh, L, w.bh, hh);
+    }
+    if constexpr (has_ctx) {
+      // S_c^T image: this lane's rows, feature f -> img_t[f][r]
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int r = 32 * nt + tok;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+          for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+              img_t[(4 * hh) * 68 + r + (32 * mt + 8 * g + t) * 68] = raw.sr[nt][mt][4 * g + t];
+            }
+      }
+    }
+    const float mc = (mask && mask[(size_t)b * C + c]) ? 0.f : 1.f;     // seq_mask (model.py:96)
+    const int cn = c + 4;
+    inc_load<NT>(raw, rs, L, bo, n, C, cn < c1 ? cn : c, hh);          // prefetch behind the MFMAs (last: harmless reload)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {                                    // one 32-pair tile at a time
+      f32x16 xt[1][2] = {{x[nt][0], x[nt][1]}};
+      if constexpr (has_ctx) {
+        f32x16 xg[1][2], g[1][2], at[1][NT];
+        {
+          const float* ap = alpha + ((size_t)b * 64 + L.r[nt]) * 64;
+#pragma unroll
+          for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+              const f32x4 v = *reinterpret_cast<const f32x4*>(ap + 32 * kt + 8 * g4 + 4 * hh);
+              at[0][kt][4 * g4] = v[0]; at[0][kt][4 * g4 + 1] = v[1]; at[0][kt][4 * g4 + 2] = v[2]; at[0][kt][4 * g4 + 3] = v[3];
+            }
+        }
+        linear_T<2, NT, 1, 68, false>(xg, at, img_t, nullptr, lane);
+        linear_T<2, 2, 1>(g, xg, Wg_l, w.bg, lane);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float wg = sigmoidf_(g[0][mt][r]);
+            xt[0][mt][r] = (1.0f - wg) * xt[0][mt][r] + wg * xg[0][mt][r];
+          }
+      }
+      f32x16 s1[1][2];
+      linear_T<2, 2, 1>(s1, xt, S0_l, w.s0, lane);
+      float s = 0.f;
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f32x4 w4 = *reinterpret_cast<const f32x4*>(w.s2w + 32 * mt + 8 * g + 4 * hh);
+#pragma unroll
+          for (int t = 0; t < 4; ++t) s += gelu_erf(s1[0][mt][4 * g + t]) * w4[t];
+        }
+      s += __shfl_xor(s, 32);
+      score[nt] += (s + w.s2b) * mc;
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  if (hh == 0) {
+    const int part = sc * 4 + wave, nparts = gridDim.x * 4;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) score_part[((size_t)b * nparts + part) * 64 + L.r[nt]] = score[nt];
+  }
+}
+
 // ------------------------------------------------------------------ row transforms
 // Tokens = sites.  For one row tile held feature-major in registers, write
 // U = W_h S, K' = A S + a0 and the beta partial of the wave's 32 sites.
