@@ -130,10 +130,14 @@ int check_shape(nnj_handle* h, int B, int T, int L) {
   return NNJ_OK;
 }
 
-struct EncDims { int Epad, ld, NT; size_t hm; };   // hm = floats of one head-major buffer
+struct EncDims { int Epad, ld, NT, nte; size_t hm; };   // hm = floats of one head-major buffer
 EncDims enc_dims(int B, int T, int C) {
   EncDims d;
-  d.Epad = (T * 8 + 15) / 16 * 16;
+  // head dim of the tied row attention, padded (with zeros) to a compiled tile count
+  static const int buckets[] = {4, 8, 12, 16, 20, 25};
+  d.nte = 25;
+  for (int k : buckets) if (T * 8 <= 16 * k) { d.nte = k; break; }
+  d.Epad = 16 * d.nte;
   d.ld = (d.Epad - 4 + 31) / 32 * 32 + 4;
   d.NT = T <= 32 ? 1 : 2;
   d.hm = (size_t)B * NNJ_NHEAD * C * d.Epad;
@@ -238,11 +242,20 @@ int launch_encoder(nnj_handle* h, const uint8_t* codes, const uint8_t* mask, flo
   for (int l = 0; l < nl; ++l) {
     {
       Scope sc(h, st, PK_ROW_ATTN);
-      const size_t lds = (size_t)2 * 32 * d.ld * sizeof(float);
-      if (int rc = set_lds(h, k_row_attn, lds)) return rc;
       const int nq = (C + 63) / 64;
-      hipLaunchKernelGGL(k_row_attn, dim3((unsigned)(B * NNJ_NHEAD * nq)), dim3(256), lds, st, Q, K, V, mask, ctx, B, C,
-                         d.Epad, d.ld, fill);
+      const dim3 grid((unsigned)(B * NNJ_NHEAD * nq));
+      const int nkt = (C + RA_KEYS - 1) / RA_KEYS;
+#define NNJ_RA_CASE(N)                                                                                  \
+  case N: {                                                                                             \
+    const size_t lds = (size_t)2 * RaShape<N>::STAGE_F * sizeof(float) + (size_t)((nkt * RA_KEYS + 15) / 16 * 16); \
+    if (int rc = set_lds(h, k_row_attn<N>, lds)) return rc;                                             \
+    hipLaunchKernelGGL(k_row_attn<N>, grid, dim3(256), lds, st, Q, K, V, mask, ctx, B, C, fill);        \
+  } break;
+      switch (d.nte) {
+        NNJ_RA_CASE(4) NNJ_RA_CASE(8) NNJ_RA_CASE(12) NNJ_RA_CASE(16) NNJ_RA_CASE(20) NNJ_RA_CASE(25)
+        default: return fail(h, NNJ_ERR_UNSUPPORTED, "row attention: no instantiation for %d tiles", d.nte);
+      }
+#undef NNJ_RA_CASE
     }
     {
       Scope sc(h, st, PK_TOK1);

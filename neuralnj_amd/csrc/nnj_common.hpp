@@ -15,6 +15,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -67,6 +68,47 @@ __device__ __forceinline__ void wait_vmem_all() {
 #if defined(__HIP_DEVICE_COMPILE__)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
+}
+
+// ---- hand-issued LDS reads (the compiler would drain in-flight LDS-DMA with vmcnt(0) before every
+// ds_read it issues itself).  Protocol (cdna_hip_programming.md 5.7, form ii): issue a batch with
+// lds_read_*, later name every destination in lds_wait_* before the first consumer.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <int OFF>
+__device__ __forceinline__ void lds_read_b64(f32x2& d, unsigned byte_addr) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(d) : "v"(byte_addr), "n"(OFF));
+#endif
+}
+template <int OFF>
+__device__ __forceinline__ void lds_read_b32(float& d, unsigned byte_addr) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(d) : "v"(byte_addr), "n"(OFF));
+#endif
+}
+__device__ __forceinline__ void lds_wait_all() {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);     // register-only MFMAs must not be hoisted above the wait (rule 18)
+#endif
+}
+// makes a value "defined here": no consumer of x can be scheduled above this point
+template <typename T>
+__device__ __forceinline__ void pin_after_wait(T& x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("" : "+v"(x));
+#endif
+}
+__device__ __forceinline__ unsigned lds_addr(const void* p) {   // LDS byte offset of a __shared__ pointer
+  return (unsigned)(size_t)(const __attribute__((address_space(3))) char*)p;
+}
+// compile-time loop: f(std::integral_constant<int, I>) for I in [0, N)
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
 }
 
 // ---- LDS weight image: W[out][in] row-major, 16-byte chunks XOR-swizzled by row so

@@ -116,142 +116,212 @@ __global__ __launch_bounds__(256) void k_embed_qkv(const uint8_t* __restrict__ c
 
 // ------------------------------------------------------------------ k_row_attn
 // Tied row attention for one (b, h) and 64 query columns: standard attention over the
-// C columns with head dimension Epad (reference axial_attention.py:97-114), online
+// C columns with head dimension Epad = 16*NTE (reference axial_attention.py:97-114), online
 // softmax, fp32 MFMA 16x16x4.  Computes S^T = K Q^T so that the probabilities come out
 // in the A-operand layout of the P*V product.
-//   LDS: K tile [32][ld], V tile [32][ld], ld = roundup(Epad-4,32)+4 (ld % 32 == 4
-//   makes both the float2 K reads and the scalar V reads conflict free).
-#define RA_NTE_MAX 25     // Epad <= 400  (R <= 50)
+//   * K/V tiles of 16 keys stream HBM/L2 -> LDS by LDS-DMA (global_load_lds_dwordx4) into a
+//     two-stage ring: the DMA of tile t+1 is in flight while tile t is multiplied; one
+//     workgroup barrier per tile.
+//   * LDS rows are padded to LD = roundup(Epad-4,32)+4 floats (LD % 32 == 4 makes the float2
+//     K reads and the scalar V reads bank-conflict free); DMA lanes that land in the pad read a
+//     harmless address.
+//   * MFMA operands are read from LDS by hand-issued ds_reads in batches, software pipelined:
+//     the next batch is issued before the current batch's MFMAs and waited for after them.
+//   * the key-padding mask of the batch element sits in LDS (no global load inside the loop).
+#define RA_KEYS 16        // keys per tile
+template <int NTE>
+struct RaShape {
+  static constexpr int Epad = 16 * NTE;
+  static constexpr int LD = (Epad - 4 + 31) / 32 * 32 + 4;
+  static constexpr int CPR = LD / 4, CPE = Epad / 4;              // 16-byte chunks per LDS row / global row
+  static constexpr int NDMA = (2 * RA_KEYS * CPR + 255) / 256;    // LDS-DMA instructions per wave per tile
+  static constexpr int STAGE_F = NDMA * 4 * 256;                  // floats per ring stage
+  static constexpr int NS = 2 * NTE;                              // float2 k-steps of S^T
+};
+
+template <int NTE>
 __global__ __launch_bounds__(256) void k_row_attn(const float* __restrict__ Q, const float* __restrict__ K,
                                                   const float* __restrict__ V,
                                                   const uint8_t* __restrict__ mask, float* __restrict__ ctx,
-                                                  int B, int C, int Epad, int ld, float fill) {
+                                                  int B, int C, float fill) {
+  using SH = RaShape<NTE>;
+  constexpr int Epad = SH::Epad, LD = SH::LD, NS = SH::NS, NDMA = SH::NDMA;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* Kl = smem;
-  float* Vl = smem + 32 * ld;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   // XCD-aware mapping: all query tiles of one (b,h) share blockIdx % 8 (one L2)
   const int nq = (C + 63) / 64;
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
   const int bh = (slot / nq) * 8 + xcd;
   const int qt = slot % nq;
-  if (bh >= B * NNJ_NHEAD) return;           // whole workgroup exits together
+  if (bh >= B * NNJ_NHEAD) return;       // whole workgroup exits together
   const int b = bh / NNJ_NHEAD;
   const size_t base = (size_t)bh * C * Epad;
   const int l15 = lane & 15, kq = lane >> 4;
-  const int nte = Epad / 16, ns = Epad / 8;
   const int q0 = qt * 64 + wave * 16;
   const int qi = q0 + l15;               // this lane's query (B operand column)
   const bool qvalid = qi < C;
+  const int nkt = (C + RA_KEYS - 1) / RA_KEYS;
+  unsigned char* maskl = reinterpret_cast<unsigned char*>(smem + 2 * SH::STAGE_F);   // [nkt*16]
+
+  // key classes for the whole (b) row: 0 = key, 1 = padded key (axial_attention.py:99-103), 2 = beyond C
+  for (int j = tid; j < nkt * RA_KEYS; j += 256)
+    maskl[j] = j >= C ? 2 : ((mask && mask[(size_t)b * C + j]) ? 1 : 0);
+
+  // DMA plan of this lane: instruction i of this wave fills LDS chunk q = (wave*NDMA+i)*64+lane of the
+  // stage image [K tile 16 x LD | V tile 16 x LD]; (is_V, float offset from the tile's first key row)
+  // or -1 for pad / unused positions.
+  int dsrc[NDMA];
+#pragma unroll
+  for (int i = 0; i < NDMA; ++i) {
+    int q = (wave * NDMA + i) * 64 + lane;
+    int isv = 0;
+    if (q >= RA_KEYS * SH::CPR) { q -= RA_KEYS * SH::CPR; isv = 1; }
+    const int row = q / SH::CPR, cc = q - row * SH::CPR;
+    dsrc[i] = (row < RA_KEYS && cc < SH::CPE) ? ((row * Epad + 4 * cc) | (isv << 30)) : -1;
+  }
+  auto issue_tile = [&](int kt, int stage) {
+    const int j0 = kt * RA_KEYS;
+    float* dst = smem + stage * SH::STAGE_F + wave * NDMA * 256;
+#pragma unroll
+    for (int i = 0; i < NDMA; ++i) {
+      const int d = dsrc[i];
+      const int off = d & 0x3fffffff;
+      // pad positions and keys beyond the alignment read row 0 of the (b,h) slice: finite, unused
+      const bool ok = d >= 0 && (j0 + off / Epad) < C;
+      const float* src = (((d >> 30) & 1) ? V : K) + base + (ok ? (size_t)j0 * Epad + off : 0);
+      lds_dma16(src, dst + i * 256);
+    }
+  };
 
   // Q fragment: lane (query, kq) holds Q[query][8s + 2kq + u]
-  float qf[2 * RA_NTE_MAX * 2];          // 100 floats (s < ns)
+  float qf[2 * NS];
 #pragma unroll
-  for (int s = 0; s < 2 * RA_NTE_MAX; ++s) {
-    float2 v = make_float2(0.f, 0.f);
-    if (s < ns && qvalid) v = *reinterpret_cast<const float2*>(Q + base + (size_t)qi * Epad + 8 * s + 2 * kq);
-    qf[2 * s] = v.x; qf[2 * s + 1] = v.y;
+  for (int s = 0; s < NS; ++s) {
+    const float2 v = *reinterpret_cast<const float2*>(Q + base + (size_t)(qvalid ? qi : 0) * Epad + 8 * s + 2 * kq);
+    qf[2 * s] = qvalid ? v.x : 0.f; qf[2 * s + 1] = qvalid ? v.y : 0.f;
   }
-  f32x4 O[RA_NTE_MAX];
+  f32x4 O[NTE];
 #pragma unroll
-  for (int t = 0; t < RA_NTE_MAX; ++t) O[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int t = 0; t < NTE; ++t) O[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
   float m_run = -INFINITY, l_run = 0.f;
 
-  const int nkt = (C + 31) / 32;
-  for (int kt = 0; kt < nkt; ++kt) {
-    const int j0 = kt * 32;
-    __syncthreads();                      // previous tile fully consumed
-    // stage K,V tiles: rows j0..j0+31 (zero beyond C), Epad floats each, 16-byte pieces
-    const int ch_per_row = Epad / 4;
-    for (int i = tid; i < 32 * ch_per_row; i += 256) {
-      const int r = i / ch_per_row, ch = i % ch_per_row;
-      f32x4 kv = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
-      if (j0 + r < C) {
-        kv = *reinterpret_cast<const f32x4*>(K + base + (size_t)(j0 + r) * Epad + 4 * ch);
-        vv = *reinterpret_cast<const f32x4*>(V + base + (size_t)(j0 + r) * Epad + 4 * ch);
-      }
-      *reinterpret_cast<f32x4*>(Kl + r * ld + 4 * ch) = kv;
-      *reinterpret_cast<f32x4*>(Vl + r * ld + 4 * ch) = vv;
-    }
-    __syncthreads();
+  // LDS byte addresses of this lane's operand streams inside a stage
+  const unsigned smem_b = lds_addr(smem);
+  const unsigned ka0 = smem_b + (unsigned)(l15 * LD + 2 * kq) * 4u;                    // K[key l15][2kq + 8s]
+  const unsigned va0 = smem_b + (unsigned)((RA_KEYS + 4 * kq) * LD + l15) * 4u;        // V[4kq + r][l15 + 16t]
+  const unsigned ma0 = lds_addr(maskl) + 4u * kq;
 
-    // S^T[key x query]: two 16-key tiles; A = K (lane: key l15, kq), B = Q regs
-    f32x4 st[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+  constexpr int KB = NS < 10 ? NS : 10;            // float2 reads per S batch
+  constexpr int NKB = (NS + KB - 1) / KB;
+
+  issue_tile(0, 0);
+  for (int kt = 0; kt < nkt; ++kt) {
+    wait_vmem_all();                      // my pieces of tile kt have landed
+    __syncthreads();                      // everyone's pieces landed; everyone is done with tile kt-1
+    if (kt + 1 < nkt) issue_tile(kt + 1, (kt + 1) & 1);
+    const unsigned sb_ = (unsigned)((kt & 1) * SH::STAGE_F) * 4u;
+    const unsigned ka = ka0 + sb_, va = va0 + sb_;
+    const int j0 = kt * RA_KEYS;
+
+    // ---- S^T[key x query]: A = K (lane: key l15, kq) from LDS, B = Q regs; two accumulation chains
+    f32x4 sa = {0.f, 0.f, 0.f, 0.f}, sbb = {0.f, 0.f, 0.f, 0.f};
+    f32x2 kA[KB], kB[KB];
+    float mk4;                             // 4 key-class bytes of this lane's keys
+    lds_read_b32<0>(mk4, ma0 + (unsigned)j0);
+    static_for<0, KB>([&](auto i) { lds_read_b64<32 * decltype(i)::value>(kA[decltype(i)::value], ka); });
+    lds_wait_all();
+    pin_after_wait(mk4);
 #pragma unroll
-    for (int s = 0; s < 2 * RA_NTE_MAX; ++s) {
-      if (s < ns) {
+    for (int i = 0; i < KB; ++i) pin_after_wait(kA[i]);
+    static_for<0, NKB>([&](auto bi) {
+      constexpr int b0 = decltype(bi)::value * KB;
+      constexpr int nb = (NS - b0) < KB ? (NS - b0) : KB;
+      constexpr int n0 = b0 + KB;
+      constexpr int nn = n0 >= NS ? 0 : ((NS - n0) < KB ? (NS - n0) : KB);
+      f32x2 (&cur)[KB] = (decltype(bi)::value & 1) ? kB : kA;
+      f32x2 (&nxt)[KB] = (decltype(bi)::value & 1) ? kA : kB;
+      static_for<0, nn>([&](auto i) { lds_read_b64<32 * (n0 + decltype(i)::value)>(nxt[decltype(i)::value], ka); });
 #pragma unroll
-        for (int t2 = 0; t2 < 2; ++t2) {
-          const float2 a = *reinterpret_cast<const float2*>(Kl + (16 * t2 + l15) * ld + 8 * s + 2 * kq);
-          st[t2] = mfma16(a.x, qf[2 * s], st[t2]);
-          st[t2] = mfma16(a.y, qf[2 * s + 1], st[t2]);
-        }
+      for (int i = 0; i < nb; ++i) {
+        sa = mfma16(cur[i][0], qf[2 * (b0 + i)], sa);
+        sbb = mfma16(cur[i][1], qf[2 * (b0 + i) + 1], sbb);
       }
-    }
-    // st[t2][reg] = S[query = l15][key = j0 + 16*t2 + 4*kq + reg]
+      lds_wait_all();
+#pragma unroll
+      for (int i = 0; i < nn; ++i) pin_after_wait(nxt[i]);
+    });
+    // first V batch goes out now; it lands behind the softmax arithmetic
+    float vA[NTE], vB[NTE];
+    static_for<0, NTE>([&](auto t) { lds_read_b32<64 * decltype(t)::value>(vA[decltype(t)::value], va); });
+
+    // st[r] = S[query = l15][key = j0 + 4*kq + r]
+    const unsigned mbits = __float_as_uint(mk4);
+    float st[4];
     float tmax = -INFINITY;
 #pragma unroll
-    for (int t2 = 0; t2 < 2; ++t2)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int key = j0 + 16 * t2 + 4 * kq + r;
-        float s = st[t2][r];
-        if (key >= C) s = -INFINITY;                       // beyond the alignment: not a key
-        else if (mask && mask[(size_t)b * C + key]) s = fill;  // padded key (axial_attention.py:99-103)
-        st[t2][r] = s;
-        tmax = fmaxf(tmax, s);
-      }
+    for (int r = 0; r < 4; ++r) {
+      const unsigned cls = (mbits >> (8 * r)) & 0xffu;
+      float s = sa[r] + sbb[r];
+      s = cls == 2 ? -INFINITY : (cls == 1 ? fill : s);
+      st[r] = s;
+      tmax = fmaxf(tmax, s);
+    }
     tmax = fmaxf(tmax, __shfl_xor(tmax, 16));
     tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
     const float m_new = fmaxf(m_run, tmax);
-    const float sc = nnj_exp(m_run - m_new);                // 0 on the first tile (m_run = -inf)
+    const float sc = nnj_exp(m_run - m_new);                 // 0 on the first tile (m_run = -inf)
     float psum = 0.f;
 #pragma unroll
-    for (int t2 = 0; t2 < 2; ++t2)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float p = nnj_exp(st[t2][r] - m_new);
-        st[t2][r] = p;
-        psum += p;
-      }
+    for (int r = 0; r < 4; ++r) {
+      const float p = nnj_exp(st[r] - m_new);
+      st[r] = p;
+      psum += p;
+    }
     psum += __shfl_xor(psum, 16);
     psum += __shfl_xor(psum, 32);
     l_run = l_run * sc + psum;
     m_run = m_new;
-    // rescale O rows: row (4*kq + reg) of the C/D layout is query 4*kq+reg -> its scale
-    // lives in the lanes with (lane & 15) == that query
-    float scr[4];
+    // rescale O rows (row 4*kq+reg of the C/D layout is query 4*kq+reg; its scale lives in the lanes
+    // with (lane & 15) == that query); skipped when no running maximum moved in this wave
+    if (!__all(sc == 1.0f)) {
+      float scr[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) scr[r] = __shfl(sc, 4 * kq + r);
-    // O[query x e] += P[query x key] V[key x e]; A = P regs, B = V from LDS
+      for (int r = 0; r < 4; ++r) scr[r] = __shfl(sc, 4 * kq + r);
 #pragma unroll
-    for (int t = 0; t < RA_NTE_MAX; ++t) {
-      if (t < nte) {
-        f32x4 o = O[t];
-        o[0] *= scr[0]; o[1] *= scr[1]; o[2] *= scr[2]; o[3] *= scr[3];
-#pragma unroll
-        for (int t2 = 0; t2 < 2; ++t2)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float vb = Vl[(16 * t2 + 4 * kq + r) * ld + 16 * t + l15];
-            o = mfma16(st[t2][r], vb, o);
-          }
-        O[t] = o;
-      }
+      for (int t = 0; t < NTE; ++t) { O[t][0] *= scr[0]; O[t][1] *= scr[1]; O[t][2] *= scr[2]; O[t][3] *= scr[3]; }
     }
+    lds_wait_all();
+#pragma unroll
+    for (int t = 0; t < NTE; ++t) pin_after_wait(vA[t]);
+    // ---- O[query x e] += P[query x key] V[key x e]; A = P regs, B = V from LDS (one key row per batch)
+    static_for<0, 4>([&](auto ri) {
+      constexpr int r = decltype(ri)::value;
+      float (&cur)[NTE] = (r & 1) ? vB : vA;
+      float (&nxt)[NTE] = (r & 1) ? vA : vB;
+      if constexpr (r + 1 < 4)
+        static_for<0, NTE>([&](auto t) {
+          lds_read_b32<((r + 1) * LD + 16 * decltype(t)::value) * 4>(nxt[decltype(t)::value], va);
+        });
+#pragma unroll
+      for (int t = 0; t < NTE; ++t) O[t] = mfma16(st[r], cur[t], O[t]);
+      lds_wait_all();
+      if constexpr (r + 1 < 4) {
+#pragma unroll
+        for (int t = 0; t < NTE; ++t) pin_after_wait(nxt[t]);
+      }
+    });
   }
   // normalise and store: O[t][reg] is (query q0 + 4*kq + reg, e = 16 t + l15)
   float linv[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) linv[r] = 1.0f / __shfl(l_run, 4 * kq + r);
 #pragma unroll
-  for (int t = 0; t < RA_NTE_MAX; ++t) {
-    if (t < nte) {
+  for (int t = 0; t < NTE; ++t) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int qrow = q0 + 4 * kq + r;
-        if (qrow < C) ctx[base + (size_t)qrow * Epad + 16 * t + l15] = O[t][r] * linv[r];
-      }
+    for (int r = 0; r < 4; ++r) {
+      const int qrow = q0 + 4 * kq + r;
+      if (qrow < C) ctx[base + (size_t)qrow * Epad + 16 * t + l15] = O[t][r] * linv[r];
     }
   }
 }

@@ -48,7 +48,7 @@ __device__ __forceinline__ bool pair_of(int mode, int n, int p, int npairs, cons
   pi = 0; pj = 1;
   if (p >= npairs) return false;
   if (mode == PAIRS_FULL) { pair_from_index(n, p, pi, pj); return true; }
-  const int ip = ij_prev[2 * b];
+  const int ip = min(max(ij_prev[2 * b], 0), n - 1);
   if (p == ip) return false;             // the reference scores (i,i) but never reads it (model.py:186-197)
   pi = p < ip ? p : ip;
   pj = p < ip ? ip : p;
@@ -298,7 +298,7 @@ struct IncLane {
 template <int NT>
 __device__ __forceinline__ IncLane inc_lane(const RowSet& rs, const int* ij_prev, int b, int n, int lane) {
   IncLane L;
-  L.m = ij_prev[2 * b];
+  L.m = min(max(ij_prev[2 * b], 0), n - 1);
   L.slot_m = slot_of(rs, b, L.m);
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
@@ -586,7 +586,7 @@ __global__ __launch_bounds__(256) void k_agg_alpha(RowSet rs, ScorerW w, const i
   __shared__ __attribute__((aligned(16))) float xl[1024];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int chunk = blockIdx.x, b = blockIdx.y;
-  const int pi = ij[2 * b], pj = ij[2 * b + 1];
+  const int pi = min(max(ij[2 * b], 0), n - 1), pj = min(max(ij[2 * b + 1], 0), n - 1);   // never index outside the rows
   const size_t bo = (size_t)b * rs.bstride;
   const size_t oi = bo + (size_t)slot_of(rs, b, pi) * C * 64, oj = bo + (size_t)slot_of(rs, b, pj) * C * 64;
   const int e = tid * 4;                       // element within the chunk: site e/64, feature e%64
@@ -642,7 +642,7 @@ __global__ __launch_bounds__(256) void k_agg_finish(RowSet rs, ScorerW w, const 
   float* al = smem + 12288;       // alpha[64]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5;
   const int b = blockIdx.y;
-  const int pi = ij[2 * b], pj = ij[2 * b + 1];
+  const int pi = min(max(ij[2 * b], 0), n - 1), pj = min(max(ij[2 * b + 1], 0), n - 1);
   stage_weight<64>(Wg_l, w.Wg, 64, tid, 256);
   if (U_out) {
     stage_weight<64>(Wh_l, w.Wh, 64, tid, 256);
@@ -783,7 +783,7 @@ __global__ __launch_bounds__(256) void k_assemble_argmax(const float* __restrict
     }
     __syncthreads();
   }
-  const int bi = red_i[0];
+  const int bi = (red_i[0] >= 0 && red_i[0] < np) ? red_i[0] : 0;   // all-NaN table: stay in range
   const float bv = red_v[0];
   __syncthreads();
   // second best for the top-2 gap
@@ -801,7 +801,10 @@ __global__ __launch_bounds__(256) void k_assemble_argmax(const float* __restrict
     pair_from_index(n, bi, ci, cj);
     if (merges_out) { merges_out[(size_t)b * merges_bstride] = ci; merges_out[(size_t)b * merges_bstride + 1] = cj; }
     if (gap_out) gap_out[(size_t)b * gap_bstride] = np > 1 ? bv - red_v[0] : 0.f;
-    if (forced) { ci = forced[(size_t)b * forced_bstride]; cj = forced[(size_t)b * forced_bstride + 1]; }
+    if (forced) {
+      const int fi = forced[(size_t)b * forced_bstride], fj = forced[(size_t)b * forced_bstride + 1];
+      if (fi >= 0 && fi < fj && fj < n) { ci = fi; cj = fj; }       // out-of-range forcing is ignored
+    }
     ij_cur[2 * b] = ci; ij_cur[2 * b + 1] = cj;
   }
 }
@@ -829,7 +832,7 @@ __global__ __launch_bounds__(256) void k_select_pair(const float* __restrict__ l
     }
     __syncthreads();
   }
-  const int bi = red_i[0];
+  const int bi = (red_i[0] >= 0 && red_i[0] < np) ? red_i[0] : 0;   // all-NaN table: stay in range
   const float bv = red_v[0];
   __syncthreads();
   float second = -INFINITY;
@@ -853,7 +856,7 @@ __global__ __launch_bounds__(256) void k_select_pair(const float* __restrict__ l
 __global__ void k_update_live(int* __restrict__ live, int live_stride, const int* __restrict__ ij, int B, int n) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
-  const int pj = ij[2 * b + 1];
+  const int pj = min(max(ij[2 * b + 1], 1), n - 1);
   int* l = live + (size_t)b * live_stride;
   for (int p = pj; p < n - 1; ++p) l[p] = l[p + 1];
 }
@@ -883,7 +886,7 @@ __global__ void k_index_map(const int* __restrict__ ij_prev, long long* __restri
 __global__ void k_compact_rows(const float* __restrict__ state, const float* __restrict__ merged,
                                const int* __restrict__ ij, float* __restrict__ out, int n, long row_f4) {
   const int t = blockIdx.y, b = blockIdx.z;     // output row t in [0, n-1)
-  const int pi = ij[2 * b], pj = ij[2 * b + 1];
+  const int pi = min(max(ij[2 * b], 0), n - 1), pj = min(max(ij[2 * b + 1], 0), n - 1);
   const int src = t < pj ? t : t + 1;
   const f32x4* s = (t == pi) ? reinterpret_cast<const f32x4*>(merged) + (size_t)b * row_f4
                              : reinterpret_cast<const f32x4*>(state) + ((size_t)b * n + src) * row_f4;
