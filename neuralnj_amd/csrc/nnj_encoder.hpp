@@ -394,59 +394,94 @@ __global__ __launch_bounds__(256) void k_tok1(const float* __restrict__ ctx, con
   }
 
   // ---- column attention
-  f32x16 y[NT][2];
-#pragma unroll
-  for (int nt = 0; nt < NT; ++nt) layer_norm64(y[nt], xr[nt], wc.ln_w, wc.ln_b, hh);
   f32x16 cx[NT][2];
   if (R == 1) {
     // single position: output = out_proj(v_proj(x)) (axial_attention.py:198-209)
+    f32x16 y[NT][2];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) layer_norm64(y[nt], xr[nt], wc.ln_w, wc.ln_b, hh);
     linear_T<2, 2, NT>(cx, y, Wv_l, wc.bv, lane);
   } else {
     const float scaling = rsqrtf((float)NNJ_DH);      // axial_attention.py:214
 #pragma unroll
     for (int hf = 0; hf < 2; ++hf) {                  // heads 4*hf .. 4*hf+3
       f32x16 qh[NT][1], kh[NT][1], vh[NT][1];
+      {
+        f32x16 y[NT][2];                              // LayerNorm recomputed per head-half: cheaper than 64 live VGPRs
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) layer_norm64(y[nt], xr[nt], wc.ln_w, wc.ln_b, hh);
       linear_T<1, 2, NT>(qh, y, Wq_l + hf * 32 * 64, wc.bq + 32 * hf, lane);
       linear_T<1, 2, NT>(kh, y, Wk_l + hf * 32 * 64, wc.bk + 32 * hf, lane);
       linear_T<1, 2, NT>(vh, y, Wv_l + hf * 32 * 64, wc.bv + 32 * hf, lane);
-      // publish k,v of this head-half for all rows of the column (wave-private LDS)
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // publish v of this head-half for all rows of the column (wave-private LDS image [row][32])
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
         const int r = 32 * nt + tok;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-          f32x4 k4 = {kh[nt][0][4 * g], kh[nt][0][4 * g + 1], kh[nt][0][4 * g + 2], kh[nt][0][4 * g + 3]};
           f32x4 v4 = {vh[nt][0][4 * g], vh[nt][0][4 * g + 1], vh[nt][0][4 * g + 2], vh[nt][0][4 * g + 3]};
-          *reinterpret_cast<f32x4*>(kvl + r * 32 + 8 * g + 4 * hh) = k4;
-          *reinterpret_cast<f32x4*>(kvl + 2048 + r * 32 + 8 * g + 4 * hh) = v4;
+          *reinterpret_cast<f32x4*>(kvl + r * 32 + 8 * g + 4 * hh) = v4;
         }
       }
-      // per (token, head): online softmax over the R keys of the column
+      // per head: S^T[key j x query i] = K_h Q_h^T straight from the projection registers (the q/k
+      // accumulators ARE the B/A operands: lane-half hh carries d = 4hh+t), softmax over j inside the
+      // lane (+ one exchange with the other half), P.V on the VALU with V broadcast from LDS
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt)
+      for (int g = 0; g < 4; ++g) {
+        f32x16 sc_[NT][NT];                       // [query tile][key tile]
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const float q0 = qh[nt][0][4 * g] * scaling, q1 = qh[nt][0][4 * g + 1] * scaling,
-                      q2 = qh[nt][0][4 * g + 2] * scaling, q3 = qh[nt][0][4 * g + 3] * scaling;
-          float m = -INFINITY, l = 0.f, a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-          for (int j = 0; j < R; ++j) {
-            const f32x4 kj = *reinterpret_cast<const f32x4*>(kvl + j * 32 + 8 * g + 4 * hh);
-            float s = q0 * kj[0] + q1 * kj[1] + q2 * kj[2] + q3 * kj[3];
-            s += __shfl_xor(s, 32);
-            if (padded) s = -10000.0f;             // every key of a padded column (axial_attention.py:220-224)
-            const float mn = fmaxf(m, s);
-            const float sc = nnj_exp(m - mn);
-            const float p = nnj_exp(s - mn);
-            const f32x4 vj = *reinterpret_cast<const f32x4*>(kvl + 2048 + j * 32 + 8 * g + 4 * hh);
-            l = l * sc + p;
-            a0 = a0 * sc + p * vj[0]; a1 = a1 * sc + p * vj[1];
-            a2 = a2 * sc + p * vj[2]; a3 = a3 * sc + p * vj[3];
-            m = mn;
+        for (int it = 0; it < NT; ++it)
+#pragma unroll
+          for (int jt = 0; jt < NT; ++jt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sc_[it][jt][r] = 0.f;
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+              sc_[it][jt] = mfma32(kh[jt][0][4 * g + t], qh[it][0][4 * g + t] * scaling, sc_[it][jt]);
           }
+#pragma unroll
+        for (int it = 0; it < NT; ++it) {
+          // element reg of tile jt is key j = 32*jt + (reg&3) + 8*(reg>>2) + 4*hh
+          float m = -INFINITY;
+#pragma unroll
+          for (int jt = 0; jt < NT; ++jt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int j = 32 * jt + (r & 3) + 8 * (r >> 2) + 4 * hh;
+              float v = sc_[it][jt][r];
+              if (padded) v = -10000.0f;           // every key of a padded column (axial_attention.py:220-224)
+              if (j >= R) v = -INFINITY;
+              sc_[it][jt][r] = v;
+              m = fmaxf(m, v);
+            }
+          m = fmaxf(m, __shfl_xor(m, 32));
+          float l = 0.f, o8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int jt = 0; jt < NT; ++jt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const float p = nnj_exp(sc_[it][jt][r] - m);
+              l += p;
+              const float* vp = kvl + (32 * jt + (r & 3) + 8 * (r >> 2) + 4 * hh) * 32 + 8 * g;
+              const f32x4 v0 = *reinterpret_cast<const f32x4*>(vp);
+              const f32x4 v1 = *reinterpret_cast<const f32x4*>(vp + 4);
+#pragma unroll
+              for (int t = 0; t < 4; ++t) { o8[t] += p * v0[t]; o8[4 + t] += p * v1[t]; }
+            }
+          l += __shfl_xor(l, 32);
           const float inv = 1.0f / l;
-          cx[nt][hf][4 * g] = a0 * inv; cx[nt][hf][4 * g + 1] = a1 * inv;
-          cx[nt][hf][4 * g + 2] = a2 * inv; cx[nt][hf][4 * g + 3] = a3 * inv;
+          // this lane keeps d = 4hh+t: add the partner half's partial sums for those d
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const float send = hh ? o8[t] : o8[4 + t];
+            const float recv = __shfl_xor(send, 32);
+            cx[it][hf][4 * g + t] = ((hh ? o8[4 + t] : o8[t]) + recv) * inv;
+          }
+          __builtin_amdgcn_sched_barrier(0);        // keep the heads' live ranges apart
         }
+      }
     }
   }
   f32x16 o[NT][2];
