@@ -161,10 +161,10 @@ PairGeom pair_geom(int mode, int n, int B, int C) {
     return g;
   }
   g.npairs = mode == PAIRS_FULL ? n * (n - 1) / 2 : n;
-  g.tpw = mode == PAIRS_FULL ? 2 : 1;
+  g.tpw = 1;                       // 8 tiles per workgroup: 8 waves x 1 tile (alpha) or 4 waves x 2 tiles (score)
   const int tiles = (g.npairs + 31) / 32;
-  g.pg = (tiles + 4 * g.tpw - 1) / (4 * g.tpw);
-  g.ppad = g.pg * 4 * g.tpw * 32;
+  g.pg = (tiles + 8 * g.tpw - 1) / (8 * g.tpw);
+  g.ppad = g.pg * 8 * g.tpw * 32;
   int nsc = (2048 + g.pg * B - 1) / (g.pg * B);
   const int max_nsc = (C + 7) / 8;
   if (nsc > max_nsc) nsc = max_nsc;
@@ -346,8 +346,9 @@ int launch_pair_scores(nnj_handle* h, const RowSet& rs, const int* ij_prev, cons
   if (has_ctx) {
     {
       Scope sc(h, st, PK_PAIR_ALPHA);
-      const size_t lds = 3 * 4096 * sizeof(float);
-      hipLaunchKernelGGL(k_pair_alpha<2>, grid, dim3(256), lds, st, rs, sw, ij_prev, base + w.alpha_part, mode, n, C,
+      const size_t lds = 2 * 3 * 4096 * sizeof(float);
+      if (int rc = set_lds(h, k_pair_alpha<1, 8>, lds)) return rc;
+      hipLaunchKernelGGL((k_pair_alpha<1, 8>), grid, dim3(512), lds, st, rs, sw, ij_prev, base + w.alpha_part, mode, n, C,
                          g.npairs, g.ppad, g.cs);
     }
     {
@@ -358,9 +359,9 @@ int launch_pair_scores(nnj_handle* h, const RowSet& rs, const int* ij_prev, cons
   }
   {
     Scope sc(h, st, PK_PAIR_SCORE);
-    const size_t lds = 5 * 4096 * sizeof(float);
-    if (int rc = set_lds(h, k_pair_score<2>, lds)) return rc;
-    hipLaunchKernelGGL(k_pair_score<2>, grid, dim3(256), lds, st, rs, sw, ij_prev, base + w.alpha, mask,
+    const size_t lds = (2 + 2 * 3) * 4096 * sizeof(float);
+    if (int rc = set_lds(h, k_pair_score<2, 4>, lds)) return rc;
+    hipLaunchKernelGGL((k_pair_score<2, 4>), grid, dim3(256), lds, st, rs, sw, ij_prev, base + w.alpha, mask,
                        base + w.score_part, mode, n, C, g.npairs, g.ppad, g.cs, has_ctx);
   }
   return NNJ_OK;

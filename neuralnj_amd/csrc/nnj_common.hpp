@@ -25,6 +25,15 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define NNJ_DH 8          // head dim
 #define NNJ_F 256         // FFN hidden
 
+// compile-time loop: f(std::integral_constant<int, I>) for I in [0, N)
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+
 __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
@@ -35,17 +44,18 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
 // exp via v_exp_f32: relative error ~1e-7*|x|; every use here is exp(x), x <= 0 (softmax
 // terms, sigmoid, erfc tail), so the absolute error stays below fp32 rounding of the sums.
 __device__ __forceinline__ float nnj_exp(float x) { return __expf(x); }
+// 1/x and 1/sqrt(x) by v_rcp_f32 / v_rsq_f32 (1 ulp): an IEEE division costs ~10 VALU instructions
+__device__ __forceinline__ float nnj_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float nnj_rsqrt(float x) { return __builtin_amdgcn_rsqf(x); }
 __device__ __forceinline__ float sigmoidf_(float x) {
-  // 1/(1+e^-x) without overflow on either side
-  const float e = nnj_exp(-fabsf(x));
-  const float r = 1.0f / (1.0f + e);
-  return x >= 0.f ? r : e * r;
+  // 1/(1+e^-x): e^-x overflowing to +inf gives rcp(inf) = 0, the correct limit
+  return nnj_rcp(1.0f + nnj_exp(-x));
 }
 // nn.GELU() default (exact erf form).  erfc by Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7,
 // a few fp32 ulps of the result), written so that 1+erf(x) for x<0 has no cancellation.
 __device__ __forceinline__ float gelu_erf(float x) {
   const float ax = fabsf(x) * 0.70710678118654752440f;
-  const float t = 1.0f / (1.0f + 0.3275911f * ax);
+  const float t = nnj_rcp(1.0f + 0.3275911f * ax);
   float p = 1.061405429f;
   p = p * t - 1.453152027f;
   p = p * t + 1.421413741f;
@@ -102,15 +112,6 @@ __device__ __forceinline__ void pin_after_wait(T& x) {
 __device__ __forceinline__ unsigned lds_addr(const void* p) {   // LDS byte offset of a __shared__ pointer
   return (unsigned)(size_t)(const __attribute__((address_space(3))) char*)p;
 }
-// compile-time loop: f(std::integral_constant<int, I>) for I in [0, N)
-template <int I, int N, typename F>
-__device__ __forceinline__ void static_for(F&& f) {
-  if constexpr (I < N) {
-    f(std::integral_constant<int, I>{});
-    static_for<I + 1, N>(f);
-  }
-}
-
 // ---- LDS weight image: W[out][in] row-major, 16-byte chunks XOR-swizzled by row so
 // that a ds_read_b128 whose 16-lane groups read 16 different rows at the same logical
 // chunk is bank-conflict free.  IN must be a multiple of 64 floats.
@@ -140,66 +141,65 @@ __device__ __forceinline__ void stage_weight_sub(float* lds, const float* __rest
 }
 
 // ---- linear layer on feature-major tiles.
-//   out[nt][mt] (MT tiles of 32 out-features) = bias + W * in,   in has KT tiles.
-//   W: swizzled LDS image [32*MT][32*KT]; bias: pointer readable with 16-byte loads
-//   (LDS or global), may be nullptr.
+//   out[nt][mt] (MT tiles of 32 out-features) = bias + W * in   (or out += W * in),  in has KT tiles.
+//   W: LDS image [32*MT][LDW] (XOR-swizzled 16-byte chunks when SWZ); bias readable with 16-byte loads.
+//   The A fragments are software pipelined (fragment s+1 is read before the MFMAs of fragment s) and
+//   consecutive MFMA groups alternate between the MT independent accumulators.  Per accumulator the
+//   k order is ascending, so results do not depend on the interleaving.
+template <int MT, int KT, int NT, int LDW, bool SWZ, bool ACC, bool BIAS>
+__device__ __forceinline__ void linear_core(f32x16 (&out)[NT][MT], const f32x16 (&in)[NT][KT],
+                                            const float* W, const float* bias, int lane) {
+  const int row = lane & 31, hh = lane >> 5;
+  if constexpr (!ACC) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (BIAS) b4 = *reinterpret_cast<const f32x4*>(bias + 32 * mt + 8 * g + 4 * hh);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          out[nt][mt][4 * g + 0] = b4[0]; out[nt][mt][4 * g + 1] = b4[1];
+          out[nt][mt][4 * g + 2] = b4[2]; out[nt][mt][4 * g + 3] = b4[3];
+        }
+      }
+  }
+  constexpr int NSTEP = KT * 4 * MT;          // step s: kt = s / (4*MT), g = (s / MT) % 4, mt = s % MT
+  auto frag = [&](int s) {
+    const int kt = s / (4 * MT), g = (s / MT) % 4, mt = s % MT;
+    const int wrow = 32 * mt + row;
+    const int chunk = (32 * kt + 8 * g + 4 * hh) >> 2;
+    return *reinterpret_cast<const f32x4*>(W + wrow * LDW + 4 * (SWZ ? wswz(wrow, chunk) : chunk));
+  };
+  f32x4 a[2];
+  a[0] = frag(0);
+  static_for<0, NSTEP>([&](auto si) {
+    constexpr int s = decltype(si)::value;
+    constexpr int kt = s / (4 * MT), g = (s / MT) % 4, mt = s % MT;
+    if constexpr (s + 1 < NSTEP) a[(s + 1) & 1] = frag(s + 1);
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) out[nt][mt] = mfma32(a[s & 1][t], in[nt][kt][4 * g + t], out[nt][mt]);
+  });
+}
+// out = bias + W*in (bias must not be null)
 template <int MT, int KT, int NT, int LDW = 32 * KT, bool SWZ = true>
 __device__ __forceinline__ void linear_T(f32x16 (&out)[NT][MT], const f32x16 (&in)[NT][KT],
                                          const float* W, const float* bias, int lane) {
-  const int row = lane & 31, hh = lane >> 5;
-  constexpr int IN = LDW;
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt) {
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
-      if (bias) b4 = *reinterpret_cast<const f32x4*>(bias + 32 * mt + 8 * g + 4 * hh);
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-        out[nt][mt][4 * g + 0] = b4[0]; out[nt][mt][4 * g + 1] = b4[1];
-        out[nt][mt][4 * g + 2] = b4[2]; out[nt][mt][4 * g + 3] = b4[3];
-      }
-    }
-    const int wrow = 32 * mt + row;
-#pragma unroll
-    for (int kt = 0; kt < KT; ++kt) {
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int chunk = (32 * kt + 8 * g + 4 * hh) >> 2;
-        const f32x4 a = *reinterpret_cast<const f32x4*>(W + wrow * IN + 4 * (SWZ ? wswz(wrow, chunk) : chunk));
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-#pragma unroll
-          for (int nt = 0; nt < NT; ++nt) out[nt][mt] = mfma32(a[t], in[nt][kt][4 * g + t], out[nt][mt]);
-        }
-      }
-    }
-  }
+  linear_core<MT, KT, NT, LDW, SWZ, false, true>(out, in, W, bias, lane);
 }
-
-// accumulate variant: out += W * in (no bias init)
-template <int MT, int KT, int NT, int LDW = 32 * KT>
+// out = W*in
+template <int MT, int KT, int NT, int LDW = 32 * KT, bool SWZ = true>
+__device__ __forceinline__ void linear_T_nb(f32x16 (&out)[NT][MT], const f32x16 (&in)[NT][KT],
+                                            const float* W, int lane) {
+  linear_core<MT, KT, NT, LDW, SWZ, false, false>(out, in, W, nullptr, lane);
+}
+// out += W*in
+template <int MT, int KT, int NT, int LDW = 32 * KT, bool SWZ = true>
 __device__ __forceinline__ void linear_T_acc(f32x16 (&out)[NT][MT], const f32x16 (&in)[NT][KT],
                                              const float* W, int lane) {
-  const int row = lane & 31, hh = lane >> 5;
-  constexpr int IN = LDW;
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt) {
-    const int wrow = 32 * mt + row;
-#pragma unroll
-    for (int kt = 0; kt < KT; ++kt) {
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int chunk = (32 * kt + 8 * g + 4 * hh) >> 2;
-        const f32x4 a = *reinterpret_cast<const f32x4*>(W + wrow * IN + 4 * wswz(wrow, chunk));
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-#pragma unroll
-          for (int nt = 0; nt < NT; ++nt) out[nt][mt] = mfma32(a[t], in[nt][kt][4 * g + t], out[nt][mt]);
-        }
-      }
-    }
-  }
+  linear_core<MT, KT, NT, LDW, SWZ, true, false>(out, in, W, nullptr, lane);
 }
 
 // ---- token I/O: 64 features of one token <-> two accumulators (zeros when !valid)
@@ -241,7 +241,7 @@ __device__ __forceinline__ void layer_norm64(f32x16 (&y)[2], const f32x16 (&x)[2
 #pragma unroll
     for (int r = 0; r < 16; ++r) { const float d = x[mt][r] - mean; v += d * d; }
   v += __shfl_xor(v, 32);
-  const float inv = 1.0f / sqrtf(v * (1.0f / 64.0f) + 1e-5f);
+  const float inv = nnj_rsqrt(v * (1.0f / 64.0f) + 1e-5f);
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt)
 #pragma unroll

@@ -315,7 +315,7 @@ __global__ __launch_bounds__(256) void k_row_attn(const float* __restrict__ Q, c
   // normalise and store: O[t][reg] is (query q0 + 4*kq + reg, e = 16 t + l15)
   float linv[4];
 #pragma unroll
-  for (int r = 0; r < 4; ++r) linv[r] = 1.0f / __shfl(l_run, 4 * kq + r);
+  for (int r = 0; r < 4; ++r) linv[r] = nnj_rcp(__shfl(l_run, 4 * kq + r));
 #pragma unroll
   for (int t = 0; t < NTE; ++t) {
 #pragma unroll
@@ -471,7 +471,7 @@ __global__ __launch_bounds__(256) void k_tok1(const float* __restrict__ ctx, con
               for (int t = 0; t < 4; ++t) { o8[t] += p * v0[t]; o8[4 + t] += p * v1[t]; }
             }
           l += __shfl_xor(l, 32);
-          const float inv = 1.0f / l;
+          const float inv = nnj_rcp(l);
           // this lane keeps d = 4hh+t: add the partner half's partial sums for those d
 #pragma unroll
           for (int t = 0; t < 4; ++t) {

@@ -55,30 +55,45 @@ __device__ __forceinline__ bool pair_of(int mode, int n, int p, int npairs, cons
   return true;
 }
 
-// ---- stage the per-site images of all n rows into LDS (swizzled [64][64] images)
-// img_a <- A-operand source rows (Kp for phase A), img_s <- S, img_u <- U,
-// img_t <- S transposed [d][r] (optional)
-__device__ __forceinline__ void stage_site(const RowSet& rs, int b, int n, int C, int c, const float* srcA,
-                                           float* img_a, float* img_s, float* img_u, float* img_t,
-                                           int tid) {
-  for (int i = tid; i < 64 * 16; i += 256) {
+// ---- per-site images of all n rows in LDS (swizzled [64][64] images), staged through registers
+// in two halves (T14 split): site_load issues the global loads of the NEXT site before the MFMAs of
+// the current one, site_store writes them to the other LDS buffer afterwards.
+//   img_a <- A-operand source rows (K' for phase A), img_s <- S, img_u <- U,
+//   img_t <- S transposed [d][r] (phase B)
+template <int NTHR>
+struct SiteRegs { f32x4 a[1024 / NTHR], s[1024 / NTHR], u[1024 / NTHR]; };
+template <bool WITH_A, int NTHR>
+__device__ __forceinline__ void site_load(SiteRegs<NTHR>& R, const RowSet& rs, int b, int n, int C, int c,
+                                          const float* srcA, int tid) {
+#pragma unroll
+  for (int k = 0; k < 1024 / NTHR; ++k) {
+    const int i = tid + NTHR * k;
     const int r = i >> 4, ch = i & 15;
-    f32x4 va = {0.f, 0.f, 0.f, 0.f}, vs = va, vu = va;
+    R.a[k] = R.s[k] = R.u[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
     if (r < n) {
       const size_t off = (size_t)b * rs.bstride + ((size_t)slot_of(rs, b, r) * C + c) * 64 + 4 * ch;
-      vs = *reinterpret_cast<const f32x4*>(rs.S + off);
-      vu = *reinterpret_cast<const f32x4*>(rs.U + off);
-      if (img_a) va = *reinterpret_cast<const f32x4*>(srcA + off);
+      R.s[k] = *reinterpret_cast<const f32x4*>(rs.S + off);
+      R.u[k] = *reinterpret_cast<const f32x4*>(rs.U + off);
+      if (WITH_A) R.a[k] = *reinterpret_cast<const f32x4*>(srcA + off);
     }
+  }
+}
+template <bool WITH_A, bool WITH_T, int NTHR>
+__device__ __forceinline__ void site_store(const SiteRegs<NTHR>& R, float* img_a, float* img_s, float* img_u,
+                                           float* img_t, int tid) {
+#pragma unroll
+  for (int k = 0; k < 1024 / NTHR; ++k) {
+    const int i = tid + NTHR * k;
+    const int r = i >> 4, ch = i & 15;
     const int sw = 4 * wswz(r, ch);
-    *reinterpret_cast<f32x4*>(img_s + r * 64 + sw) = vs;
-    *reinterpret_cast<f32x4*>(img_u + r * 64 + sw) = vu;
-    if (img_a) *reinterpret_cast<f32x4*>(img_a + r * 64 + sw) = va;
-    if (img_t) {
+    *reinterpret_cast<f32x4*>(img_s + r * 64 + sw) = R.s[k];
+    *reinterpret_cast<f32x4*>(img_u + r * 64 + sw) = R.u[k];
+    if (WITH_A) *reinterpret_cast<f32x4*>(img_a + r * 64 + sw) = R.a[k];
+    if (WITH_T) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int d = 4 * ch + e;
-        img_t[d * 64 + 4 * wswz(d, r >> 2) + (r & 3)] = vs[e];
+        img_t[d * 64 + 4 * wswz(d, r >> 2) + (r & 3)] = R.s[k][e];
       }
     }
   }
@@ -100,7 +115,7 @@ __device__ __forceinline__ void gate_tile(f32x16 (&x)[2], const float* img_s, co
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         const float z = sigmoidf_(ui[t] - uj[t] + b4[t]);
-        x[mt][4 * g + t] = z * si[t] + (1.0f - z) * sj[t];
+        x[mt][4 * g + t] = sj[t] + z * (si[t] - sj[t]);     // z*x_i + (1-z)*x_j
       }
     }
 }
@@ -108,14 +123,11 @@ __device__ __forceinline__ void gate_tile(f32x16 (&x)[2], const float* img_s, co
 // ------------------------------------------------------------------ k_pair_alpha
 // Phase A: alpha_part[b][sc][pair][r] = sum_{c in chunk sc} x_pair[c,:] . K'_r[c,:]
 // grid (nsc, pair groups, B); 4 waves x TPW tiles of 32 pairs.
-template <int TPW>
-__global__ __launch_bounds__(256) void k_pair_alpha(RowSet rs, ScorerW w, const int* __restrict__ ij_prev,
+template <int TPW, int NW>
+__global__ __launch_bounds__(64 * NW) void k_pair_alpha(RowSet rs, ScorerW w, const int* __restrict__ ij_prev,
                                                     float* __restrict__ alpha_part, int mode, int n, int C,
                                                     int npairs, int ppad, int cs) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* img_k = smem;
-  float* img_s = smem + 4096;
-  float* img_u = smem + 8192;
+  extern __shared__ __attribute__((aligned(16))) float smem[];   // 2 x [img_k | img_s | img_u]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5;
   const int sc = blockIdx.x, pg = blockIdx.y, b = blockIdx.z;
   const int c0 = sc * cs, c1 = min(C, c0 + cs);
@@ -123,9 +135,9 @@ __global__ __launch_bounds__(256) void k_pair_alpha(RowSet rs, ScorerW w, const 
   bool any = false;
 #pragma unroll
   for (int tt = 0; tt < TPW; ++tt) {
-    const int p = ((pg * 4 + wave) * TPW + tt) * 32 + (lane & 31);
+    const int p = ((pg * NW + wave) * TPW + tt) * 32 + (lane & 31);
     pair_of(mode, n, p, npairs, ij_prev, b, pi[tt], pj[tt]);
-    any = any || (((pg * 4 + wave) * TPW + tt) * 32 < npairs);
+    any = any || (((pg * NW + wave) * TPW + tt) * 32 < npairs);
   }
   f32x16 acc[TPW][1][2];
 #pragma unroll
@@ -134,22 +146,31 @@ __global__ __launch_bounds__(256) void k_pair_alpha(RowSet rs, ScorerW w, const 
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[tt][0][mt][r] = 0.f;
+  SiteRegs<64 * NW> R;
+  if (c0 < c1) {
+    site_load<true, 64 * NW>(R, rs, b, n, C, c0, rs.Kp, tid);
+    site_store<true, false, 64 * NW>(R, smem, smem + 4096, smem + 8192, nullptr, tid);
+  }
+  __syncthreads();
   for (int c = c0; c < c1; ++c) {
-    __syncthreads();
-    stage_site(rs, b, n, C, c, rs.Kp, img_k, img_s, img_u, nullptr, tid);
-    __syncthreads();
+    float* cur = smem + ((c - c0) & 1) * 12288;
+    float* nxt = smem + (((c - c0) & 1) ^ 1) * 12288;
+    const bool more = c + 1 < c1;
+    if (more) site_load<true, 64 * NW>(R, rs, b, n, C, c + 1, rs.Kp, tid);     // in flight behind the MFMAs
     if (any) {
 #pragma unroll
       for (int tt = 0; tt < TPW; ++tt) {
         f32x16 x[1][2];
-        gate_tile(x[0], img_s, img_u, w.bh, pi[tt], pj[tt], hh);
-        linear_T_acc<2, 2, 1>(acc[tt], x, img_k, lane);
+        gate_tile(x[0], cur + 4096, cur + 8192, w.bh, pi[tt], pj[tt], hh);
+        linear_T_acc<2, 2, 1>(acc[tt], x, cur, lane);
       }
     }
+    if (more) site_store<true, false, 64 * NW>(R, nxt, nxt + 4096, nxt + 8192, nullptr, tid);
+    __syncthreads();
   }
 #pragma unroll
   for (int tt = 0; tt < TPW; ++tt) {
-    const int p = ((pg * 4 + wave) * TPW + tt) * 32 + (lane & 31);
+    const int p = ((pg * NW + wave) * TPW + tt) * 32 + (lane & 31);
     if (p < ppad) {
       float* dst = alpha_part + (((size_t)b * gridDim.x + sc) * ppad + p) * 64;
 #pragma unroll
@@ -201,30 +222,28 @@ __global__ __launch_bounds__(256) void k_alpha_softmax(RowSet rs, ScorerW w, con
 // Phase B: per (pair, site): x_g = sum_r alpha_r S_r ; g = W_g x_g + b_g ; w = sigmoid(g);
 // x = (1-w) x + w x_g ; s = s_out(x) ; score_part[b][sc][pair] = sum_{c in chunk} mask_c s
 // (model.py:148-153, 93-97).  has_ctx = (n > 2) (model.py:111).
-template <int TPW>
-__global__ __launch_bounds__(256) void k_pair_score(RowSet rs, ScorerW w, const int* __restrict__ ij_prev,
+template <int TPW, int NW>
+__global__ __launch_bounds__(64 * NW) void k_pair_score(RowSet rs, ScorerW w, const int* __restrict__ ij_prev,
                                                     const float* __restrict__ alpha,
                                                     const uint8_t* __restrict__ mask,
                                                     float* __restrict__ score_part, int mode, int n, int C,
                                                     int npairs, int ppad, int cs, int has_ctx) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* img_t = smem;            // S_c transposed [d][r]
-  float* img_s = smem + 4096;
-  float* img_u = smem + 8192;
-  float* Wg_l = smem + 12288;
-  float* S0_l = smem + 16384;
+  extern __shared__ __attribute__((aligned(16))) float smem[];   // Wg | S0 | 2 x [img_t | img_s | img_u]
+  float* Wg_l = smem;
+  float* S0_l = smem + 4096;
+  float* ring = smem + 8192;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5;
   const int sc = blockIdx.x, pg = blockIdx.y, b = blockIdx.z;
   const int c0 = sc * cs, c1 = min(C, c0 + cs);
-  stage_weight<64>(Wg_l, w.Wg, 64, tid, 256);
-  stage_weight<64>(S0_l, w.S0, 64, tid, 256);
+  stage_weight<64>(Wg_l, w.Wg, 64, tid, 64 * NW);
+  stage_weight<64>(S0_l, w.S0, 64, tid, 64 * NW);
   int pi[TPW], pj[TPW];
   bool any = false;
   f32x16 al[TPW][1][2];
   float score[TPW];
 #pragma unroll
   for (int tt = 0; tt < TPW; ++tt) {
-    const int tile = (pg * 4 + wave) * TPW + tt;
+    const int tile = (pg * NW + wave) * TPW + tt;
     const int p = tile * 32 + (lane & 31);
     pair_of(mode, n, p, npairs, ij_prev, b, pi[tt], pj[tt]);
     any = any || (tile * 32 < npairs);
@@ -232,19 +251,20 @@ __global__ __launch_bounds__(256) void k_pair_score(RowSet rs, ScorerW w, const 
     const bool ld = has_ctx && p < ppad;
     load_token64(al[tt][0], alpha + ((size_t)b * ppad + p) * 64, ld, hh);
   }
-  // s_out.2 weights for this lane's 32 features
-  float s2w[2][16];
-#pragma unroll
-  for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const f32x4 v = *reinterpret_cast<const f32x4*>(w.s2w + 32 * mt + 8 * g + 4 * hh);
-      s2w[mt][4 * g] = v[0]; s2w[mt][4 * g + 1] = v[1]; s2w[mt][4 * g + 2] = v[2]; s2w[mt][4 * g + 3] = v[3];
-    }
+  SiteRegs<64 * NW> R;
+  if (c0 < c1) {
+    site_load<false, 64 * NW>(R, rs, b, n, C, c0, nullptr, tid);
+    site_store<false, true, 64 * NW>(R, nullptr, ring + 4096, ring + 8192, ring, tid);
+  }
+  __syncthreads();
   for (int c = c0; c < c1; ++c) {
-    __syncthreads();
-    stage_site(rs, b, n, C, c, nullptr, nullptr, img_s, img_u, has_ctx ? img_t : nullptr, tid);
-    __syncthreads();
+    float* cur = ring + ((c - c0) & 1) * 12288;
+    float* nxt = ring + (((c - c0) & 1) ^ 1) * 12288;
+    const float* img_t = cur;
+    const float* img_s = cur + 4096;
+    const float* img_u = cur + 8192;
+    const bool more = c + 1 < c1;
+    if (more) site_load<false, 64 * NW>(R, rs, b, n, C, c + 1, nullptr, tid);   // in flight behind the MFMAs
     const float mc = (mask && mask[(size_t)b * C + c]) ? 0.f : 1.f;   // seq_mask (model.py:96)
     if (any) {
 #pragma unroll
@@ -253,14 +273,14 @@ __global__ __launch_bounds__(256) void k_pair_score(RowSet rs, ScorerW w, const 
         gate_tile(x[0], img_s, img_u, w.bh, pi[tt], pj[tt], hh);
         if (has_ctx) {
           f32x16 xg[1][2], g[1][2];
-          linear_T<2, 2, 1>(xg, al[tt], img_t, nullptr, lane);
+          linear_T_nb<2, 2, 1>(xg, al[tt], img_t, lane);
           linear_T<2, 2, 1>(g, xg, Wg_l, w.bg, lane);
 #pragma unroll
           for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
               const float wg = sigmoidf_(g[0][mt][r]);
-              x[0][mt][r] = (1.0f - wg) * x[0][mt][r] + wg * xg[0][mt][r];
+              x[0][mt][r] += wg * (xg[0][mt][r] - x[0][mt][r]);   // (1-w)*x + w*x_g
             }
         }
         f32x16 s1[1][2];
@@ -269,16 +289,22 @@ __global__ __launch_bounds__(256) void k_pair_score(RowSet rs, ScorerW w, const 
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) s += gelu_erf(s1[0][mt][r]) * s2w[mt][r];
+          for (int g4 = 0; g4 < 4; ++g4) {
+            const f32x4 w4 = *reinterpret_cast<const f32x4*>(w.s2w + 32 * mt + 8 * g4 + 4 * hh);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) s += gelu_erf(s1[0][mt][4 * g4 + t]) * w4[t];
+          }
         s += __shfl_xor(s, 32);
         score[tt] += (s + w.s2b) * mc;
       }
     }
+    if (more) site_store<false, true, 64 * NW>(R, nullptr, nxt + 4096, nxt + 8192, nxt, tid);
+    __syncthreads();
   }
   if (hh == 0) {
 #pragma unroll
     for (int tt = 0; tt < TPW; ++tt) {
-      const int p = ((pg * 4 + wave) * TPW + tt) * 32 + (lane & 31);
+      const int p = ((pg * NW + wave) * TPW + tt) * 32 + (lane & 31);
       if (p < ppad) score_part[((size_t)b * gridDim.x + sc) * ppad + p] = score[tt];
     }
   }
@@ -348,7 +374,7 @@ __device__ __forceinline__ void inc_gate(f32x16 (&x)[NT][2], const IncRaw<NT>& r
           const float z = sigmoidf_((L.r_first[nt] ? -d : d) + b4[t]);
           const float a = L.r_first[nt] ? raw.sr[nt][mt][k] : sh.sm[mt][k];
           const float c2 = L.r_first[nt] ? sh.sm[mt][k] : raw.sr[nt][mt][k];
-          x[nt][mt][k] = z * a + (1.0f - z) * c2;
+          x[nt][mt][k] = c2 + z * (a - c2);                 // z*x_i + (1-z)*x_j
         }
     }
 }
@@ -496,14 +522,14 @@ __global__ __launch_bounds__(256) void k_inc_score(RowSet rs, ScorerW w, const i
               at[0][kt][4 * g4] = v[0]; at[0][kt][4 * g4 + 1] = v[1]; at[0][kt][4 * g4 + 2] = v[2]; at[0][kt][4 * g4 + 3] = v[3];
             }
         }
-        linear_T<2, NT, 1, 68, false>(xg, at, img_t, nullptr, lane);
+        linear_T_nb<2, NT, 1, 68, false>(xg, at, img_t, lane);
         linear_T<2, 2, 1>(g, xg, Wg_l, w.bg, lane);
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const float wg = sigmoidf_(g[0][mt][r]);
-            xt[0][mt][r] = (1.0f - wg) * xt[0][mt][r] + wg * xg[0][mt][r];
+            xt[0][mt][r] += wg * (xg[0][mt][r] - xt[0][mt][r]);   // (1-w)*x + w*x_g
           }
       }
       f32x16 s1[1][2];
@@ -537,7 +563,7 @@ __device__ __forceinline__ void row_transforms(const f32x16 (&s)[1][2], const fl
                                                int c, bool valid, int lane) {
   const int hh = lane >> 5;
   f32x16 o[1][2];
-  linear_T<2, 2, 1>(o, s, Wh_l, nullptr, lane);
+  linear_T_nb<2, 2, 1>(o, s, Wh_l, lane);
   store_token64(o[0], U_row + (size_t)c * 64, valid, hh);
   linear_T<2, 2, 1>(o, s, A_l, w.a0, lane);
   store_token64(o[0], Kp_row + (size_t)c * 64, valid, hh);
@@ -602,7 +628,7 @@ __global__ __launch_bounds__(256) void k_agg_alpha(RowSet rs, ScorerW w, const i
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       const float z = sigmoidf_(ui[t] - uj[t] + b4[t]);
-      x[t] = z * si[t] + (1.0f - z) * sj[t];
+      x[t] = sj[t] + z * (si[t] - sj[t]);
     }
   }
   *reinterpret_cast<f32x4*>(xl + e) = x;
@@ -692,7 +718,7 @@ __global__ __launch_bounds__(256) void k_agg_finish(RowSet rs, ScorerW w, const 
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
           const float z = sigmoidf_(ui[mt][4 * g + t] - uj[mt][4 * g + t] + b4[t]);
-          x[0][mt][4 * g + t] = z * si[mt][4 * g + t] + (1.0f - z) * sj[mt][4 * g + t];
+          x[0][mt][4 * g + t] = sj[mt][4 * g + t] + z * (si[mt][4 * g + t] - sj[mt][4 * g + t]);
         }
       }
   }
@@ -716,7 +742,7 @@ __global__ __launch_bounds__(256) void k_agg_finish(RowSet rs, ScorerW w, const 
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const float wg = sigmoidf_(g[0][mt][r]);
-        x[0][mt][r] = (1.0f - wg) * x[0][mt][r] + wg * xg[0][mt][r];
+        x[0][mt][r] += wg * (xg[0][mt][r] - x[0][mt][r]);
       }
   }
   const int oslot = in_place ? slot_i : 0;
