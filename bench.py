@@ -174,8 +174,9 @@ def main():
                 ach = models[name]["flops"] / avg_s / 1e12
                 traffic = None
                 tpath = os.path.join(REPO, "profiles", "traffic.json")
-                if os.path.exists(tpath):
-                    traffic = json.load(open(tpath)).get(name, {}).get("hbm_bytes_per_launch")
+                if os.path.exists(tpath) and (B, T, L) == (256, 50, 1024):
+                    # measured HBM bytes per launch (rocprofv3 PMC passes, see profiles/traffic.json "source")
+                    traffic = json.load(open(tpath)).get("per_kind", {}).get(name, {}).get("hbm_bytes_per_launch")
                 roof = {"kernel": name, "bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS,
                         "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
                         "avg_launch_ms": ms / cnt, "launches": cnt,
