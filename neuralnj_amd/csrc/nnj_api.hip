@@ -268,10 +268,14 @@ int launch_encoder(nnj_handle* h, const uint8_t* codes, const uint8_t* mask, flo
     {
       Scope sc(h, st, PK_TOK2);
       const size_t lds = (size_t)16384 * sizeof(float);
-      if (int rc = set_lds(h, k_tok2<NT>, lds)) return rc;
       const bool more = l + 1 < nl;
-      hipLaunchKernelGGL(k_tok2<NT>, dim3(colblocks), dim3(256), lds, st, x, mask, ffn_ptrs(h, h->lo[l]),
-                         more ? attn_ptrs(h, h->lo[l + 1].row) : none, Q, K, V, B, T, C, d.Epad, more ? 1 : 0);
+      {   // flat token tiling: 256 consecutive (column,row) tokens of one MSA per workgroup
+        const int wg_per_b = (T * C + 255) / 256;
+        if (int rc = set_lds(h, k_tok2f, lds)) return rc;
+        hipLaunchKernelGGL(k_tok2f, dim3((unsigned)(wg_per_b * B)), dim3(512), lds, st, x, mask, ffn_ptrs(h, h->lo[l]),
+                           more ? attn_ptrs(h, h->lo[l + 1].row) : none, Q, K, V, B, T, C, d.Epad, more ? 1 : 0,
+                           wg_per_b);
+      }
     }
   }
   HIPCHK(h, hipGetLastError());

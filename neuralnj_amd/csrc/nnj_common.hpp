@@ -202,15 +202,18 @@ __device__ __forceinline__ void linear_T_acc(f32x16 (&out)[NT][MT], const f32x16
   linear_core<MT, KT, NT, LDW, SWZ, true, false>(out, in, W, nullptr, lane);
 }
 
-// ---- token I/O: 64 features of one token <-> two accumulators (zeros when !valid)
+// ---- token I/O: 64 features of one token <-> two accumulators (zeros when !valid).
+// The loads are UNCONDITIONAL (a branch per load would put every load in its own basic block and
+// serialise the memory latency): `p` must be a readable address even when !valid -- callers clamp
+// the index -- and the result is zeroed by a select.
 __device__ __forceinline__ void load_token64(f32x16 (&a)[2], const float* p, bool valid, int hh) {
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (valid) v = *reinterpret_cast<const f32x4*>(p + 32 * mt + 8 * g + 4 * hh);
-      a[mt][4 * g + 0] = v[0]; a[mt][4 * g + 1] = v[1]; a[mt][4 * g + 2] = v[2]; a[mt][4 * g + 3] = v[3];
+      const f32x4 v = *reinterpret_cast<const f32x4*>(p + 32 * mt + 8 * g + 4 * hh);
+      a[mt][4 * g + 0] = valid ? v[0] : 0.f; a[mt][4 * g + 1] = valid ? v[1] : 0.f;
+      a[mt][4 * g + 2] = valid ? v[2] : 0.f; a[mt][4 * g + 3] = valid ? v[3] : 0.f;
     }
 }
 __device__ __forceinline__ void store_token64(const f32x16 (&a)[2], float* p, bool valid, int hh) {

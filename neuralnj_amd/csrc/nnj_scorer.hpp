@@ -69,13 +69,15 @@ __device__ __forceinline__ void site_load(SiteRegs<NTHR>& R, const RowSet& rs, i
   for (int k = 0; k < 1024 / NTHR; ++k) {
     const int i = tid + NTHR * k;
     const int r = i >> 4, ch = i & 15;
-    R.a[k] = R.s[k] = R.u[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    if (r < n) {
-      const size_t off = (size_t)b * rs.bstride + ((size_t)slot_of(rs, b, r) * C + c) * 64 + 4 * ch;
-      R.s[k] = *reinterpret_cast<const f32x4*>(rs.S + off);
-      R.u[k] = *reinterpret_cast<const f32x4*>(rs.U + off);
-      if (WITH_A) R.a[k] = *reinterpret_cast<const f32x4*>(srcA + off);
-    }
+    const bool live = r < n;                  // rows >= n: load row 0 (always there) and zero by select
+    const size_t off = (size_t)b * rs.bstride + ((size_t)slot_of(rs, b, live ? r : 0) * C + c) * 64 + 4 * ch;
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    const f32x4 vs = *reinterpret_cast<const f32x4*>(rs.S + off);
+    const f32x4 vu = *reinterpret_cast<const f32x4*>(rs.U + off);
+    R.s[k] = live ? vs : z;
+    R.u[k] = live ? vu : z;
+    R.a[k] = z;
+    if (WITH_A) { const f32x4 va = *reinterpret_cast<const f32x4*>(srcA + off); R.a[k] = live ? va : z; }
   }
 }
 template <bool WITH_A, bool WITH_T, int NTHR>
@@ -599,7 +601,7 @@ __global__ __launch_bounds__(256) void k_row_xf(const float* __restrict__ S, flo
   const bool valid = c < C;
   const size_t roff = (size_t)b * bstride + (size_t)row * C * 64;
   f32x16 s[1][2];
-  load_token64(s[0], S + roff + (size_t)c * 64, valid, lane >> 5);
+  load_token64(s[0], S + roff + (size_t)(valid ? c : 0) * 64, valid, lane >> 5);
   row_transforms(s, Wh_l, A_l, w, U + roff, Kp + roff, beta_part + ((size_t)b * slots + row) * ntile32 + tile,
                  c, valid, lane);
 }
@@ -706,10 +708,10 @@ __global__ __launch_bounds__(256) void k_agg_finish(RowSet rs, ScorerW w, const 
   f32x16 x[1][2], xg[1][2];
   {
     f32x16 si[2], sj[2], ui[2], uj[2];
-    load_token64(si, rs.S + bo + ((size_t)slot_i * C + c) * 64, valid, hh);
-    load_token64(sj, rs.S + bo + ((size_t)slot_j * C + c) * 64, valid, hh);
-    load_token64(ui, rs.U + bo + ((size_t)slot_i * C + c) * 64, valid, hh);
-    load_token64(uj, rs.U + bo + ((size_t)slot_j * C + c) * 64, valid, hh);
+    load_token64(si, rs.S + bo + ((size_t)slot_i * C + (valid ? c : 0)) * 64, valid, hh);
+    load_token64(sj, rs.S + bo + ((size_t)slot_j * C + (valid ? c : 0)) * 64, valid, hh);
+    load_token64(ui, rs.U + bo + ((size_t)slot_i * C + (valid ? c : 0)) * 64, valid, hh);
+    load_token64(uj, rs.U + bo + ((size_t)slot_j * C + (valid ? c : 0)) * 64, valid, hh);
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -731,7 +733,7 @@ __global__ __launch_bounds__(256) void k_agg_finish(RowSet rs, ScorerW w, const 
       const float a = al[r];
       if (a == 0.f) continue;                        // rows i, j carry exactly zero weight
       f32x16 sr[2];
-      load_token64(sr, rs.S + bo + ((size_t)slot_of(rs, b, r) * C + c) * 64, valid, hh);
+      load_token64(sr, rs.S + bo + ((size_t)slot_of(rs, b, r) * C + (valid ? c : 0)) * 64, valid, hh);
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt) xg[0][mt] += a * sr[mt];
     }
