@@ -6,7 +6,9 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <algorithm>
 #include <cstring>
+#include <initializer_list>
 #include <vector>
 
 #include "../../include/nnj.h"
@@ -157,7 +159,7 @@ PairGeom pair_geom(int mode, int n, int B, int C) {
     if (blocks < 1) blocks = 1;
     g.cs = (C + blocks - 1) / blocks;
     blocks = (C + g.cs - 1) / g.cs;
-    g.nsc = blocks * 4;
+    g.nsc = blocks * (n > 32 ? 4 : 8);       // partial sets: one per wave (4 waves for n > 32, 8 otherwise)
     return g;
   }
   g.npairs = mode == PAIRS_FULL ? n * (n - 1) / 2 : n;
@@ -188,12 +190,14 @@ LoopWs loop_ws(int B, int T, int C) {
   w.Kp = take(rows);
   w.beta = take((size_t)B * T * nt32);
   size_t ap = 0, al = 0, sp = 0;
-  for (int mode = 0; mode < 2; ++mode) {
-    PairGeom g = pair_geom(mode, T, B, C);
-    ap = std::max(ap, (size_t)B * g.nsc * g.ppad * 64);
-    al = std::max(al, (size_t)B * g.ppad * 64);
-    sp = std::max(sp, (size_t)B * g.nsc * g.ppad);
-  }
+  for (int mode = 0; mode < 2; ++mode)
+    for (int n : {T, std::min(T, 32)}) {      // the incremental geometry changes at n = 32
+      if (n < 2) continue;
+      PairGeom g = pair_geom(mode, n, B, C);
+      ap = std::max(ap, (size_t)B * g.nsc * g.ppad * 64);
+      al = std::max(al, (size_t)B * g.ppad * 64);
+      sp = std::max(sp, (size_t)B * g.nsc * g.ppad);
+    }
   w.alpha_part = take(ap);
   w.alpha = take(al);
   w.score_part = take(sp);
@@ -306,19 +310,19 @@ int launch_pair_scores(nnj_handle* h, const RowSet& rs, const int* ij_prev, cons
   const ScorerW sw = scorer_ptrs(h);
   const int has_ctx = n > 2 ? 1 : 0;
   if (mode == PAIRS_INCR) {
-    const dim3 grid((unsigned)(g.nsc / 4), (unsigned)B);
     const bool big = n > 32;
+    const dim3 grid((unsigned)(g.nsc / (big ? 4 : 8)), (unsigned)B);
     if (has_ctx) {
       {
         Scope sc(h, st, PK_PAIR_ALPHA_INCR);
         if (big) {
           const size_t lds = (size_t)4 * 2 * 2 * 2048 * sizeof(float);
-          if (int rc = set_lds(h, k_inc_alpha<2>, lds)) return rc;
-          hipLaunchKernelGGL(k_inc_alpha<2>, grid, dim3(256), lds, st, rs, sw, ij_prev, base + w.alpha_part, n, C, g.cs);
+          if (int rc = set_lds(h, k_inc_alpha<2, 4>, lds)) return rc;
+          hipLaunchKernelGGL((k_inc_alpha<2, 4>), grid, dim3(256), lds, st, rs, sw, ij_prev, base + w.alpha_part, n, C, g.cs);
         } else {
-          const size_t lds = (size_t)4 * 2 * 1 * 2048 * sizeof(float);
-          if (int rc = set_lds(h, k_inc_alpha<1>, lds)) return rc;
-          hipLaunchKernelGGL(k_inc_alpha<1>, grid, dim3(256), lds, st, rs, sw, ij_prev, base + w.alpha_part, n, C, g.cs);
+          const size_t lds = (size_t)8 * 2 * 1 * 2048 * sizeof(float);
+          if (int rc = set_lds(h, k_inc_alpha<1, 8>, lds)) return rc;
+          hipLaunchKernelGGL((k_inc_alpha<1, 8>), grid, dim3(512), lds, st, rs, sw, ij_prev, base + w.alpha_part, n, C, g.cs);
         }
       }
       {
@@ -329,18 +333,20 @@ int launch_pair_scores(nnj_handle* h, const RowSet& rs, const int* ij_prev, cons
     }
     {
       Scope sc(h, st, PK_PAIR_SCORE_INCR);
-      const size_t lds = (size_t)(8192 + 4 * 64 * 68) * sizeof(float);
       if (big) {
-        if (int rc = set_lds(h, k_inc_score<2, true>, lds)) return rc;
-        hipLaunchKernelGGL((k_inc_score<2, true>), grid, dim3(256), lds, st, rs, sw, ij_prev, base + w.alpha, mask,
+        const size_t lds = (size_t)(8192 + 4 * 64 * 68) * sizeof(float);
+        if (int rc = set_lds(h, k_inc_score<2, true, 4>, lds)) return rc;
+        hipLaunchKernelGGL((k_inc_score<2, true, 4>), grid, dim3(256), lds, st, rs, sw, ij_prev, base + w.alpha, mask,
                            base + w.score_part, n, C, g.cs);
       } else if (has_ctx) {
-        if (int rc = set_lds(h, k_inc_score<1, true>, lds)) return rc;
-        hipLaunchKernelGGL((k_inc_score<1, true>), grid, dim3(256), lds, st, rs, sw, ij_prev, base + w.alpha, mask,
+        const size_t lds = (size_t)(8192 + 8 * 64 * 36) * sizeof(float);
+        if (int rc = set_lds(h, k_inc_score<1, true, 8>, lds)) return rc;
+        hipLaunchKernelGGL((k_inc_score<1, true, 8>), grid, dim3(512), lds, st, rs, sw, ij_prev, base + w.alpha, mask,
                            base + w.score_part, n, C, g.cs);
       } else {
-        if (int rc = set_lds(h, k_inc_score<1, false>, lds)) return rc;
-        hipLaunchKernelGGL((k_inc_score<1, false>), grid, dim3(256), lds, st, rs, sw, ij_prev, base + w.alpha, mask,
+        const size_t lds = (size_t)(8192 + 8 * 64 * 36) * sizeof(float);
+        if (int rc = set_lds(h, k_inc_score<1, false, 8>, lds)) return rc;
+        hipLaunchKernelGGL((k_inc_score<1, false, 8>), grid, dim3(512), lds, st, rs, sw, ij_prev, base + w.alpha, mask,
                            base + w.score_part, n, C, g.cs);
       }
     }

@@ -384,9 +384,9 @@ __device__ __forceinline__ void inc_gate(f32x16 (&x)[NT][2], const IncRaw<NT>& r
 // Phase A: alpha partials.  grid (nsc, B).  K' image of a site goes HBM -> LDS by LDS-DMA
 // (global_load_lds_dwordx4, swizzle applied on the per-lane SOURCE address), double buffered
 // per wave.  part[b][sc*4+wave][pair r][r'].
-template <int NT>
-__global__ __launch_bounds__(256) void k_inc_alpha(RowSet rs, ScorerW w, const int* __restrict__ ij_prev,
-                                                   float* __restrict__ alpha_part, int n, int C, int cs) {
+template <int NT, int NW>
+__global__ __launch_bounds__(64 * NW) void k_inc_alpha(RowSet rs, ScorerW w, const int* __restrict__ ij_prev,
+                                                       float* __restrict__ alpha_part, int n, int C, int cs) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63, hh = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -421,13 +421,13 @@ __global__ __launch_bounds__(256) void k_inc_alpha(RowSet rs, ScorerW w, const i
     for (int i = 0; i < 8 * NT; ++i)
       lds_dma16(kp_b + gsrc[i] + (unsigned)(c * 64), kbuf + i * 256);
   }
-  for (; c < c1; c += 4) {
+  for (; c < c1; c += NW) {
     IncShared sh;
     inc_load_shared(sh, rs, L, bo, C, c, hh);
     wait_vmem_all();                                       // this site's rows and K' image have landed
     f32x16 x[NT][2];
     inc_gate<NT>(x, raw, sh, L, w.bh, hh);
-    const int cn = c + 4 < c1 ? c + 4 : c;                 // prefetch the next site behind the MFMAs
+    const int cn = c + NW < c1 ? c + NW : c;                 // prefetch the next site behind the MFMAs
     {                                                      // (last iteration: harmless reload of this site)
       inc_load<NT>(raw, rs, L, bo, n, C, cn, hh);
       float* nb = kbuf + (cur ^ 1) * (NT * 2048);
@@ -438,7 +438,7 @@ __global__ __launch_bounds__(256) void k_inc_alpha(RowSet rs, ScorerW w, const i
     linear_T_acc<NT, 2, NT>(acc, x, kbuf + cur * (NT * 2048), lane);
     cur ^= 1;
   }
-  const int part = sc * 4 + wave, nparts = gridDim.x * 4;
+  const int part = sc * NW + wave, nparts = gridDim.x * NW;
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
     float* dst = alpha_part + (((size_t)b * nparts + part) * 64 + L.r[nt]) * 64;
@@ -457,8 +457,8 @@ __global__ __launch_bounds__(256) void k_inc_alpha(RowSet rs, ScorerW w, const i
 // Phase B: scores of the new pairs.  The transposed site image S_c^T (A operand of
 // x_g^T = S_c^T alpha^T) is written by the wave itself from the rows its lanes hold.
 // part[b][sc*4+wave][pair r].
-template <int NT, bool CTX>
-__global__ __launch_bounds__(256) void k_inc_score(RowSet rs, ScorerW w, const int* __restrict__ ij_prev,
+template <int NT, bool CTX, int NW>
+__global__ __launch_bounds__(64 * NW) void k_inc_score(RowSet rs, ScorerW w, const int* __restrict__ ij_prev,
                                                    const float* __restrict__ alpha,
                                                    const uint8_t* __restrict__ mask,
                                                    float* __restrict__ score_part, int n, int C, int cs) {
@@ -467,11 +467,12 @@ __global__ __launch_bounds__(256) void k_inc_score(RowSet rs, ScorerW w, const i
   float* S0_l = smem + 4096;
   const int tid = threadIdx.x, lane = tid & 63, hh = lane >> 5, tok = lane & 31;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  float* img_t = smem + 8192 + wave * (64 * 68);          // [64 d][68]: row stride 68 floats, no swizzle
+  constexpr int TLD = 32 * NT + 4;                          // row stride of the transposed image (conflict free)
+  float* img_t = smem + 8192 + wave * (64 * TLD);         // [64 d][TLD], no swizzle
   const int sc = blockIdx.x, b = blockIdx.y;
   const int c0 = sc * cs, c1 = min(C, c0 + cs);
-  stage_weight<64>(Wg_l, w.Wg, 64, tid, 256);
-  stage_weight<64>(S0_l, w.S0, 64, tid, 256);
+  stage_weight<64>(Wg_l, w.Wg, 64, tid, 64 * NW);
+  stage_weight<64>(S0_l, w.S0, 64, tid, 64 * NW);
   __syncthreads();
   constexpr bool has_ctx = CTX;                            // CTX = (n > 2), model.py:111
   const IncLane L = inc_lane<NT>(rs, ij_prev, b, n, lane);
@@ -484,7 +485,7 @@ __global__ __launch_bounds__(256) void k_inc_score(RowSet rs, ScorerW w, const i
   IncRaw<NT> raw;
   int c = c0 + wave;
   if (c < c1) inc_load<NT>(raw, rs, L, bo, n, C, c, hh);
-  for (; c < c1; c += 4) {
+  for (; c < c1; c += NW) {
     f32x16 x[NT][2];
     {
       IncShared sh;
@@ -502,12 +503,12 @@ __global__ __launch_bounds__(256) void k_inc_score(RowSet rs, ScorerW w, const i
           for (int g = 0; g < 4; ++g)
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-              img_t[(4 * hh) * 68 + r + (32 * mt + 8 * g + t) * 68] = raw.sr[nt][mt][4 * g + t];
+              img_t[(4 * hh) * TLD + r + (32 * mt + 8 * g + t) * TLD] = raw.sr[nt][mt][4 * g + t];
             }
       }
     }
     const float mc = (mask && mask[(size_t)b * C + c]) ? 0.f : 1.f;     // seq_mask (model.py:96)
-    const int cn = c + 4;
+    const int cn = c + NW;
     inc_load<NT>(raw, rs, L, bo, n, C, cn < c1 ? cn : c, hh);          // prefetch behind the MFMAs (last: harmless reload)
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {                                    // one 32-pair tile at a time
@@ -524,7 +525,7 @@ __global__ __launch_bounds__(256) void k_inc_score(RowSet rs, ScorerW w, const i
               at[0][kt][4 * g4] = v[0]; at[0][kt][4 * g4 + 1] = v[1]; at[0][kt][4 * g4 + 2] = v[2]; at[0][kt][4 * g4 + 3] = v[3];
             }
         }
-        linear_T_nb<2, NT, 1, 68, false>(xg, at, img_t, lane);
+        linear_T_nb<2, NT, 1, TLD, false>(xg, at, img_t, lane);
         linear_T<2, 2, 1>(g, xg, Wg_l, w.bg, lane);
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
@@ -551,7 +552,7 @@ __global__ __launch_bounds__(256) void k_inc_score(RowSet rs, ScorerW w, const i
     }
   }
   if (hh == 0) {
-    const int part = sc * 4 + wave, nparts = gridDim.x * 4;
+    const int part = sc * NW + wave, nparts = gridDim.x * NW;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) score_part[((size_t)b * nparts + part) * 64 + L.r[nt]] = score[nt];
   }
