@@ -133,8 +133,9 @@ struct RaShape {
   static constexpr int Epad = 16 * NTE;
   static constexpr int LD = (Epad - 4 + 31) / 32 * 32 + 4;
   static constexpr int CPR = LD / 4, CPE = Epad / 4;              // 16-byte chunks per LDS row / global row
-  static constexpr int NDMA = (2 * RA_KEYS * CPR + 255) / 256;    // LDS-DMA instructions per wave per tile
-  static constexpr int STAGE_F = NDMA * 4 * 256;                  // floats per ring stage
+  static constexpr int KI = (RA_KEYS * CPR + 63) / 64;            // 1-KiB DMA instructions per K (or V) tile
+  static constexpr int NDMA = (2 * KI + 3) / 4;                   // LDS-DMA instructions per wave per tile
+  static constexpr int STAGE_F = NDMA * 4 * 256;                  // floats per ring stage: [K: KI KiB | V: KI KiB]
   static constexpr int NS = 2 * NTE;                              // float2 k-steps of S^T
 };
 
@@ -167,29 +168,38 @@ __global__ __launch_bounds__(256) void k_row_attn(const float* __restrict__ Q, c
   for (int j = tid; j < nkt * RA_KEYS; j += 256)
     maskl[j] = j >= C ? 2 : ((mask && mask[(size_t)b * C + j]) ? 1 : 0);
 
-  // DMA plan of this lane: instruction i of this wave fills LDS chunk q = (wave*NDMA+i)*64+lane of the
-  // stage image [K tile 16 x LD | V tile 16 x LD]; (is_V, float offset from the tile's first key row)
-  // or -1 for pad / unused positions.
-  int dsrc[NDMA];
+  // DMA plan: the stage image is [K tile | V tile], each KI whole 1-KiB instructions, so every
+  // instruction has ONE wave-uniform source base (K or V tile start) plus a 32-bit per-lane offset
+  // (0 for lanes that land in the row pad: they re-read the tile's first bytes, harmless).
+  unsigned voff[NDMA];
 #pragma unroll
   for (int i = 0; i < NDMA; ++i) {
-    int q = (wave * NDMA + i) * 64 + lane;
-    int isv = 0;
-    if (q >= RA_KEYS * SH::CPR) { q -= RA_KEYS * SH::CPR; isv = 1; }
+    const int I = wave * NDMA + i;                      // wave-uniform instruction index in the stage
+    const int q = (I < SH::KI ? I : I - SH::KI) * 64 + lane;
     const int row = q / SH::CPR, cc = q - row * SH::CPR;
-    dsrc[i] = (row < RA_KEYS && cc < SH::CPE) ? ((row * Epad + 4 * cc) | (isv << 30)) : -1;
+    voff[i] = (row < RA_KEYS && cc < SH::CPE) ? (unsigned)(row * Epad + 4 * cc) : 0u;
   }
   auto issue_tile = [&](int kt, int stage) {
     const int j0 = kt * RA_KEYS;
     float* dst = smem + stage * SH::STAGE_F + wave * NDMA * 256;
+    const float* Kt = K + base + (size_t)j0 * Epad;     // wave-uniform tile bases
+    const float* Vt = V + base + (size_t)j0 * Epad;
+    if (j0 + RA_KEYS <= C) {                            // (wave-uniform) full tile: base + 32-bit offset
 #pragma unroll
-    for (int i = 0; i < NDMA; ++i) {
-      const int d = dsrc[i];
-      const int off = d & 0x3fffffff;
-      // pad positions and keys beyond the alignment read row 0 of the (b,h) slice: finite, unused
-      const bool ok = d >= 0 && (j0 + off / Epad) < C;
-      const float* src = (((d >> 30) & 1) ? V : K) + base + (ok ? (size_t)j0 * Epad + off : 0);
-      lds_dma16(src, dst + i * 256);
+      for (int i = 0; i < NDMA; ++i) {
+        const int I = wave * NDMA + i;
+        if (I < 2 * SH::KI) lds_dma16((I < SH::KI ? Kt : Vt) + voff[i], dst + i * 256);
+      }
+    } else {                                            // last tile of an alignment with C % 16 != 0
+#pragma unroll
+      for (int i = 0; i < NDMA; ++i) {
+        const int I = wave * NDMA + i;
+        if (I < 2 * SH::KI) {
+          unsigned o = voff[i];
+          if ((j0 + (int)(o / Epad)) >= C) o = 0u;      // keys beyond the alignment: finite filler
+          lds_dma16((I < SH::KI ? Kt : Vt) + o, dst + i * 256);
+        }
+      }
     }
   };
 
@@ -208,7 +218,7 @@ __global__ __launch_bounds__(256) void k_row_attn(const float* __restrict__ Q, c
   // LDS byte addresses of this lane's operand streams inside a stage
   const unsigned smem_b = lds_addr(smem);
   const unsigned ka0 = smem_b + (unsigned)(l15 * LD + 2 * kq) * 4u;                    // K[key l15][2kq + 8s]
-  const unsigned va0 = smem_b + (unsigned)((RA_KEYS + 4 * kq) * LD + l15) * 4u;        // V[4kq + r][l15 + 16t]
+  const unsigned va0 = smem_b + (unsigned)(SH::KI * 256 + 4 * kq * LD + l15) * 4u;     // V[4kq + r][l15 + 16t]
   const unsigned ma0 = lds_addr(maskl) + 4u * kq;
 
   constexpr int KB = NS < 10 ? NS : 10;            // float2 reads per S batch
