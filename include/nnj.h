@@ -144,6 +144,20 @@ int nnj_rollout_argmax(nnj_handle* h, const uint8_t* codes_dev, const uint8_t* m
                        float* logits_trace_dev, float* top2_gap_dev, float* state_out_dev,
                        void* ws_dev, size_t ws_bytes, void* stream);
 
+/* Sampling twin of nnj_rollout_argmax -- the eval, argmax=False branch of reinforce_rollout used by
+ * RL_Search ("NeuralNJ-MC", reference finetune_rl_search.py:147, 338-427): at
+ * every step the pair is drawn from Categorical(logits / temperature) by inverse CDF (fp64, flat pair
+ * order) on the caller's uniforms_dev float [B,T-1] in [0,1) -- the reference's own RNG stream is not
+ * reproducible across devices, so the stream is an input.  n_encode = B: codes/mask hold B alignments;
+ * n_encode = 1: ONE alignment (codes [1,T,L], mask [1,L]) is encoded once and replicated to the B
+ * rollouts (the reference re-encodes it per rollout).  merges_out [B,T-1,2] = the sampled pairs.
+ * Tree likelihood scoring of the sampled trees (raxml-ng) is outside this library. */
+int nnj_rollout_sample(nnj_handle* h, const uint8_t* codes_dev, const uint8_t* mask_dev,
+                       int32_t B, int32_t T, int32_t L, int32_t n_encode,
+                       const float* uniforms_dev, float temperature,
+                       int32_t* merges_out_dev, float* logits_trace_dev,
+                       void* ws_dev, size_t ws_bytes, void* stream);
+
 /* Kernel timing for bench.py's roofline object: when enabled, every kernel launch of
  * the entry points is bracketed by a HIP event pair on the launch stream, tagged with
  * its kernel kind.  After the caller has synchronised the stream, nnj_profile_read

@@ -39,6 +39,8 @@ _SIGS = {
     "nnj_select_pair": ([_vp, _vp, _vp, _vp, C.c_int32, C.c_int32, _vp], C.c_int),
     "nnj_rollout_argmax": ([_vp, _vp, _vp, C.c_int32, C.c_int32, C.c_int32, _vp, _vp, _vp, _vp, _vp, _vp,
                             C.c_size_t, _vp], C.c_int),
+    "nnj_rollout_sample": ([_vp, _vp, _vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _vp, C.c_float, _vp, _vp, _vp,
+                            C.c_size_t, _vp], C.c_int),
     "nnj_profile_enable": ([_vp, C.c_int32], C.c_int),
     "nnj_profile_kinds": ([], C.c_int),
     "nnj_profile_kind_name": ([C.c_int32], C.c_char_p),
@@ -240,6 +242,30 @@ class Nnj:
             out["top2_gap"] = gap
         if want_state:
             out["state"] = st
+        return out
+
+    def rollout_sample(self, codes, mask, uniforms, temperature=1.0, replicas=None, want_trace=False):
+        """Sampled rollouts (NeuralNJ-MC device part).  `uniforms` float [B,T-1] in [0,1).
+        replicas=None: codes [B,T,L] are B alignments.  replicas=B: codes [1,T,L] is ONE alignment,
+        encoded once and rolled out B times."""
+        codes = self._u8(codes)
+        n_enc, T, L = codes.shape
+        B = n_enc if replicas is None else int(replicas)
+        if replicas is not None and n_enc != 1:
+            raise ValueError("replicas needs a single alignment (codes [1,T,L])")
+        mask = self._u8(mask)
+        u = self._f32(uniforms)
+        assert tuple(u.shape) == (B, T - 1)
+        merges = torch.empty((B, T - 1, 2), dtype=torch.int32, device=self.device)
+        total = sum(n * (n - 1) // 2 for n in range(2, T + 1))
+        trace = torch.empty((B, total), dtype=torch.float32, device=self.device) if want_trace else None
+        ws = self.workspace(B, T, L)
+        self._chk(self.lib.nnj_rollout_sample(self.h, _p(codes), _p(mask), B, T, L, 1 if replicas is not None else B,
+                                              _p(u), C.c_float(float(temperature)), _p(merges), _p(trace), _p(ws),
+                                              ws.numel(), self._stream()))
+        out = dict(merges=merges)
+        if want_trace:
+            out["logits"] = trace
         return out
 
     # ------------------------------------------------------------------ profiling

@@ -572,7 +572,7 @@ int nnj_pair_scores_full(nnj_handle* h, const float* state, const uint8_t* mask,
     Scope sc(h, st, PK_ASSEMBLE);
     hipLaunchKernelGGL(k_assemble_argmax, dim3((unsigned)B), dim3(256), 0, st, base + w.score_part, g.nsc, g.ppad,
                        (const float*)nullptr, (const int*)nullptr, logits_out, (float*)nullptr, 0L, (const int*)nullptr,
-                       0L, (int*)nullptr, 0L, (float*)nullptr, 0L, ij, (int)PAIRS_FULL, n);
+                       0L, (int*)nullptr, 0L, (float*)nullptr, 0L, ij, (int)PAIRS_FULL, n, (const float*)nullptr, 0L, 1.0f);
   }
   HIPCHK(h, hipGetLastError());
   return NNJ_OK;
@@ -596,7 +596,7 @@ int nnj_pair_scores_incr(nnj_handle* h, const float* state, const uint8_t* mask,
     Scope sc(h, st, PK_ASSEMBLE);
     hipLaunchKernelGGL(k_assemble_argmax, dim3((unsigned)B), dim3(256), 0, st, base + w.score_part, g.nsc, g.ppad,
                        logits_prev, ij_prev, logits_out, (float*)nullptr, 0L, (const int*)nullptr, 0L, (int*)nullptr, 0L,
-                       (float*)nullptr, 0L, ij, (int)PAIRS_INCR, n);
+                       (float*)nullptr, 0L, ij, (int)PAIRS_INCR, n, (const float*)nullptr, 0L, 1.0f);
   }
   HIPCHK(h, hipGetLastError());
   return NNJ_OK;
@@ -662,11 +662,13 @@ int nnj_select_pair(nnj_handle* h, const float* logits, int32_t* ij_out, float* 
   return NNJ_OK;
 }
 
-int nnj_rollout_argmax(nnj_handle* h, const uint8_t* codes, const uint8_t* mask, int32_t B, int32_t T, int32_t L,
-                       const int32_t* forced, int32_t* merges_out, float* trace, float* gap, float* state_out,
-                       void* ws, size_t ws_bytes, void* stream) {
+static int rollout_impl(nnj_handle* h, const uint8_t* codes, const uint8_t* mask_in, int32_t B, int32_t T, int32_t L,
+                        int32_t n_encode, const int32_t* forced, const float* uniforms, float inv_temp,
+                        int32_t* merges_out, float* trace, float* gap, float* state_out, void* ws, size_t ws_bytes,
+                        void* stream) {
   if (int rc = ready(h)) return rc;
-  if (!codes || !merges_out || T < 2) return fail(h, NNJ_ERR_ARG, "nnj_rollout_argmax: bad argument");
+  if (!codes || !merges_out || T < 2) return fail(h, NNJ_ERR_ARG, "rollout: bad argument");
+  if (n_encode != B && n_encode != 1) return fail(h, NNJ_ERR_ARG, "rollout: n_encode must be 1 or B");
   if (int rc = check_shape(h, B, T, L)) return rc;
   if (int rc = need_ws(h, ws, ws_bytes, B, T, L)) return rc;
   hipStream_t st = static_cast<hipStream_t>(stream);
@@ -674,9 +676,19 @@ int nnj_rollout_argmax(nnj_handle* h, const uint8_t* codes, const uint8_t* mask,
   float* S = static_cast<float*>(ws);
   const size_t state = align_up((size_t)B * T * C * 64, 64);
   float* base = S + state;
-  if (int rc = run_encoder(h, codes, mask, S, base, B, T, C, st)) return rc;      // finetune_rl_search.py:108-112
-  if (state_out) HIPCHK(h, hipMemcpyAsync(state_out, S, (size_t)B * T * C * 64 * sizeof(float), hipMemcpyDeviceToDevice, st));
   const LoopWs w = loop_ws(B, T, C);
+  const uint8_t* mask = mask_in;
+  if (int rc = run_encoder(h, codes, mask_in, S, base, n_encode, T, C, st)) return rc;   // finetune_rl_search.py:108-112
+  if (n_encode == 1 && B > 1) {
+    Scope sc(h, st, PK_MISC);
+    hipLaunchKernelGGL(k_replicate, dim3(64, (unsigned)(B - 1)), dim3(256), 0, st, S, (long)T * C * 16);
+    if (mask_in) {
+      uint8_t* mrep = reinterpret_cast<uint8_t*>(base + w.merged);       // [B][L] bytes fit in the merged-row scratch
+      hipLaunchKernelGGL(k_replicate_u8, dim3((unsigned)(((size_t)B * L + 255) / 256)), dim3(256), 0, st, mask_in, mrep, B, L);
+      mask = mrep;
+    }
+  }
+  if (state_out) HIPCHK(h, hipMemcpyAsync(state_out, S, (size_t)B * T * C * 64 * sizeof(float), hipMemcpyDeviceToDevice, st));
   int* live = reinterpret_cast<int*>(base + w.live);
   int* ij = reinterpret_cast<int*>(base + w.ij);
   {
@@ -700,7 +712,8 @@ int nnj_rollout_argmax(nnj_handle* h, const uint8_t* codes, const uint8_t* mask,
       hipLaunchKernelGGL(k_assemble_argmax, dim3((unsigned)B), dim3(256), 0, st, base + w.score_part, g.nsc, g.ppad,
                          (const float*)lg[(step + 1) & 1], (const int*)ij, lg[step & 1], trace ? trace + off : nullptr,
                          (long)total, forced ? forced + 2 * step : nullptr, (long)(T - 1) * 2, merges_out + 2 * step,
-                         (long)(T - 1) * 2, gap ? gap + step : nullptr, (long)(T - 1), ij, mode, n);
+                         (long)(T - 1) * 2, gap ? gap + step : nullptr, (long)(T - 1), ij, mode, n,
+                         uniforms ? uniforms + step : nullptr, (long)(T - 1), inv_temp);
     }
     off += (size_t)n * (n - 1) / 2;
     if (n > 2) {                                                                                    // env.step :164
@@ -712,6 +725,21 @@ int nnj_rollout_argmax(nnj_handle* h, const uint8_t* codes, const uint8_t* mask,
   }
   HIPCHK(h, hipGetLastError());
   return NNJ_OK;
+}
+
+int nnj_rollout_argmax(nnj_handle* h, const uint8_t* codes, const uint8_t* mask, int32_t B, int32_t T, int32_t L,
+                       const int32_t* forced, int32_t* merges_out, float* trace, float* gap, float* state_out,
+                       void* ws, size_t ws_bytes, void* stream) {
+  return rollout_impl(h, codes, mask, B, T, L, B, forced, nullptr, 1.0f, merges_out, trace, gap, state_out, ws, ws_bytes,
+                      stream);
+}
+
+int nnj_rollout_sample(nnj_handle* h, const uint8_t* codes, const uint8_t* mask, int32_t B, int32_t T, int32_t L,
+                       int32_t n_encode, const float* uniforms, float temperature, int32_t* merges_out, float* trace,
+                       void* ws, size_t ws_bytes, void* stream) {
+  if (!uniforms || !(temperature > 0.f)) return fail(h, NNJ_ERR_ARG, "nnj_rollout_sample: uniforms and a positive temperature are required");
+  return rollout_impl(h, codes, mask, B, T, L, n_encode, nullptr, uniforms, 1.0f / temperature, merges_out, trace, nullptr,
+                      nullptr, ws, ws_bytes, stream);
 }
 
 int nnj_debug_encoder_stop(nnj_handle* h, int32_t stage) {

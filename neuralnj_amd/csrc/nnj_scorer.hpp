@@ -769,7 +769,9 @@ __global__ __launch_bounds__(256) void k_assemble_argmax(const float* __restrict
                                                          const int* __restrict__ forced, long forced_bstride,
                                                          int* __restrict__ merges_out, long merges_bstride,
                                                          float* __restrict__ gap_out, long gap_bstride,
-                                                         int* ij_cur, int mode, int n) {
+                                                         int* ij_cur, int mode, int n,
+                                                         const float* __restrict__ uniforms, long u_bstride,
+                                                         float inv_temp) {
   __shared__ float newsc[64];
   __shared__ float red_v[256];
   __shared__ int red_i[256];
@@ -828,6 +830,21 @@ __global__ __launch_bounds__(256) void k_assemble_argmax(const float* __restrict
   if (tid == 0) {
     int ci, cj;
     pair_from_index(n, bi, ci, cj);
+    if (uniforms) {
+      // Categorical(logits / temperature).sample() by inverse CDF on a supplied uniform u in [0,1)
+      // (finetune_rl_search.py:147): smallest k with sum_{p<=k} e_p > u * sum_p e_p, fp64, flat order
+      const float* lg = logits_out + (size_t)b * np;
+      double total = 0.0;
+      for (int p = 0; p < np; ++p) total += exp((double)(lg[p] - bv) * (double)inv_temp);
+      const double target = (double)uniforms[(size_t)b * u_bstride] * total;
+      double run = 0.0;
+      int k = np - 1;
+      for (int p = 0; p < np; ++p) {
+        run += exp((double)(lg[p] - bv) * (double)inv_temp);
+        if (run > target) { k = p; break; }
+      }
+      pair_from_index(n, k, ci, cj);
+    }
     if (merges_out) { merges_out[(size_t)b * merges_bstride] = ci; merges_out[(size_t)b * merges_bstride + 1] = cj; }
     if (gap_out) gap_out[(size_t)b * gap_bstride] = np > 1 ? bv - red_v[0] : 0.f;
     if (forced) {
@@ -921,4 +938,16 @@ __global__ void k_compact_rows(const float* __restrict__ state, const float* __r
                              : reinterpret_cast<const f32x4*>(state) + ((size_t)b * n + src) * row_f4;
   f32x4* d = reinterpret_cast<f32x4*>(out) + ((size_t)b * (n - 1) + t) * row_f4;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < row_f4; i += (long)gridDim.x * blockDim.x) d[i] = s[i];
+}
+
+// state of batch element 0 copied to elements 1..B-1 (encode once, replicate: the sampling mode runs
+// B rollouts of ONE alignment; the reference re-encodes it for every rollout)
+__global__ void k_replicate(float* __restrict__ buf, long per_b_f4) {
+  const f32x4* src = reinterpret_cast<const f32x4*>(buf);
+  f32x4* dst = reinterpret_cast<f32x4*>(buf) + (size_t)(blockIdx.y + 1) * per_b_f4;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < per_b_f4; i += (long)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+__global__ void k_replicate_u8(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, int B, int L) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < (long)B * L) dst[i] = src[i % L];
 }

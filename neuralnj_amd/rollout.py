@@ -55,6 +55,28 @@ def argmax_rollout(batch, agent, env, device=None):
     return scores, best, merges
 
 
+def sample_rollouts(batch, agent, env, n_rollouts, seed=0, temperature=1.0, device=None):
+    """Device part of the reference's RL_Search / "NeuralNJ-MC" (finetune_rl_search.py:338-427):
+    `n_rollouts` sampled rollouts of ONE alignment, encoded once.  Returns the distinct sampled trees
+    as Newick strings with their multiplicities.  Ranking them by likelihood (raxml-ng in the
+    reference) is outside this package."""
+    device = device or next(agent.parameters()).device
+    codes = batch["codes"] if "codes" in batch else agent.onehot_to_codes(batch["data"].to(device))
+    mask = batch["seq_weights"].to(device) == 0
+    T = codes.shape[1]
+    u = torch.from_numpy(np.random.default_rng(seed).random((n_rollouts, T - 1)).astype(np.float32))
+    r = agent._context().rollout_sample(codes[:1].to(device), mask[:1], u, temperature=temperature,
+                                        replicas=n_rollouts)
+    merges = r["merges"].cpu().numpy()
+    env.init_states([batch["seqs"][0]] * n_rollouts, [batch["seq_keys"][0]] * n_rollouts, None)
+    env.apply_merges(merges)
+    trees = {}
+    for st in env.states:
+        t = st.subtrees[0]
+        trees.setdefault(t.topo_repr, [t.utree_op_str, 0])[1] += 1
+    return [(nwk, cnt) for nwk, cnt in trees.values()], merges
+
+
 def argmax_inference(cfgs, test_dir, write_dir, device="cuda", fast=True):
     """Counterpart of the reference's Argmax_inference (finetune_rl_search.py:478-509):
     one tree per *.phy file in test_dir, written as <name>.tre."""

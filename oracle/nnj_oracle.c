@@ -718,13 +718,32 @@ int nnjo_select_pair(const float* logits, int32_t* ij_out, float* top2_gap, int3
   return NNJO_OK;
 }
 
-/* reinforce_rollout, eval + argmax branch -- reference finetune_rl_search.py:78-189.
- * forced_merges: NULL or int32 [B,T-1,2] applied instead of the argmax.
- * merges_out int32 [B,T-1,2] (always the argmax of each step's table);
+/* Categorical(logits / temperature).sample() by inverse CDF on a supplied uniform (the reference's
+ * RNG stream, finetune_rl_search.py:147, is not reproducible across devices; the stream is an input):
+ * smallest k with sum_{p<=k} e_p > u * sum_p e_p, e_p = exp((l_p - max) / temperature), fp64, flat order. */
+static size_t sample_index(const float* l, size_t np, float u, float inv_temp) {
+  float mx = l[0];
+  for (size_t p = 1; p < np; ++p) if (l[p] > mx) mx = l[p];
+  double total = 0.0;
+  for (size_t p = 0; p < np; ++p) total += exp((double)(l[p] - mx) * (double)inv_temp);
+  const double target = (double)u * total;
+  double run = 0.0;
+  for (size_t p = 0; p < np; ++p) {
+    run += exp((double)(l[p] - mx) * (double)inv_temp);
+    if (run > target) return p;
+  }
+  return np - 1;
+}
+
+/* reinforce_rollout, eval branch -- reference finetune_rl_search.py:78-189.
+ * Argmax (uniforms == NULL, :145) or sampling (:147) with caller-supplied uniforms [B,T-1].
+ * forced_merges: NULL or int32 [B,T-1,2] applied instead of the chosen pair.
+ * merges_out int32 [B,T-1,2] = the chosen pair of each step (argmax or sample);
  * logits_trace: NULL or float [B, sum_{n=T..2} P(n)]; top2_gap: NULL or [B,T-1];
  * state_out: NULL or [B,T,C,D] encoder output. */
-int nnjo_rollout_argmax(nnjo_handle* h, const float* onehot, const uint8_t* mask,
+static int rollout_impl(nnjo_handle* h, const float* onehot, const uint8_t* mask,
                         int32_t B, int32_t T, int32_t L, const int32_t* forced_merges,
+                        const float* uniforms, float inv_temp,
                         int32_t* merges_out, float* logits_trace, float* top2_gap, float* state_out) {
   if (!h || !onehot || !merges_out || B <= 0 || T < 2) return NNJO_ERR_ARG;
   if (!h->have_w) return NNJO_ERR_NO_WEIGHTS;
@@ -750,6 +769,15 @@ int nnjo_rollout_argmax(nnjo_handle* h, const float* onehot, const uint8_t* mask
     if (rc) break;
     nnjo_select_pair(logits, ij, gap, B, n);                                             /* :145,159-160 */
     for (int b = 0; b < B; ++b) {
+      if (uniforms) {                                                                    /* :147 */
+        size_t k = sample_index(logits + (size_t)b * np, np, uniforms[(size_t)b * (T - 1) + step], inv_temp);
+        size_t t = 0;
+        for (int i = 0; i < n; ++i) {
+          const size_t cnt = (size_t)(n - 1 - i);
+          if (k < t + cnt) { ij[2 * b] = i; ij[2 * b + 1] = i + 1 + (int)(k - t); break; }
+          t += cnt;
+        }
+      }
       merges_out[((size_t)b * (T - 1) + step) * 2] = ij[2 * b];
       merges_out[((size_t)b * (T - 1) + step) * 2 + 1] = ij[2 * b + 1];
       if (top2_gap) top2_gap[(size_t)b * (T - 1) + step] = gap[b];
@@ -767,6 +795,21 @@ int nnjo_rollout_argmax(nnjo_handle* h, const float* onehot, const uint8_t* mask
   }
   free(state); free(state2); free(logits); free(logits_prev); free(ij); free(ij_apply); free(gap);
   return rc;
+}
+
+int nnjo_rollout_argmax(nnjo_handle* h, const float* onehot, const uint8_t* mask,
+                        int32_t B, int32_t T, int32_t L, const int32_t* forced_merges,
+                        int32_t* merges_out, float* logits_trace, float* top2_gap, float* state_out) {
+  return rollout_impl(h, onehot, mask, B, T, L, forced_merges, NULL, 1.0f, merges_out, logits_trace, top2_gap, state_out);
+}
+
+/* eval, argmax=False branch (RL_Search): onehot [B,T,L,V] holds the B alignments (replicas of one
+ * alignment are simply repeated by the caller); uniforms float [B,T-1]. */
+int nnjo_rollout_sample(nnjo_handle* h, const float* onehot, const uint8_t* mask,
+                        int32_t B, int32_t T, int32_t L, const float* uniforms, float temperature,
+                        int32_t* merges_out, float* logits_trace) {
+  if (!uniforms || !(temperature > 0.f)) return NNJO_ERR_ARG;
+  return rollout_impl(h, onehot, mask, B, T, L, NULL, uniforms, 1.0f / temperature, merges_out, logits_trace, NULL, NULL);
 }
 
 int nnjo_set_threads(int32_t n) {

@@ -156,3 +156,16 @@ class Oracle:
         if want_state:
             res["state"] = st
         return res
+
+    def rollout_sample(self, onehot, mask, uniforms, temperature=1.0):
+        onehot = np.ascontiguousarray(onehot, dtype=np.float32)
+        B, T, L, _ = onehot.shape
+        total = sum(n * (n - 1) // 2 for n in range(2, T + 1))
+        merges = np.empty((B, T - 1, 2), np.int32)
+        trace = np.empty((B, total), np.float32)
+        u = np.ascontiguousarray(uniforms, dtype=np.float32)
+        assert u.shape == (B, T - 1)
+        self._chk(self.lib.nnjo_rollout_sample(self.h, _ptr(onehot, C.c_float), _ptr(self._mask(mask), C.c_uint8),
+                                               B, T, L, _ptr(u, C.c_float), C.c_float(float(temperature)),
+                                               _ptr(merges, C.c_int32), _ptr(trace, C.c_float)))
+        return dict(merges=merges, logits=trace)

@@ -227,3 +227,33 @@ def test_model_env_api_follows_reference_call_sequence():
     assert np.array_equal(merges2, z["merges"]) and best2 == best
     with pytest.raises(ValueError):
         agent.encode_zxr(torch.full((1, 3, 8, 4), 2, dtype=torch.int8), torch.zeros(1, 8, dtype=torch.bool))
+
+
+def test_sampling_mode_matches_oracle_and_replicates(ctx_cache):
+    """nnj_rollout_sample (NeuralNJ-MC device part, finetune_rl_search.py:147): same sampled merge lists
+    as the oracle for the same uniforms; encode-once-and-replicate equals B explicit copies bit for bit;
+    a cold temperature reproduces the argmax rollout."""
+    z, cfgs, packed = load_golden("synth_b1_t20_l256_s0")
+    g = ctx_cache(cfgs, packed)
+    o = _oracle(cfgs, packed)
+    codes1, mask1 = z["codes"], z["mask"]
+    B, T, L = 6, codes1.shape[1], codes1.shape[2]
+    u = np.random.default_rng(11).random((B, T - 1)).astype(np.float32)
+    codes = np.repeat(codes1, B, 0)
+    mask = np.repeat(mask1, B, 0)
+    r_rep = g.rollout_sample(torch.from_numpy(codes1), torch.from_numpy(mask1), u, temperature=3.0, replicas=B,
+                             want_trace=True)
+    r_all = g.rollout_sample(torch.from_numpy(codes), torch.from_numpy(mask), u, temperature=3.0, want_trace=True)
+    assert torch.equal(r_rep["merges"], r_all["merges"]) and torch.equal(r_rep["logits"], r_all["logits"])
+    merges = r_all["merges"].cpu().numpy()
+    assert len({tuple(m.reshape(-1)) for m in merges}) > 1            # different uniforms, different trees
+    ref = o.rollout_sample(synth.codes_to_onehot(codes).astype(np.float32), mask, u, temperature=3.0)
+    # identical trajectories wherever the oracle's own sample is not within rounding of a CDF boundary
+    agree = (ref["merges"] == merges).all(axis=(1, 2))
+    assert agree.mean() >= 0.8
+    first = np.argmax(~agree) if not agree.all() else 0
+    assert_logits_close(r_all["logits"].cpu().numpy()[agree], ref["logits"][agree], RTOL, "sampled tables")
+    cold = g.rollout_sample(torch.from_numpy(codes1), torch.from_numpy(mask1), u[:1], temperature=1e-4)
+    assert np.array_equal(cold["merges"].cpu().numpy(), z["merges"])
+    with pytest.raises(RuntimeError):
+        g.rollout_sample(torch.from_numpy(codes1), None, u[:1], temperature=0.0)

@@ -77,3 +77,28 @@ def test_component_entry_points_consistent():
         assert np.array_equal(np.take_along_axis(cat, idx, 1), logits_new)
         assert_logits_close(logits_new, ref_tables[step + 1])
         logits = logits_new
+
+
+def test_oracle_sampling_mode_properties():
+    """Sampling twin (finetune_rl_search.py:147): u -> 0 picks nothing below the first pair with
+    mass, a very low temperature reproduces the argmax rollout, and merges are valid pairs."""
+    z, cfgs, packed = load_golden("synth_b2_t8_l128_s0")
+    o = Oracle(cfgs, packed)
+    oh, mask = onehot_f32(z["codes"]), z["mask"]
+    B, T, L = z["codes"].shape
+    u = np.random.default_rng(3).random((B, T - 1)).astype(np.float32)
+    cold = o.rollout_sample(oh, mask, u, temperature=1e-4)
+    assert np.array_equal(cold["merges"], z["merges"])            # T -> 0: the sample is the argmax
+    hot = o.rollout_sample(oh, mask, u, temperature=50.0)
+    m = hot["merges"]
+    assert (m[:, :, 0] < m[:, :, 1]).all() and (m[:, :, 1] < np.arange(T, 1, -1)[None, :]).all()
+    assert not np.array_equal(m, z["merges"])                      # hot sampling explores
+    again = o.rollout_sample(oh, mask, u, temperature=50.0)
+    assert np.array_equal(again["merges"], m)                      # deterministic in the uniforms
+    # inverse-CDF semantics on the first table, recomputed in numpy fp64
+    t0 = hot["logits"][:, :T * (T - 1) // 2].astype(np.float64)
+    e = np.exp((t0 - t0.max(1, keepdims=True)) / 50.0)
+    cdf = np.cumsum(e, 1)
+    k = np.array([int(np.searchsorted(cdf[b], float(u[b, 0]) * cdf[b, -1], side="right")) for b in range(B)])
+    pairs = [(i, j) for i in range(T) for j in range(i + 1, T)]
+    assert [pairs[x] for x in k] == [tuple(p) for p in m[:, 0]]
