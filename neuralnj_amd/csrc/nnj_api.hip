@@ -266,9 +266,10 @@ int launch_encoder(nnj_handle* h, const uint8_t* codes, const uint8_t* mask, flo
       const size_t lds = (size_t)(16384 + 4 * 4096) * sizeof(float);
       if (int rc = set_lds(h, k_tok1<NT>, lds)) return rc;
       hipLaunchKernelGGL(k_tok1<NT>, dim3(colblocks), dim3(256), lds, st, ctx, mask, x, attn_ptrs(h, h->lo[l].row),
-                         attn_ptrs(h, h->lo[l].col), B, T, C, d.Epad, (l == 0 && h->debug_stop == 1) ? 1 : 0);
+                         attn_ptrs(h, h->lo[l].col), B, T, C, d.Epad,
+                         ((l == 0 && h->debug_stop == 1) ? 1 : 0) | (h->debug_stop >= 16 ? (h->debug_stop >> 4) << 1 : 0));
     }
-    if (l == 0 && (h->debug_stop == 1 || h->debug_stop == 2)) break;
+    if (l == 0 && (h->debug_stop == 1 || h->debug_stop == 2)) break;   // values >= 16 are timing ablations (tools/ablate.py)
     {
       Scope sc(h, st, PK_TOK2);
       const size_t lds = (size_t)16384 * sizeof(float);

@@ -91,6 +91,12 @@ __device__ __forceinline__ void lds_read_b64(f32x2& d, unsigned byte_addr) {
 #endif
 }
 template <int OFF>
+__device__ __forceinline__ void lds_read_b128(f32x4& d, unsigned byte_addr) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(byte_addr), "n"(OFF));
+#endif
+}
+template <int OFF>
 __device__ __forceinline__ void lds_read_b32(float& d, unsigned byte_addr) {
 #if defined(__HIP_DEVICE_COMPILE__)
   asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(d) : "v"(byte_addr), "n"(OFF));

@@ -393,7 +393,7 @@ __global__ __launch_bounds__(256) void k_tok1(const float* __restrict__ ctx, con
   stage_weight<64>(W0, wc.Wo, 64, tid, 256);
   __syncthreads();
   if (!active) return;
-  if (skip_col) {                            // debug tap: state after the row-attention block
+  if (skip_col & 3) {                        // 1: debug tap (state after the row-attention block); 2: timing ablation
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
       const int r = 32 * nt + tok;
