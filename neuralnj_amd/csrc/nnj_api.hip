@@ -46,6 +46,7 @@ struct nnj_handle {
   size_t oA, oa0, ou, olut;      // derived (after the packed block)
   float t0 = 0.f, s2b = 0.f;
   int debug_stop = 0;            // encoder debug tap (nnj_debug_encoder_stop)
+  int num_cu = 256;              // compute units of the device (persistent-kernel grid size)
   char err[512] = "";
   // profiling
   bool prof = false;
@@ -274,12 +275,19 @@ int launch_encoder(nnj_handle* h, const uint8_t* codes, const uint8_t* mask, flo
       Scope sc(h, st, PK_TOK2);
       const size_t lds = (size_t)16384 * sizeof(float);
       const bool more = l + 1 < nl;
-      {   // flat token tiling: 256 consecutive (column,row) tokens of one MSA per workgroup
-        const int wg_per_b = (T * C + 255) / 256;
-        if (int rc = set_lds(h, k_tok2f, lds)) return rc;
-        hipLaunchKernelGGL(k_tok2f, dim3((unsigned)(wg_per_b * B)), dim3(512), lds, st, x, mask, ffn_ptrs(h, h->lo[l]),
-                           more ? attn_ptrs(h, h->lo[l + 1].row) : none, Q, K, V, B, T, C, d.Epad, more ? 1 : 0,
-                           wg_per_b);
+      {   // persistent FFN / QKV kernels over flat 256-token groups, one workgroup per CU
+        const int groups_per_b = (T * C + 255) / 256;
+        const long ngroups = (long)groups_per_b * B;
+        const unsigned grid = (unsigned)std::min<long>(ngroups, h->num_cu);
+        const size_t lds_ffn = (size_t)2 * 16384 * sizeof(float);
+        if (int rc = set_lds(h, k_ffn, lds_ffn)) return rc;
+        hipLaunchKernelGGL(k_ffn, dim3(grid), dim3(512), lds_ffn, st, x, ffn_ptrs(h, h->lo[l]), B, T, C, groups_per_b);
+        if (more) {
+          const size_t lds_qkv = (size_t)3 * 4096 * sizeof(float);
+          const unsigned grid2 = (unsigned)std::min<long>(ngroups, 2L * h->num_cu);
+          hipLaunchKernelGGL(k_qkv, dim3(grid2), dim3(512), lds_qkv, st, (const float*)x, mask,
+                             attn_ptrs(h, h->lo[l + 1].row), Q, K, V, B, T, C, d.Epad, groups_per_b);
+        }
       }
     }
   }
@@ -452,6 +460,7 @@ int nnj_create(const nnj_config* cfg, nnj_handle** out) {
     return fail(nullptr, NNJ_ERR_NO_DEVICE, "device %d is %s; libnnj_hip.so is built for gfx950 only", cfg->device, prop.gcnArchName);
   nnj_handle* h = new nnj_handle();
   h->cfg = *cfg;
+  h->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   *out = h;
   return NNJ_OK;
 }

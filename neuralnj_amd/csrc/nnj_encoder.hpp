@@ -672,3 +672,120 @@ __global__ __launch_bounds__(512) void k_tok2f(float* __restrict__ x, const uint
   linear_T<2, 2, 1>(o, y, Wv_l, wn.bv, lane);
   put(o, V, 1.0f);
 }
+
+// ------------------------------------------------------------------ persistent token kernels
+// One workgroup per CU, weights staged into LDS ONCE, then a loop over 256-token groups (flat
+// (column,row) token order, 8 waves x 32 tokens, two waves per SIMD) with the next group's tokens
+// prefetched behind the MFMAs.  No barrier inside the loop.  (The per-group weight re-staging of a
+// non-persistent kernel moved 2.7x more bytes than the activations themselves.)
+//   k_ffn : LN -> fc1 -> GELU -> fc2 -> +x            LDS 128 KiB: W1 [256][64] | W2 [64][256]
+//   k_qkv : LN -> q,k,v of the row attention            LDS  48 KiB: Wq | Wk | Wv
+__device__ __forceinline__ void flat_token(int t, int R, int C, int& c, int& r, bool& valid) {
+  valid = t < R * C;
+  c = valid ? t / R : 0;
+  r = valid ? t - c * R : 0;
+}
+
+__global__ __launch_bounds__(512) void k_ffn(float* __restrict__ x, FfnW wf, int B, int R, int C, int groups_per_b) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* W1l = smem;              // [256][64]
+  float* W2l = smem + 16384;      // [64][256]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5;
+  stage_weight<64>(W1l, wf.W1, 256, tid, 512);
+  stage_weight<256>(W2l, wf.W2, 64, tid, 512);
+  __syncthreads();
+  const int ngroups = groups_per_b * B;
+  int grp = blockIdx.x;
+  if (grp >= ngroups) return;
+  int c, r; bool valid;
+  auto addr = [&](int g_) {
+    const int b = g_ / groups_per_b;
+    flat_token(((g_ % groups_per_b) * 8 + wave) * 32 + (lane & 31), R, C, c, r, valid);
+    return x + (((size_t)b * R + r) * C + c) * 64;
+  };
+  float* xp = addr(grp);
+  bool cur_valid = valid;
+  f32x16 xr[2];
+  load_token64(xr, xp, cur_valid, hh);
+  while (true) {
+    const int nxt = grp + gridDim.x;
+    f32x16 xn[2];
+    float* xpn = xp; bool nvalid = false;
+    if (nxt < ngroups) { xpn = addr(nxt); nvalid = valid; load_token64(xn, xpn, nvalid, hh); }   // prefetch
+    // compiler memory barrier: keeps the loop-invariant bias / LayerNorm parameter loads INSIDE the loop
+    // (hoisted, they would occupy ~200 VGPRs for the whole kernel and spill)
+    asm volatile("" ::: "memory");
+    f32x16 y[1][2], out[1][2];
+    layer_norm64(y[0], xr, wf.ln_w, wf.ln_b, hh);
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 b4 = *reinterpret_cast<const f32x4*>(wf.b2 + 32 * mt + 8 * g + 4 * hh);
+        out[0][mt][4 * g] = b4[0]; out[0][mt][4 * g + 1] = b4[1]; out[0][mt][4 * g + 2] = b4[2]; out[0][mt][4 * g + 3] = b4[3];
+      }
+#pragma unroll 1
+    for (int half = 0; half < 2; ++half) {
+      asm volatile("" ::: "memory");
+      f32x16 hdn[1][4];
+      linear_T<4, 2, 1>(hdn, y, W1l + half * 128 * 64, wf.b1 + half * 128, lane);
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int k = 0; k < 16; ++k) hdn[0][mt][k] = gelu_erf(hdn[0][mt][k]);
+      linear_T_acc<2, 4, 1, 256>(out, hdn, W2l + half * 128, lane);
+    }
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) xr[mt] += out[0][mt];
+    store_token64(xr, xp, cur_valid, hh);
+    if (nxt >= ngroups) break;
+    grp = nxt; xp = xpn; cur_valid = nvalid;
+    xr[0] = xn[0]; xr[1] = xn[1];
+  }
+}
+
+__global__ __launch_bounds__(512) void k_qkv(const float* __restrict__ x, const uint8_t* __restrict__ mask, AttnW wn,
+                                             float* __restrict__ Q, float* __restrict__ K, float* __restrict__ V,
+                                             int B, int R, int C, int Epad, int groups_per_b) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Wq_l = smem;
+  float* Wk_l = smem + 4096;
+  float* Wv_l = smem + 8192;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5;
+  stage_weight<64>(Wq_l, wn.Wq, 64, tid, 512);
+  stage_weight<64>(Wk_l, wn.Wk, 64, tid, 512);
+  stage_weight<64>(Wv_l, wn.Wv, 64, tid, 512);
+  __syncthreads();
+  const int ngroups = groups_per_b * B;
+  const float qs = rsqrtf((float)NNJ_DH) / sqrtf((float)R);
+  for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+    const int b = grp / groups_per_b;
+    int c, r; bool valid;
+    flat_token(((grp % groups_per_b) * 8 + wave) * 32 + (lane & 31), R, C, c, r, valid);
+    asm volatile("" ::: "memory");      // keep the parameter loads inside the loop (see k_ffn)
+    f32x16 xr[2], y[1][2], o[1][2];
+    load_token64(xr, x + (((size_t)b * R + r) * C + c) * 64, valid, hh);
+    layer_norm64(y[0], xr, wn.ln_w, wn.ln_b, hh);
+    const bool padded = mask && mask[(size_t)b * C + c];
+    const float qscale = padded ? 0.0f : qs;
+    // lane (token, hh) owns d = 4hh..4hh+3 of every head: 16-byte pieces at [b][h][c][r*8 + 4hh]
+    auto put = [&](float* dst, float scale) {
+      if (!valid) return;
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int h = 4 * mt + g;
+          f32x4 v = {o[0][mt][4 * g] * scale, o[0][mt][4 * g + 1] * scale, o[0][mt][4 * g + 2] * scale,
+                     o[0][mt][4 * g + 3] * scale};
+          *reinterpret_cast<f32x4*>(dst + (((size_t)b * NNJ_NHEAD + h) * C + c) * Epad + r * 8 + 4 * hh) = v;
+        }
+    };
+    linear_T<2, 2, 1>(o, y, Wq_l, wn.bq, lane);
+    put(Q, qscale);
+    linear_T<2, 2, 1>(o, y, Wk_l, wn.bk, lane);
+    put(K, 1.0f);
+    linear_T<2, 2, 1>(o, y, Wv_l, wn.bv, lane);
+    put(V, 1.0f);
+  }
+}
