@@ -264,9 +264,10 @@ int launch_encoder(nnj_handle* h, const uint8_t* codes, const uint8_t* mask, flo
     }
     {
       Scope sc(h, st, PK_TOK1);
-      const size_t lds = (size_t)(16384 + 4 * 4096) * sizeof(float);
+      const size_t lds = (size_t)(5 * 4096 + 4 * 2048) * sizeof(float);
       if (int rc = set_lds(h, k_tok1<NT>, lds)) return rc;
-      hipLaunchKernelGGL(k_tok1<NT>, dim3(colblocks), dim3(256), lds, st, ctx, mask, x, attn_ptrs(h, h->lo[l].row),
+      const unsigned grid1 = (unsigned)std::min<long>((long)colblocks, (long)h->num_cu);   // persistent
+      hipLaunchKernelGGL(k_tok1<NT>, dim3(grid1), dim3(256), lds, st, ctx, mask, x, attn_ptrs(h, h->lo[l].row),
                          attn_ptrs(h, h->lo[l].col), B, T, C, d.Epad,
                          ((l == 0 && h->debug_stop == 1) ? 1 : 0) | (h->debug_stop >= 16 ? (h->debug_stop >> 4) << 1 : 0));
     }

@@ -344,26 +344,31 @@ template <int NT>
 __global__ __launch_bounds__(256) void k_tok1(const float* __restrict__ ctx, const uint8_t* __restrict__ mask,
                                               float* __restrict__ x, AttnW wr, AttnW wc, int B, int R, int C,
                                               int Epad, int skip_col) {
+  // persistent: one workgroup per CU, the five 64x64 weight images staged ONCE (80 KiB), then a loop
+  // over groups of 4 columns (one column per wave) with no workgroup barrier inside
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* W0 = smem;               // Wo_row, later Wo_col
+  float* W0 = smem;               // Wo_row
   float* Wq_l = smem + 4096;
   float* Wk_l = smem + 8192;
   float* Wv_l = smem + 12288;
+  float* Wo_l = smem + 16384;     // Wo_col
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  float* kvl = smem + 16384 + wave * 4096;   // [2][64][32]
+  float* kvl = smem + 20480 + wave * 2048;   // V image of one head-half [64][32], wave private
   stage_weight<64>(W0, wr.Wo, 64, tid, 256);
   stage_weight<64>(Wq_l, wc.Wq, 64, tid, 256);
   stage_weight<64>(Wk_l, wc.Wk, 64, tid, 256);
   stage_weight<64>(Wv_l, wc.Wv, 64, tid, 256);
+  stage_weight<64>(Wo_l, wc.Wo, 64, tid, 256);
   __syncthreads();
-  const long col = (long)blockIdx.x * 4 + wave;
-  const bool active = col < (long)B * C;
-  const int b = active ? (int)(col / C) : 0, c = active ? (int)(col % C) : 0;
   const int tok = lane & 31, hh = lane >> 5;
-  const bool padded = active && mask && mask[(size_t)b * C + c];
+  const long ncols = (long)B * C;
+  for (long col = (long)blockIdx.x * 4 + wave; col < ncols; col += (long)gridDim.x * 4) {
+  asm volatile("" ::: "memory");            // keep bias / LayerNorm parameter loads inside the loop (see k_ffn)
+  const int b = (int)(col / C), c = (int)(col % C);
+  const bool padded = mask && mask[(size_t)b * C + c];
 
   f32x16 xr[NT][2];
-  if (active) {
+  {
     // ---- row attention: out_proj(context) + residual
     f32x16 cx[NT][2];
 #pragma unroll
@@ -389,17 +394,13 @@ __global__ __launch_bounds__(256) void k_tok1(const float* __restrict__ ctx, con
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt) xr[nt][mt] += o[nt][mt];
   }
-  __syncthreads();                           // everyone is done with Wo_row
-  stage_weight<64>(W0, wc.Wo, 64, tid, 256);
-  __syncthreads();
-  if (!active) return;
   if (skip_col & 3) {                        // 1: debug tap (state after the row-attention block); 2: timing ablation
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
       const int r = 32 * nt + tok;
       store_token64(xr[nt], x + (((size_t)b * R + r) * C + c) * 64, r < R, hh);
     }
-    return;
+    continue;
   }
 
   // ---- column attention
@@ -494,7 +495,7 @@ __global__ __launch_bounds__(256) void k_tok1(const float* __restrict__ ctx, con
     }
   }
   f32x16 o[NT][2];
-  linear_T<2, 2, NT>(o, cx, W0, wc.bo, lane);
+  linear_T<2, 2, NT>(o, cx, Wo_l, wc.bo, lane);
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
     const int r = 32 * nt + tok;
@@ -502,6 +503,7 @@ __global__ __launch_bounds__(256) void k_tok1(const float* __restrict__ ctx, con
     for (int mt = 0; mt < 2; ++mt) xr[nt][mt] += o[nt][mt];
     store_token64(xr[nt], x + (((size_t)b * R + r) * C + c) * 64, r < R, hh);
   }
+  }   // persistent column loop
 }
 
 // ------------------------------------------------------------------ k_tok2
