@@ -380,8 +380,8 @@ int launch_pair_scores(nnj_handle* h, const RowSet& rs, const int* ij_prev, cons
   {
     Scope sc(h, st, PK_PAIR_SCORE);
     const size_t lds = (2 + 2 * 3) * 4096 * sizeof(float);
-    if (int rc = set_lds(h, k_pair_score<2, 4>, lds)) return rc;
-    hipLaunchKernelGGL((k_pair_score<2, 4>), grid, dim3(256), lds, st, rs, sw, ij_prev, base + w.alpha, mask,
+    if (int rc = set_lds(h, k_pair_score<1, 8>, lds)) return rc;
+    hipLaunchKernelGGL((k_pair_score<1, 8>), grid, dim3(512), lds, st, rs, sw, ij_prev, base + w.alpha, mask,
                        base + w.score_part, mode, n, C, g.npairs, g.ppad, g.cs, has_ctx);
   }
   return NNJ_OK;

@@ -119,6 +119,7 @@ __device__ __forceinline__ void gate_tile(f32x16 (&x)[2], const float* img_s, co
         const float z = sigmoidf_(ui[t] - uj[t] + b4[t]);
         x[mt][4 * g + t] = sj[t] + z * (si[t] - sj[t]);     // z*x_i + (1-z)*x_j
       }
+      if (g & 1) __builtin_amdgcn_sched_barrier(0);         // at most 8 row pieces in flight: bounded live range
     }
 }
 
