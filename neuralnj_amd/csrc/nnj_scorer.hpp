@@ -201,10 +201,12 @@ __global__ __launch_bounds__(256) void k_alpha_softmax(RowSet rs, ScorerW w, con
   int pi, pj;
   const bool valid = pair_of(mode, n, p, npairs, ij_prev, b, pi, pj);
   float a = 0.f;
+#pragma unroll 8          // independent loads in flight; the additions stay in order
   for (int sc = 0; sc < nsc; ++sc) a += alpha_part[(((size_t)b * nsc + sc) * ppad + p) * 64 + lane];
   float beta = 0.f;
   if (lane < n) {
     const float* bp = rs.beta_part + ((size_t)b * (rs.bstride / ((long)C * 64)) + slot_of(rs, b, lane)) * rs.ntile32;
+#pragma unroll 8
     for (int t = 0; t < rs.ntile32; ++t) beta += bp[t];
     beta += (float)C * w.t0;
   }
@@ -684,10 +686,12 @@ __global__ __launch_bounds__(256) void k_agg_finish(RowSet rs, ScorerW w, const 
     const bool in = has_ctx && lane < n && lane != pi && lane != pj;
     if (in) {
       float s = 0.f;
+#pragma unroll 8
       for (int ch = 0; ch < nch; ++ch) s += part[((size_t)b * nch + ch) * 64 + lane];
       const float* bp = rs.beta_part + ((size_t)b * (rs.bstride / ((long)C * 64)) + slot_of(rs, b, lane)) * rs.ntile32;
       float beta = 0.f;
-      for (int t = 0; t < rs.ntile32; ++t) beta += bp[t];
+  #pragma unroll 8
+    for (int t = 0; t < rs.ntile32; ++t) beta += bp[t];
       beta += (float)C * w.t0;
       a = (s + beta) * (1.0f / sqrtf(64.0f * (float)C));
     }
@@ -731,9 +735,9 @@ __global__ __launch_bounds__(256) void k_agg_finish(RowSet rs, ScorerW w, const 
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) xg[0][mt][r] = 0.f;
+#pragma unroll 4                                   // several rows' loads in flight (rows i, j have weight 0)
     for (int r = 0; r < n; ++r) {
       const float a = al[r];
-      if (a == 0.f) continue;                        // rows i, j carry exactly zero weight
       f32x16 sr[2];
       load_token64(sr, rs.S + bo + ((size_t)slot_of(rs, b, r) * C + (valid ? c : 0)) * 64, valid, hh);
 #pragma unroll
@@ -783,6 +787,7 @@ __global__ __launch_bounds__(256) void k_assemble_argmax(const float* __restrict
     ip = ij_prev[2 * b]; jp = ij_prev[2 * b + 1];
     if (tid < n) {
       float s = 0.f;
+#pragma unroll 8
       for (int sc = 0; sc < nsc; ++sc) s += score_part[((size_t)b * nsc + sc) * ppad + tid];
       newsc[tid] = s;
     }
@@ -794,6 +799,7 @@ __global__ __launch_bounds__(256) void k_assemble_argmax(const float* __restrict
     float v;
     if (mode == PAIRS_FULL) {
       v = 0.f;
+#pragma unroll 8
       for (int sc = 0; sc < nsc; ++sc) v += score_part[((size_t)b * nsc + sc) * ppad + p];
     } else {
       int ii, jj;
