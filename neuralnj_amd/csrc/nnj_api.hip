@@ -128,7 +128,7 @@ int set_lds(nnj_handle* h, K kernel, size_t bytes) {
 // ---- shapes the kernels cover
 int check_shape(nnj_handle* h, int B, int T, int L) {
   if (B <= 0 || T < 1 || L <= 0) return fail(h, NNJ_ERR_ARG, "bad shape B=%d T=%d L=%d", B, T, L);
-  if (T > 50) return fail(h, NNJ_ERR_UNSUPPORTED, "T=%d: this build covers up to 50 rows (row-attention head dim 400)", T);
+  if (T > 64) return fail(h, NNJ_ERR_UNSUPPORTED, "T=%d: this build covers up to 64 rows (one column per wave, row-attention head dim 512)", T);
   if (L % 4) return fail(h, NNJ_ERR_UNSUPPORTED, "L=%d must be a multiple of 4", L);
   return NNJ_OK;
 }
@@ -137,8 +137,8 @@ struct EncDims { int Epad, ld, NT, nte; size_t hm; };   // hm = floats of one he
 EncDims enc_dims(int B, int T, int C) {
   EncDims d;
   // head dim of the tied row attention, padded (with zeros) to a compiled tile count
-  static const int buckets[] = {4, 8, 12, 16, 20, 25};
-  d.nte = 25;
+  static const int buckets[] = {4, 8, 12, 16, 20, 25, 32};
+  d.nte = 32;
   for (int k : buckets) if (T * 8 <= 16 * k) { d.nte = k; break; }
   d.Epad = 16 * d.nte;
   d.ld = (d.Epad - 4 + 31) / 32 * 32 + 4;
@@ -257,7 +257,7 @@ int launch_encoder(nnj_handle* h, const uint8_t* codes, const uint8_t* mask, flo
     hipLaunchKernelGGL(k_row_attn<N>, grid, dim3(256), lds, st, Q, K, V, mask, ctx, B, C, fill);        \
   } break;
       switch (d.nte) {
-        NNJ_RA_CASE(4) NNJ_RA_CASE(8) NNJ_RA_CASE(12) NNJ_RA_CASE(16) NNJ_RA_CASE(20) NNJ_RA_CASE(25)
+        NNJ_RA_CASE(4) NNJ_RA_CASE(8) NNJ_RA_CASE(12) NNJ_RA_CASE(16) NNJ_RA_CASE(20) NNJ_RA_CASE(25) NNJ_RA_CASE(32)
         default: return fail(h, NNJ_ERR_UNSUPPORTED, "row attention: no instantiation for %d tiles", d.nte);
       }
 #undef NNJ_RA_CASE

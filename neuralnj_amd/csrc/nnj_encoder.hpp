@@ -9,7 +9,8 @@
 //   k_embed_qkv : embed (6-entry LUT of the site codes) -> x ; LN -> q,k,v (row attn, layer 0)
 //   k_row_attn  : tied row attention, flash style, head dim E = R*8, per (b, h, 64 queries)
 //   k_tok1      : ctx -> out_proj -> +x ; LN -> q,k,v -> column attention -> out_proj -> +x
-//   k_tok2      : LN -> fc1 -> GELU -> fc2 -> +x ; [LN -> q,k,v of the next layer's row attn]
+//   k_ffn/k_qkv : LN -> fc1 -> GELU -> fc2 -> +x ; LN -> q,k,v of the next layer's row attn (persistent,
+//                 flat token tiling)
 //
 // HBM layouts: x [B,R,C,64]; Q/K/V/ctx head-major [B,8,C,Epad] with e = r*8 + d,
 // Epad = roundup(R*8,16) (zero padded) -- a (b,h) slice is a plain [C x Epad] matrix.
@@ -504,175 +505,6 @@ __global__ __launch_bounds__(256) void k_tok1(const float* __restrict__ ctx, con
     store_token64(xr[nt], x + (((size_t)b * R + r) * C + c) * 64, r < R, hh);
   }
   }   // persistent column loop
-}
-
-// ------------------------------------------------------------------ k_tok2
-// FFN block (reference msa_modules.py:147-151 inside 109-125), then optionally the
-// next layer's row-attention LN + q,k,v.
-//   LDS: 64 KiB: [W1 half 128x64 | W2 half 64x128], reused for Wq,Wk,Wv.
-// NW = 4: one wave per column, NT row tiles each.  NW = 8 (NT = 1): two waves per column, one 32-row
-// tile each -- two waves per SIMD, so one wave's LayerNorm/GELU arithmetic overlaps the other's MFMAs.
-template <int NT, int NW>
-__global__ __launch_bounds__(64 * NW) void k_tok2(float* __restrict__ x, const uint8_t* __restrict__ mask,
-                                              FfnW wf, AttnW wn, float* __restrict__ Q, float* __restrict__ K,
-                                              float* __restrict__ V, int B, int R, int C, int Epad,
-                                              int do_qkv) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* W1l = smem;            // [128][64]
-  float* W2l = smem + 8192;     // [64][128]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const long col = (long)blockIdx.x * 4 + (wave & 3);
-  const int r0 = 32 * (wave >> 2);
-  const bool active = col < (long)B * C;
-  const int b = active ? (int)(col / C) : 0, c = active ? (int)(col % C) : 0;
-  const int tok = lane & 31, hh = lane >> 5;
-
-  // FFN per 32-token tile (keeps the live set under 256 VGPRs: x, out, 128 hidden units)
-  f32x16 xr[NT][2], out[NT][1][2], y[NT][1][2];
-  if (active) {
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      const int r = r0 + 32 * nt + tok;
-      load_token64(xr[nt], x + (((size_t)b * R + (r < R ? r : 0)) * C + c) * 64, r < R, hh);
-      layer_norm64(y[nt][0], xr[nt], wf.ln_w, wf.ln_b, hh);
-    }
-    // out starts as the fc2 bias
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const f32x4 b4 = *reinterpret_cast<const f32x4*>(wf.b2 + 32 * mt + 8 * g + 4 * hh);
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-          out[nt][0][mt][4 * g] = b4[0]; out[nt][0][mt][4 * g + 1] = b4[1];
-          out[nt][0][mt][4 * g + 2] = b4[2]; out[nt][0][mt][4 * g + 3] = b4[3];
-        }
-      }
-  }
-#pragma unroll 1
-  for (int half = 0; half < 2; ++half) {
-    __syncthreads();
-    stage_weight<64>(W1l, wf.W1 + (size_t)half * 128 * 64, 128, tid, 64 * NW);
-    stage_weight_sub<256, 128>(W2l, wf.W2, 0, 64, half * 128, tid, 64 * NW);
-    __syncthreads();
-    if (active) {
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-        f32x16 hdn[1][4];
-        linear_T<4, 2, 1>(hdn, y[nt], W1l, wf.b1 + half * 128, lane);
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) hdn[0][mt][r] = gelu_erf(hdn[0][mt][r]);
-        linear_T_acc<2, 4, 1>(out[nt], hdn, W2l, lane);
-        __builtin_amdgcn_sched_barrier(0);     // keep the two token tiles' live ranges apart
-      }
-    }
-  }
-  if (active) {
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      const int r = r0 + 32 * nt + tok;
-#pragma unroll
-      for (int mt = 0; mt < 2; ++mt) xr[nt][mt] += out[nt][0][mt];
-      store_token64(xr[nt], x + (((size_t)b * R + r) * C + c) * 64, r < R, hh);
-    }
-  }
-  if (!do_qkv) return;
-  __syncthreads();
-  float* Wq_l = smem;
-  float* Wk_l = smem + 4096;
-  float* Wv_l = smem + 8192;
-  stage_weight<64>(Wq_l, wn.Wq, 64, tid, 64 * NW);
-  stage_weight<64>(Wk_l, wn.Wk, 64, tid, 64 * NW);
-  stage_weight<64>(Wv_l, wn.Wv, 64, tid, 64 * NW);
-  __syncthreads();
-  if (!active) return;
-  const bool padded = mask && mask[(size_t)b * C + c];
-  row_qkv_stage<NT>(xr, wn, Wq_l, Wk_l, Wv_l, Q, K, V, b, c, C, R, Epad, padded, lane, r0);
-}
-
-// ------------------------------------------------------------------ k_tok2f
-// k_tok2 with FLAT token tiling: the FFN and the q,k,v projections are token-local, so the 32-token
-// tiles run over the flattened (column, row) index t = c*R + r of one batch element instead of
-// whole columns -- no empty token slots when R is not a multiple of 32 (R = 50: 1600 instead of
-// 2048 tiles per MSA).  8 waves = 256 consecutive tokens per workgroup, two waves per SIMD.
-// Head-major rows r in [R, Epad/8) are never touched here: they were zeroed by k_embed_qkv.
-__global__ __launch_bounds__(512) void k_tok2f(float* __restrict__ x, const uint8_t* __restrict__ mask,
-                                               FfnW wf, AttnW wn, float* __restrict__ Q, float* __restrict__ K,
-                                               float* __restrict__ V, int B, int R, int C, int Epad, int do_qkv,
-                                               int wg_per_b) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* W1l = smem;            // [128][64]
-  float* W2l = smem + 8192;     // [64][128]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int b = blockIdx.x / wg_per_b;
-  const int t = ((blockIdx.x % wg_per_b) * 8 + wave) * 32 + (lane & 31);
-  const bool valid = t < R * C;
-  const int c = valid ? t / R : 0, r = valid ? t - c * R : 0;
-  const int hh = lane >> 5;
-  float* xp = x + (((size_t)b * R + r) * C + c) * 64;
-
-  f32x16 xr[2], out[1][2], y[1][2];
-  load_token64(xr, xp, valid, hh);
-  layer_norm64(y[0], xr, wf.ln_w, wf.ln_b, hh);
-#pragma unroll
-  for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const f32x4 b4 = *reinterpret_cast<const f32x4*>(wf.b2 + 32 * mt + 8 * g + 4 * hh);
-      out[0][mt][4 * g] = b4[0]; out[0][mt][4 * g + 1] = b4[1];
-      out[0][mt][4 * g + 2] = b4[2]; out[0][mt][4 * g + 3] = b4[3];
-    }
-#pragma unroll 1
-  for (int half = 0; half < 2; ++half) {
-    __syncthreads();
-    stage_weight<64>(W1l, wf.W1 + (size_t)half * 128 * 64, 128, tid, 512);
-    stage_weight_sub<256, 128>(W2l, wf.W2, 0, 64, half * 128, tid, 512);
-    __syncthreads();
-    f32x16 hdn[1][4];
-    linear_T<4, 2, 1>(hdn, y, W1l, wf.b1 + half * 128, lane);
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-      for (int k = 0; k < 16; ++k) hdn[0][mt][k] = gelu_erf(hdn[0][mt][k]);
-    linear_T_acc<2, 4, 1>(out, hdn, W2l, lane);
-  }
-#pragma unroll
-  for (int mt = 0; mt < 2; ++mt) xr[mt] += out[0][mt];
-  store_token64(xr, xp, valid, hh);
-  if (!do_qkv) return;
-  __syncthreads();
-  float* Wq_l = smem;
-  float* Wk_l = smem + 4096;
-  float* Wv_l = smem + 8192;
-  stage_weight<64>(Wq_l, wn.Wq, 64, tid, 512);
-  stage_weight<64>(Wk_l, wn.Wk, 64, tid, 512);
-  stage_weight<64>(Wv_l, wn.Wv, 64, tid, 512);
-  __syncthreads();
-  const bool padded = mask && mask[(size_t)b * C + c];
-  layer_norm64(y[0], xr, wn.ln_w, wn.ln_b, hh);
-  const float qscale = padded ? 0.0f : (rsqrtf((float)NNJ_DH) / sqrtf((float)R));
-  // lane (token, hh) owns d = 4hh..4hh+3 of every head: 16-byte pieces at [b][h][c][r*8 + 4hh]
-  auto put = [&](const f32x16 (&o)[1][2], float* dst, float scale) {
-    if (!valid) return;
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int h = 4 * mt + g;
-        f32x4 v = {o[0][mt][4 * g] * scale, o[0][mt][4 * g + 1] * scale, o[0][mt][4 * g + 2] * scale,
-                   o[0][mt][4 * g + 3] * scale};
-        *reinterpret_cast<f32x4*>(dst + (((size_t)b * NNJ_NHEAD + h) * C + c) * Epad + r * 8 + 4 * hh) = v;
-      }
-  };
-  f32x16 o[1][2];
-  linear_T<2, 2, 1>(o, y, Wq_l, wn.bq, lane);
-  put(o, Q, qscale);
-  linear_T<2, 2, 1>(o, y, Wk_l, wn.bk, lane);
-  put(o, K, 1.0f);
-  linear_T<2, 2, 1>(o, y, Wv_l, wn.bv, lane);
-  put(o, V, 1.0f);
 }
 
 // ------------------------------------------------------------------ persistent token kernels

@@ -128,7 +128,8 @@ def test_seeded_random_inputs_vs_oracle(ctx_cache):
     packed = weights.pack(cfgs, weights.seeded_state(cfgs, 21, "sharp"))
     g = ctx_cache(cfgs, packed)
     o = _oracle(cfgs, packed)
-    for (B, T, L, seed) in ((3, 5, 36, 1), (1, 2, 64, 2), (2, 33, 100, 3), (1, 17, 260, 4), (1, 50, 128, 5)):
+    for (B, T, L, seed) in ((3, 5, 36, 1), (1, 2, 64, 2), (2, 33, 100, 3), (1, 17, 260, 4), (1, 50, 128, 5),
+                            (1, 64, 64, 6), (2, 57, 96, 7)):      # 64 = the largest row count this build covers
         codes = synth.synth_codes_tree(B, T, L, seed)
         mask = np.zeros((B, L), bool)
         if seed % 2:
@@ -190,8 +191,8 @@ def test_unsupported_shapes_fail_loudly(ctx_cache):
     cfgs = utils.shipped_config()
     packed = weights.pack(cfgs, weights.seeded_state(cfgs, 0, "sharp"))
     g = ctx_cache(cfgs, packed)
-    with pytest.raises(RuntimeError, match="50 rows"):
-        g.rollout_argmax(torch.zeros(1, 51, 64, dtype=torch.uint8))
+    with pytest.raises(RuntimeError, match="64 rows"):
+        g.rollout_argmax(torch.zeros(1, 65, 64, dtype=torch.uint8))
     with pytest.raises(RuntimeError, match="multiple of 4"):
         g.encode(torch.zeros(1, 4, 30, dtype=torch.uint8))
     from neuralnj_amd._lib import Nnj
