@@ -59,7 +59,7 @@ def kernel_models(B, T, L, layers):
     return m
 
 
-def cpu_baseline(cfgs, packed, T, L, budget_s=20.0):
+def cpu_baseline(cfgs, packed, T, L, budget_s=15.0):
     """Times the CPU oracle (oracle/nnj_oracle.c, kind "port") on all host cores."""
     sys.path.insert(0, os.path.join(REPO, "tests"))
     from oracle_lib import Oracle
@@ -77,7 +77,7 @@ def cpu_baseline(cfgs, packed, T, L, budget_s=20.0):
         o.rollout_argmax(oh, mask)
         n += 1
         el = time.time() - t0
-        if el >= budget_s or n >= 6:
+        if el >= budget_s or n >= 64:
             break
     return dict(value=n / el, unit="trees/sec", cores=cores, kind="port",
                 sample=f"{n} single-MSA Argmax rollouts of {T} taxa x {L} sites, fp32 OpenMP oracle, {el:.1f} s")
@@ -100,18 +100,28 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # Rehearsal knobs (one-GPU box): NNJ_BENCH_SHARE_GPU=1 puts every rank on cuda:0 and
+    # NNJ_BENCH_BACKEND=gloo runs the (tiny) collectives on CPU tensors.  The real multi-GPU run uses
+    # one GPU per rank and RCCL ("nccl").
+    share = os.environ.get("NNJ_BENCH_SHARE_GPU") == "1"
+    backend = os.environ.get("NNJ_BENCH_BACKEND", "nccl")
+    dev_index = 0 if share else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    cdev = dev if backend == "nccl" else torch.device("cpu")     # where collective buffers live
     dist = None
     if world > 1:
         import torch.distributed as dist_mod
         dist = dist_mod
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     cfgs = utils.shipped_config()
     packed = weights.pack(cfgs, weights.seeded_state(cfgs, 0, "sharp"))
     # weights: rank 0's copy is broadcast once over RCCL so every rank provably runs the same model
-    wt = torch.from_numpy(packed).to(dev)
+    wt = torch.from_numpy(packed).to(cdev)
     if dist is not None:
         dist.broadcast(wt, src=0)
     g = Nnj(cfgs, dev)
@@ -146,12 +156,13 @@ def main():
     if not args.no_profile:
         g.profile_enable(False)
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
         # merge lists of all shards gathered on every rank (the only result exchange of the path)
-        gathered = [torch.empty_like(merges, device=dev) for _ in range(world)]
-        dist.all_gather(gathered, merges.to(dev))
+        gathered = [torch.empty_like(merges, device=cdev) for _ in range(world)]
+        dist.all_gather(gathered, merges.to(cdev))
+        assert all(tuple(x.shape) == (B, T - 1, 2) for x in gathered)
     trees = world * B * args.steps
     out = {
         "metric": "trees/sec (Argmax) on 50-taxa x 1024-site MSAs",
