@@ -82,7 +82,8 @@ int nnj_load_weights(nnj_handle* h, const float* packed_host, size_t n);
 int nnj_workspace_bytes(const nnj_handle* h, int32_t B, int32_t T, int32_t L, size_t* bytes);
 
 /* PhyloATTN.encode_zxr -- reference model.py:67-88 (+ msa_modules.py:62-151,
- * axial_attention.py:6-255).  Exactly one of codes_dev / onehot_dev is non-NULL. */
+ * axial_attention.py:6-255).  Exactly one of codes_dev / onehot_dev is non-NULL: codes_dev takes the
+ * 6-entry LUT fast path; onehot_dev (float [B,T,L,4], any values) runs the embed MLP on the device. */
 int nnj_encode(nnj_handle* h, const uint8_t* codes_dev, const float* onehot_dev,
                const uint8_t* mask_dev, float* state_out_dev,
                int32_t B, int32_t T, int32_t L,

@@ -164,6 +164,18 @@ class Nnj:
                                       self._stream()))
         return out
 
+    def encode_onehot(self, onehot, mask=None):
+        """General float input [B,T,L,4] (any values, not only the six site vectors)."""
+        onehot = self._f32(onehot)
+        B, T, L, V = onehot.shape
+        assert V == 4
+        mask = self._u8(mask)
+        out = torch.empty((B, T, L, self.D), dtype=torch.float32, device=self.device)
+        ws = self.workspace(B, T, L)
+        self._chk(self.lib.nnj_encode(self.h, None, _p(onehot), _p(mask), _p(out), B, T, L, _p(ws), ws.numel(),
+                                      self._stream()))
+        return out
+
     def pair_scores_full(self, state, mask=None):
         state = self._f32(state)
         B, n, L, _ = state.shape

@@ -222,8 +222,8 @@ size_t ws_floats(int B, int T, int C) {
 
 // ------------------------------------------------------------------ encoder launches
 template <int NT>
-int launch_encoder(nnj_handle* h, const uint8_t* codes, const uint8_t* mask, float* x, float* scratch,
-                   int B, int T, int C, hipStream_t st) {
+int launch_encoder(nnj_handle* h, const uint8_t* codes, const float* onehot, const uint8_t* mask, float* x,
+                   float* scratch, int B, int T, int C, hipStream_t st) {
   const EncDims d = enc_dims(B, T, C);
   float* Q = scratch;
   float* K = Q + align_up(d.hm, 64);
@@ -235,9 +235,11 @@ int launch_encoder(nnj_handle* h, const uint8_t* codes, const uint8_t* mask, flo
   AttnW none{};
   {
     Scope sc(h, st, PK_EMBED_QKV);
-    const size_t lds = 3 * 4096 * sizeof(float);
+    const size_t lds = 4 * 4096 * sizeof(float);
     if (int rc = set_lds(h, k_embed_qkv<NT>, lds)) return rc;
-    hipLaunchKernelGGL(k_embed_qkv<NT>, dim3(colblocks), dim3(256), lds, st, codes, lut, mask, x, Q, K, V,
+    const float* wp = h->d_w;
+    const EmbedW ew{wp + h->oE0, wp + h->oe0, wp + h->oE2, wp + h->oe2};
+    hipLaunchKernelGGL(k_embed_qkv<NT>, dim3(colblocks), dim3(256), lds, st, codes, onehot, ew, lut, mask, x, Q, K, V,
                        nl > 0 ? attn_ptrs(h, h->lo[0].row) : none, B, T, C, d.Epad, nl > 0 ? 1 : 0);
   }
   // reference no-grad chunking: one masked_fill(-10000) per row chunk, summed (axial_attention.py:35-64)
@@ -297,9 +299,9 @@ int launch_encoder(nnj_handle* h, const uint8_t* codes, const uint8_t* mask, flo
 }
 
 int run_encoder(nnj_handle* h, const uint8_t* codes, const uint8_t* mask, float* x, float* scratch, int B, int T,
-                int C, hipStream_t st) {
-  return T <= 32 ? launch_encoder<1>(h, codes, mask, x, scratch, B, T, C, st)
-                 : launch_encoder<2>(h, codes, mask, x, scratch, B, T, C, st);
+                int C, hipStream_t st, const float* onehot = nullptr) {
+  return T <= 32 ? launch_encoder<1>(h, codes, onehot, mask, x, scratch, B, T, C, st)
+                 : launch_encoder<2>(h, codes, onehot, mask, x, scratch, B, T, C, st);
 }
 
 // ------------------------------------------------------------------ NJ-loop launches
@@ -557,13 +559,13 @@ int nnj_workspace_bytes(const nnj_handle* h, int32_t B, int32_t T, int32_t L, si
 int nnj_encode(nnj_handle* h, const uint8_t* codes, const float* onehot, const uint8_t* mask, float* state_out,
                int32_t B, int32_t T, int32_t L, void* ws, size_t ws_bytes, void* stream) {
   if (int rc = ready(h)) return rc;
-  if (onehot) return fail(h, NNJ_ERR_UNSUPPORTED, "nnj_encode: float one-hot input is not covered; pass 1-byte site codes");
-  if (!codes || !state_out) return fail(h, NNJ_ERR_ARG, "nnj_encode: null argument");
+  if ((!codes && !onehot) || (codes && onehot) || !state_out)
+    return fail(h, NNJ_ERR_ARG, "nnj_encode: exactly one of codes / onehot, and an output buffer, are required");
   if (int rc = check_shape(h, B, T, L)) return rc;
   if (int rc = need_ws(h, ws, ws_bytes, B, T, L)) return rc;
   float* base = static_cast<float*>(ws);
   const size_t state = align_up((size_t)B * T * L * 64, 64);
-  return run_encoder(h, codes, mask, state_out, base + state, B, T, L, static_cast<hipStream_t>(stream));
+  return run_encoder(h, codes, mask, state_out, base + state, B, T, L, static_cast<hipStream_t>(stream), onehot);
 }
 
 int nnj_pair_scores_full(nnj_handle* h, const float* state, const uint8_t* mask, float* logits_out, int32_t B,

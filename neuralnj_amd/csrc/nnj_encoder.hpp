@@ -23,6 +23,9 @@ struct AttnW {            // pointers into the packed device weights (row-major 
 struct FfnW {
   const float *W1, *b1, *W2, *b2, *ln_w, *ln_b;
 };
+struct EmbedW {           // embed = Linear(4 -> 64), GELU, Linear(64 -> 64)  (reference model.py:39-43)
+  const float *E0, *e0, *E2, *e2;
+};
 
 // ------------------------------------------------------------------ QKV epilogue
 // Writes one of q/k/v (feature-major registers of the wave's column) to the
@@ -78,6 +81,7 @@ __device__ __forceinline__ void row_qkv_stage(const f32x16 (&x)[NT][2], const At
 // vectors (reference model.py:39-43,76-77 evaluated on phydata.py:38-46's vectors).
 template <int NT>
 __global__ __launch_bounds__(256) void k_embed_qkv(const uint8_t* __restrict__ codes,
+                                                   const float* __restrict__ onehot, EmbedW ew,
                                                    const float* __restrict__ lut,
                                                    const uint8_t* __restrict__ mask, float* __restrict__ x,
                                                    float* __restrict__ Q, float* __restrict__ K,
@@ -87,7 +91,9 @@ __global__ __launch_bounds__(256) void k_embed_qkv(const uint8_t* __restrict__ c
   float* Wq_l = smem;
   float* Wk_l = smem + 4096;
   float* Wv_l = smem + 8192;
+  float* E2_l = smem + 12288;     // only staged for the general float input
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (onehot) stage_weight<64>(E2_l, ew.E2, 64, tid, 256);
   if (do_qkv) {
     stage_weight<64>(Wq_l, w.Wq, 64, tid, 256);
     stage_weight<64>(Wk_l, w.Wk, 64, tid, 256);
@@ -99,14 +105,44 @@ __global__ __launch_bounds__(256) void k_embed_qkv(const uint8_t* __restrict__ c
   const int b = (int)(col / C), c = (int)(col % C);
   const int tok = lane & 31, hh = lane >> 5;
   f32x16 xr[NT][2];
+  if (onehot) {
+    // general float input [B,R,L,4]: the embed MLP itself (first Linear on the VALU, second by MFMA)
+    f32x16 t1[NT][2];
 #pragma unroll
-  for (int nt = 0; nt < NT; ++nt) {
-    const int r = 32 * nt + tok;
-    const bool valid = r < R;
-    int code = codes[((size_t)b * R + (valid ? r : 0)) * C + c];
-    if (!valid || code > 5) code = 5;
-    load_token64(xr[nt], lut + code * 64, valid, hh);
-    store_token64(xr[nt], x + (((size_t)b * R + r) * C + c) * 64, valid, hh);
+    for (int nt = 0; nt < NT; ++nt) {
+      const int r = 32 * nt + tok;
+      const bool valid = r < R;
+      const f32x4 oh = *reinterpret_cast<const f32x4*>(onehot + (((size_t)b * R + (valid ? r : 0)) * C + c) * 4);
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f32x4 b4 = *reinterpret_cast<const f32x4*>(ew.e0 + 32 * mt + 8 * g + 4 * hh);
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const f32x4 wv = *reinterpret_cast<const f32x4*>(ew.E0 + (32 * mt + 8 * g + 4 * hh + t) * 4);
+            const float s = b4[t] + wv[0] * oh[0] + wv[1] * oh[1] + wv[2] * oh[2] + wv[3] * oh[3];
+            t1[nt][mt][4 * g + t] = valid ? gelu_erf(s) : 0.f;
+          }
+        }
+    }
+    linear_T<2, 2, NT>(xr, t1, E2_l, ew.e2, lane);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int r = 32 * nt + tok;
+      if (!(r < R)) { xr[nt][0] = (f32x16)(0.f); xr[nt][1] = (f32x16)(0.f); }
+      store_token64(xr[nt], x + (((size_t)b * R + r) * C + c) * 64, r < R, hh);
+    }
+  } else {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int r = 32 * nt + tok;
+      const bool valid = r < R;
+      int code = codes[((size_t)b * R + (valid ? r : 0)) * C + c];
+      if (!valid || code > 5) code = 5;
+      load_token64(xr[nt], lut + code * 64, valid, hh);
+      store_token64(xr[nt], x + (((size_t)b * R + r) * C + c) * 64, valid, hh);
+    }
   }
   if (do_qkv) {
     const bool padded = mask && mask[(size_t)b * C + c];

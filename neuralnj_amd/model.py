@@ -115,7 +115,11 @@ class PhyloATTN(nn.Module):
             raise ValueError("encode_zxr expects [B, rows, cols, vocab] one-hot input")
         num_cols = batch_input.shape[2]
         self.patch_num = math.ceil(num_cols / self.patch_size)
-        codes = self.onehot_to_codes(batch_input.to(ctx.device))
+        x = batch_input.to(ctx.device)
+        try:
+            codes = self.onehot_to_codes(x)          # the six site vectors: 1 byte per site, LUT embed
+        except ValueError:
+            return ctx.encode_onehot(x.float(), batch_seq_mask)   # arbitrary float input: embed MLP on the device
         return ctx.encode(codes, batch_seq_mask)
 
     def decode_zxr(self, batch_input, batch_seq_mask=None, indices_to_prev_info=None):

@@ -226,8 +226,16 @@ def test_model_env_api_follows_reference_call_sequence():
     env2 = PhyInferEnv(cfgs, "cuda:0")
     _, best2, merges2 = argmax_rollout(batch, agent, env2)
     assert np.array_equal(merges2, z["merges"]) and best2 == best
-    with pytest.raises(ValueError):
-        agent.encode_zxr(torch.full((1, 3, 8, 4), 2, dtype=torch.int8), torch.zeros(1, 8, dtype=torch.bool))
+    # arbitrary (non one-hot) float input goes through the on-device embed MLP, like the reference's .float()
+    soft = torch.rand(2, 8, 128, 4)
+    got = agent.encode_zxr(soft, torch.zeros(2, 128, dtype=torch.bool)).cpu().numpy()
+    from oracle_lib import Oracle
+    ref = Oracle(cfgs, packed).encode(soft.numpy(), np.zeros((2, 128), bool))
+    np.testing.assert_allclose(got, ref, atol=RTOL * np.abs(ref).max())
+    onehot = torch.from_numpy(synth.codes_to_onehot(z["codes"]).astype(np.float32))
+    a = agent._context().encode_onehot(onehot, None)
+    b = agent._context().encode(torch.from_numpy(z["codes"]), None)
+    np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), atol=2e-5)   # LUT path == MLP path
 
 
 def test_sampling_mode_matches_oracle_and_replicates(ctx_cache):
