@@ -266,12 +266,19 @@ int launch_encoder(nnj_handle* h, const uint8_t* codes, const float* onehot, con
     }
     {
       Scope sc(h, st, PK_TOK1);
-      const size_t lds = (size_t)(5 * 4096 + 4 * 2048) * sizeof(float);
-      if (int rc = set_lds(h, k_tok1<NT>, lds)) return rc;
+      const int dbg = ((l == 0 && h->debug_stop == 1) ? 1 : 0) | (h->debug_stop >= 16 ? (h->debug_stop >> 4) << 1 : 0);
       const unsigned grid1 = (unsigned)std::min<long>((long)colblocks, (long)h->num_cu);   // persistent
-      hipLaunchKernelGGL(k_tok1<NT>, dim3(grid1), dim3(256), lds, st, ctx, mask, x, attn_ptrs(h, h->lo[l].row),
-                         attn_ptrs(h, h->lo[l].col), B, T, C, d.Epad,
-                         ((l == 0 && h->debug_stop == 1) ? 1 : 0) | (h->debug_stop >= 16 ? (h->debug_stop >> 4) << 1 : 0));
+      if (NT == 2) {      // 32 < R <= 64: two waves per column
+        const size_t lds = (size_t)(5 * 4096 + 4 * (64 * 36 + 64 * 32) + 16) * sizeof(float);
+        if (int rc = set_lds(h, k_tok1p, lds)) return rc;
+        hipLaunchKernelGGL(k_tok1p, dim3(grid1), dim3(512), lds, st, ctx, mask, x, attn_ptrs(h, h->lo[l].row),
+                           attn_ptrs(h, h->lo[l].col), B, T, C, d.Epad, dbg);
+      } else {
+        const size_t lds = (size_t)(5 * 4096 + 4 * 2048) * sizeof(float);
+        if (int rc = set_lds(h, k_tok1<1>, lds)) return rc;
+        hipLaunchKernelGGL(k_tok1<1>, dim3(grid1), dim3(256), lds, st, ctx, mask, x, attn_ptrs(h, h->lo[l].row),
+                           attn_ptrs(h, h->lo[l].col), B, T, C, d.Epad, dbg);
+      }
     }
     if (l == 0 && (h->debug_stop == 1 || h->debug_stop == 2)) break;   // values >= 16 are timing ablations (tools/ablate.py)
     {

@@ -543,6 +543,156 @@ __global__ __launch_bounds__(256) void k_tok1(const float* __restrict__ ctx, con
   }   // persistent column loop
 }
 
+// ------------------------------------------------------------------ k_tok1p
+// k_tok1 for 32 < R <= 64 with TWO waves per column (one 32-row tile each), 8 waves per workgroup:
+// two waves per SIMD, so the VALU stream (softmax, P.V) issues at the full rate and one wave's VALU
+// overlaps the other's MFMAs.  The K and V projections of a head-half are exchanged through a
+// per-column LDS image; the two waves of a column meet at a pair barrier built on an LDS counter
+// (never a workgroup barrier: the four column pairs run unsynchronised).  Persistent: the five
+// weight images are staged once (80 KiB) + 4 x (K image [64][36] + V image [64][32]) = 149 KiB.
+__device__ __forceinline__ void pair_barrier(int* cnt, int& epoch) {
+  // both waves of the pair arrive (LDS executes a wave's operations in order: its image writes are
+  // in place before its increment), then wait until the counter shows both arrivals of this epoch
+  epoch += 2;
+  asm volatile("" ::: "memory");
+  if ((threadIdx.x & 63) == 0) atomicAdd(cnt, 1);
+  // bounded spin: a lost partner ends in wrong numbers (caught by the parity tests), never in a hung GPU
+  for (int spins = 0; *reinterpret_cast<volatile int*>(cnt) < epoch && spins < (1 << 22); ++spins) __builtin_amdgcn_s_sleep(1);
+  asm volatile("" ::: "memory");
+}
+
+__global__ __launch_bounds__(512) void k_tok1p(const float* __restrict__ ctx, const uint8_t* __restrict__ mask,
+                                               float* __restrict__ x, AttnW wr, AttnW wc, int B, int R, int C,
+                                               int Epad, int skip_col) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* W0 = smem;               // Wo_row
+  float* Wq_l = smem + 4096;
+  float* Wk_l = smem + 8192;
+  float* Wv_l = smem + 12288;
+  float* Wo_l = smem + 16384;     // Wo_col
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int slot = wave & 3, rt = wave >> 2;            // column slot of the workgroup, row tile of the column
+  float* kimg = smem + 20480 + slot * (64 * 36 + 64 * 32);   // K image [64][36]
+  float* vimg = kimg + 64 * 36;                              // V image [64][32]
+  int* cnt = reinterpret_cast<int*>(smem + 20480 + 4 * (64 * 36 + 64 * 32)) + slot;
+  stage_weight<64>(W0, wr.Wo, 64, tid, 512);
+  stage_weight<64>(Wq_l, wc.Wq, 64, tid, 512);
+  stage_weight<64>(Wk_l, wc.Wk, 64, tid, 512);
+  stage_weight<64>(Wv_l, wc.Wv, 64, tid, 512);
+  stage_weight<64>(Wo_l, wc.Wo, 64, tid, 512);
+  if (tid < 4) reinterpret_cast<int*>(smem + 20480 + 4 * (64 * 36 + 64 * 32))[tid] = 0;
+  __syncthreads();
+  int epoch = 0;
+  const int tok = lane & 31, hh = lane >> 5;
+  const int r = 32 * rt + tok;                          // this lane's row of the column
+  const bool valid = r < R;
+  const long ncols = (long)B * C;
+  const float scaling = rsqrtf((float)NNJ_DH);         // axial_attention.py:214
+  for (long col = (long)blockIdx.x * 4 + slot; col < ncols; col += (long)gridDim.x * 4) {
+    asm volatile("" ::: "memory");                      // keep parameter loads inside the loop (see k_ffn)
+    const int b = (int)(col / C), c = (int)(col % C);
+    const bool padded = mask && mask[(size_t)b * C + c];
+    float* xp = x + (((size_t)b * R + (valid ? r : 0)) * C + c) * 64;
+    f32x16 xr[1][2];
+    {
+      // ---- row attention: out_proj(context) + residual
+      f32x16 cx[1][2], o[1][2];
+      load_token64(xr[0], xp, valid, hh);
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int h = 4 * mt + g;
+          const f32x4 v = *reinterpret_cast<const f32x4*>(ctx + (((size_t)b * NNJ_NHEAD + h) * C + c) * Epad +
+                                                          (valid ? r : 0) * 8 + 4 * hh);
+          cx[0][mt][4 * g + 0] = valid ? v[0] : 0.f; cx[0][mt][4 * g + 1] = valid ? v[1] : 0.f;
+          cx[0][mt][4 * g + 2] = valid ? v[2] : 0.f; cx[0][mt][4 * g + 3] = valid ? v[3] : 0.f;
+        }
+      linear_T<2, 2, 1>(o, cx, W0, wr.bo, lane);
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) xr[0][mt] += o[0][mt];
+    }
+    if (skip_col & 3) { store_token64(xr[0], xp, valid, hh); continue; }
+
+    // ---- column attention over the 2 x 32 rows of the column
+    f32x16 cx[1][2];
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {                    // heads 4*hf .. 4*hf+3
+      f32x16 qh[1][1], kh[1][1], vh[1][1];
+      {
+        f32x16 y[1][2];
+        layer_norm64(y[0], xr[0], wc.ln_w, wc.ln_b, hh);
+        linear_T<1, 2, 1>(qh, y, Wq_l + hf * 32 * 64, wc.bq + 32 * hf, lane);
+        linear_T<1, 2, 1>(kh, y, Wk_l + hf * 32 * 64, wc.bk + 32 * hf, lane);
+        linear_T<1, 2, 1>(vh, y, Wv_l + hf * 32 * 64, wc.bv + 32 * hf, lane);
+      }
+      pair_barrier(cnt, epoch);                         // the partner has finished reading the previous images
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 k4 = {kh[0][0][4 * g], kh[0][0][4 * g + 1], kh[0][0][4 * g + 2], kh[0][0][4 * g + 3]};
+        const f32x4 v4 = {vh[0][0][4 * g], vh[0][0][4 * g + 1], vh[0][0][4 * g + 2], vh[0][0][4 * g + 3]};
+        *reinterpret_cast<f32x4*>(kimg + r * 36 + 8 * g + 4 * hh) = k4;
+        *reinterpret_cast<f32x4*>(vimg + r * 32 + 8 * g + 4 * hh) = v4;
+      }
+      pair_barrier(cnt, epoch);                         // both row tiles' K and V are in the images
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        // S^T[key j x query i]: A = K image rows (lane = key), B = this wave's q registers (lane = query)
+        f32x16 sc_[2];
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt) {
+          const f32x4 ka = *reinterpret_cast<const f32x4*>(kimg + (32 * jt + tok) * 36 + 8 * g + 4 * hh);
+#pragma unroll
+          for (int k = 0; k < 16; ++k) sc_[jt][k] = 0.f;
+#pragma unroll
+          for (int t = 0; t < 4; ++t) sc_[jt] = mfma32(ka[t], qh[0][0][4 * g + t] * scaling, sc_[jt]);
+        }
+        // element k of tile jt is key j = 32*jt + (k&3) + 8*(k>>2) + 4*hh
+        float m = -INFINITY;
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+          for (int k = 0; k < 16; ++k) {
+            const int j = 32 * jt + (k & 3) + 8 * (k >> 2) + 4 * hh;
+            float v = sc_[jt][k];
+            if (padded) v = -10000.0f;                  // every key of a padded column (axial_attention.py:220-224)
+            if (j >= R) v = -INFINITY;
+            sc_[jt][k] = v;
+            m = fmaxf(m, v);
+          }
+        m = fmaxf(m, __shfl_xor(m, 32));
+        float l = 0.f, o8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+          for (int k = 0; k < 16; ++k) {
+            const float p = nnj_exp(sc_[jt][k] - m);
+            l += p;
+            const float* vp = vimg + (32 * jt + (k & 3) + 8 * (k >> 2) + 4 * hh) * 32 + 8 * g;
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(vp);
+            const f32x4 v1 = *reinterpret_cast<const f32x4*>(vp + 4);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) { o8[t] += p * v0[t]; o8[4 + t] += p * v1[t]; }
+          }
+        l += __shfl_xor(l, 32);
+        const float inv = nnj_rcp(l);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {                   // this lane keeps d = 4hh+t of the head
+          const float send = hh ? o8[t] : o8[4 + t];
+          const float recv = __shfl_xor(send, 32);
+          cx[0][hf][4 * g + t] = ((hh ? o8[4 + t] : o8[t]) + recv) * inv;
+        }
+      }
+    }
+    f32x16 o[1][2];
+    linear_T<2, 2, 1>(o, cx, Wo_l, wc.bo, lane);
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) xr[0][mt] += o[0][mt];
+    store_token64(xr[0], xp, valid, hh);
+  }
+}
+
 // ------------------------------------------------------------------ persistent token kernels
 // One workgroup per CU, weights staged into LDS ONCE, then a loop over 256-token groups (flat
 // (column,row) token order, 8 waves x 32 tokens, two waves per SIMD) with the next group's tokens
