@@ -353,19 +353,19 @@ int launch_pair_scores(nnj_handle* h, const RowSet& rs, const int* ij_prev, cons
     {
       Scope sc(h, st, PK_PAIR_SCORE_INCR);
       if (big) {
-        const size_t lds = (size_t)(8192 + 4 * 64 * 68) * sizeof(float);
-        if (int rc = set_lds(h, k_inc_score<2, true, 4>, lds)) return rc;
-        hipLaunchKernelGGL((k_inc_score<2, true, 4>), grid, dim3(256), lds, st, rs, sw, ij_prev, base + w.alpha, mask,
+        const size_t lds = (size_t)(2 * b6_floats(64, 64) + 4 * b6_floats(64, 64) + 16) * sizeof(float);
+        if (int rc = set_lds(h, k_inc_score<2, true>, lds)) return rc;
+        hipLaunchKernelGGL((k_inc_score<2, true>), grid, dim3(512), lds, st, rs, sw, ij_prev, base + w.alpha, mask,
                            base + w.score_part, n, C, g.cs);
       } else if (has_ctx) {
-        const size_t lds = (size_t)(8192 + 8 * 64 * 36) * sizeof(float);
-        if (int rc = set_lds(h, k_inc_score<1, true, 8>, lds)) return rc;
-        hipLaunchKernelGGL((k_inc_score<1, true, 8>), grid, dim3(512), lds, st, rs, sw, ij_prev, base + w.alpha, mask,
+        const size_t lds = (size_t)(2 * b6_floats(64, 64) + 8 * b6_floats(64, 32) + 16) * sizeof(float);
+        if (int rc = set_lds(h, k_inc_score<1, true>, lds)) return rc;
+        hipLaunchKernelGGL((k_inc_score<1, true>), grid, dim3(512), lds, st, rs, sw, ij_prev, base + w.alpha, mask,
                            base + w.score_part, n, C, g.cs);
       } else {
-        const size_t lds = (size_t)(8192 + 8 * 64 * 36) * sizeof(float);
-        if (int rc = set_lds(h, k_inc_score<1, false, 8>, lds)) return rc;
-        hipLaunchKernelGGL((k_inc_score<1, false, 8>), grid, dim3(512), lds, st, rs, sw, ij_prev, base + w.alpha, mask,
+        const size_t lds = (size_t)(2 * b6_floats(64, 64) + 8 * b6_floats(64, 32) + 16) * sizeof(float);
+        if (int rc = set_lds(h, k_inc_score<1, false>, lds)) return rc;
+        hipLaunchKernelGGL((k_inc_score<1, false>), grid, dim3(512), lds, st, rs, sw, ij_prev, base + w.alpha, mask,
                            base + w.score_part, n, C, g.cs);
       }
     }
@@ -388,7 +388,7 @@ int launch_pair_scores(nnj_handle* h, const RowSet& rs, const int* ij_prev, cons
   }
   {
     Scope sc(h, st, PK_PAIR_SCORE);
-    const size_t lds = (2 + 2 * 3) * 4096 * sizeof(float);
+    const size_t lds = (size_t)(2 * b6_floats(64, 64) + 2 * 14336) * sizeof(float);
     if (int rc = set_lds(h, k_pair_score<1, 8>, lds)) return rc;
     hipLaunchKernelGGL((k_pair_score<1, 8>), grid, dim3(512), lds, st, rs, sw, ij_prev, base + w.alpha, mask,
                        base + w.score_part, mode, n, C, g.npairs, g.ppad, g.cs, has_ctx);

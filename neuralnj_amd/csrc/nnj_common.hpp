@@ -208,6 +208,181 @@ __device__ __forceinline__ void linear_T_acc(f32x16 (&out)[NT][MT], const f32x16
   linear_core<MT, KT, NT, LDW, SWZ, true, false>(out, in, W, nullptr, lane);
 }
 
+// ---- fp32 linear layers on the bf16 matrix pipe ("bf16x6").
+// v_mfma_f32_32x32x16_bf16 moves 16x the k of v_mfma_f32_32x32x2_f32 per cycle.  Every fp32 operand is
+// split EXACTLY into three bf16 pieces, x = h + m + l (8 + 8 + 8 significand bits, round-to-nearest at
+// each cut, the residuals are exact fp32 subtractions), and a product is accumulated in fp32 from the six
+// piece products of weight >= 2^-16:  hh + hm + mh + hl + lh + mm.  The dropped ones (ml, lm, ll) are
+// below 2^-24 of the product, i.e. below the rounding of an fp32 multiply, so the result is an fp32
+// GEMM to fp32 accuracy at 6/16 of the fp32-MFMA cycles.  The C/D layout of the 32x32x16 instruction
+// is the feature-major tile above, and its B operand of k-step G of a 32-feature tile is registers
+// 8G..8G+7 of that tile: the layer chaining of linear_core carries over unchanged.
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+struct Frag3 { u32x4 h, m, l; };                           // 8 bf16 per piece
+
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+// RNE, lo -> bits 15:0.  A plain cast (hipcc emits v_cvt_pk_bf16_f32): the compiler sees the instruction and
+// inserts the VALU -> MFMA hazard waits itself, which it cannot do for inline asm.
+__device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
+  const bf16x2 v = {(__bf16)lo, (__bf16)hi};
+  return __builtin_bit_cast(unsigned, v);
+}
+// two fp32 -> three packed bf16 pairs
+__device__ __forceinline__ void split2(float a, float b, unsigned& h, unsigned& m, unsigned& l) {
+  h = cvt_pk_bf16(a, b);
+  const float ra = a - __uint_as_float(h << 16), rb = b - __uint_as_float(h & 0xffff0000u);
+  m = cvt_pk_bf16(ra, rb);
+  const float la = ra - __uint_as_float(m << 16), lb = rb - __uint_as_float(m & 0xffff0000u);
+  l = cvt_pk_bf16(la, lb);
+}
+// registers base..base+7 of a feature-major tile -> the fragment of one k-step
+template <int BASE>
+__device__ __forceinline__ void split8(Frag3& o, const f32x16& x) {
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    unsigned h, m, l;
+    split2(x[BASE + 2 * p], x[BASE + 2 * p + 1], h, m, l);
+    o.h[p] = h; o.m[p] = m; o.l[p] = l;
+  }
+}
+__device__ __forceinline__ f32x16 mfma_bf16(u32x4 a, u32x4 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c,
+                                                 0, 0, 0);
+}
+// c += A*B from the six leading piece products, smallest first
+__device__ __forceinline__ f32x16 mfma_b6(const Frag3& a, const Frag3& b, f32x16 c) {
+  c = mfma_bf16(a.l, b.h, c);
+  c = mfma_bf16(a.h, b.l, c);
+  c = mfma_bf16(a.m, b.m, c);
+  c = mfma_bf16(a.m, b.h, c);
+  c = mfma_bf16(a.h, b.m, c);
+  c = mfma_bf16(a.h, b.h, c);
+  return c;
+}
+
+// LDS weight image for the bf16x6 layers: three planes (h, m, l) of [rows][IN] bf16.  Within a row the
+// in-features are permuted so that the eight a lane needs for one k-step are one 16-byte chunk:
+// chunk q = 4*kt + 2*G + hh holds features 32kt + 16G + 8j + 4hh + t (j = 0,1; t = 0..3) in order
+// (j, t); chunks are XOR-swizzled by row & 7 (ds_read_b128 of 32 rows x 2 chunks: conflict free).
+// Plane stride = rows*IN*2 bytes.  One matrix takes rows*IN*6 bytes = 1.5x its fp32 image.
+// (rows of fewer than 8 chunks -- 32 in-features -- swizzle by the row PAIR: two rows share 128 bytes.)
+template <int CH>
+__device__ __forceinline__ int wswz6(int row, int chunk) {
+  return CH >= 8 ? chunk ^ (row & 7) : chunk ^ ((row >> 1) & 3);
+}
+template <int IN>
+__device__ __forceinline__ void stage_weight_b6(float* lds, const float* __restrict__ g, int rows, int tid,
+                                                int nthreads) {
+  constexpr int CH = IN / 8;
+  u32x4* img = reinterpret_cast<u32x4*>(lds);
+  const int plane = rows * CH;                               // in 16-byte units
+  for (int i = tid; i < rows * CH; i += nthreads) {
+    const int r = i / CH, q = i % CH;
+    const int f0 = 32 * (q >> 2) + 16 * ((q >> 1) & 1) + 4 * (q & 1);
+    const f32x4 v0 = *reinterpret_cast<const f32x4*>(g + (size_t)r * IN + f0);
+    const f32x4 v1 = *reinterpret_cast<const f32x4*>(g + (size_t)r * IN + f0 + 8);
+    Frag3 f;
+    unsigned h, m, l;
+    split2(v0[0], v0[1], h, m, l); f.h[0] = h; f.m[0] = m; f.l[0] = l;
+    split2(v0[2], v0[3], h, m, l); f.h[1] = h; f.m[1] = m; f.l[1] = l;
+    split2(v1[0], v1[1], h, m, l); f.h[2] = h; f.m[2] = m; f.l[2] = l;
+    split2(v1[2], v1[3], h, m, l); f.h[3] = h; f.m[3] = m; f.l[3] = l;
+    const int o = r * CH + wswz6<CH>(r, q);
+    img[o] = f.h; img[plane + o] = f.m; img[2 * plane + o] = f.l;
+  }
+}
+// floats of LDS one staged matrix occupies
+__host__ __device__ constexpr int b6_floats(int rows, int in) { return rows * in * 3 / 2; }
+
+// out[nt][mt] = bias + W*in (or += W*in), W = a stage_weight_b6 image of [32*MT][32*KT].
+template <int MT, int KT, int NT, bool ACC, bool BIAS, bool LEAN = false>
+__device__ __forceinline__ void linear_core_b6(f32x16 (&out)[NT][MT], const f32x16 (&in)[NT][KT],
+                                               const float* W, const float* bias, int lane) {
+  const int row = lane & 31, hh = lane >> 5;
+  if constexpr (!ACC) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (BIAS) b4 = *reinterpret_cast<const f32x4*>(bias + 32 * mt + 8 * g + 4 * hh);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          out[nt][mt][4 * g + 0] = b4[0]; out[nt][mt][4 * g + 1] = b4[1];
+          out[nt][mt][4 * g + 2] = b4[2]; out[nt][mt][4 * g + 3] = b4[3];
+        }
+      }
+  }
+  constexpr int CH = 4 * KT;                                 // 16-byte chunks per image row
+  constexpr int PLANE = 32 * MT * CH;
+  const u32x4* img = reinterpret_cast<const u32x4*>(W);
+  constexpr int NSTEP = 2 * KT * MT;                         // step s: ks = s / MT (k-step), mt = s % MT
+  auto frag = [&](int s, Frag3& a) {
+    const int ks = s / MT, mt = s % MT;
+    const int wrow = 32 * mt + row;
+    const int o = wrow * CH + wswz6<CH>(wrow, 2 * ks + hh);
+    a.h = img[o]; a.m = img[PLANE + o]; a.l = img[2 * PLANE + o];
+  };
+  if constexpr (LEAN) {
+    // register-lean form for kernels at two waves per SIMD (the partner wave fills the gaps): one A and
+    // one B fragment live at a time, 24 registers instead of 48
+    static_for<0, 2 * KT>([&](auto ki) {
+      constexpr int ks = decltype(ki)::value;
+      Frag3 b[NT];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) split8<8 * (ks & 1)>(b[nt], in[nt][ks >> 1]);
+      static_for<0, MT>([&](auto mi) {
+        constexpr int mt = decltype(mi)::value;
+        Frag3 a;
+        frag(ks * MT + mt, a);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) out[nt][mt] = mfma_b6(a, b[nt], out[nt][mt]);
+      });
+      __builtin_amdgcn_sched_barrier(0);
+    });
+  } else {
+  // Software pipeline, one scheduling region per k-step: the MFMAs of k-step ks run beside the split of
+  // the B fragment of ks+1 (VALU) and the A reads of the next step (LDS); the region boundary keeps the
+  // splits of later steps from being hoisted (their live ranges would not fit the register file).
+  Frag3 a[2];
+  Frag3 b[2][NT];
+  frag(0, a[0]);
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) split8<0>(b[0][nt], in[nt][0]);
+  static_for<0, 2 * KT>([&](auto ki) {
+    constexpr int ks = decltype(ki)::value;
+    static_for<0, MT>([&](auto mi) {
+      constexpr int mt = decltype(mi)::value;
+      constexpr int s = ks * MT + mt;
+      if constexpr (s + 1 < NSTEP) frag(s + 1, a[(s + 1) & 1]);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) out[nt][mt] = mfma_b6(a[s & 1], b[ks & 1][nt], out[nt][mt]);
+    });
+    if constexpr (ks + 1 < 2 * KT) {
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) split8<8 * ((ks + 1) & 1)>(b[(ks + 1) & 1][nt], in[nt][(ks + 1) >> 1]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  });
+  }
+}
+template <int MT, int KT, int NT, bool LEAN = false>
+__device__ __forceinline__ void linear6_T(f32x16 (&out)[NT][MT], const f32x16 (&in)[NT][KT], const float* W,
+                                          const float* bias, int lane) {
+  linear_core_b6<MT, KT, NT, false, true, LEAN>(out, in, W, bias, lane);
+}
+template <int MT, int KT, int NT, bool LEAN = false>
+__device__ __forceinline__ void linear6_T_nb(f32x16 (&out)[NT][MT], const f32x16 (&in)[NT][KT], const float* W,
+                                             int lane) {
+  linear_core_b6<MT, KT, NT, false, false, LEAN>(out, in, W, nullptr, lane);
+}
+template <int MT, int KT, int NT, bool LEAN = false>
+__device__ __forceinline__ void linear6_T_acc(f32x16 (&out)[NT][MT], const f32x16 (&in)[NT][KT], const float* W,
+                                              int lane) {
+  linear_core_b6<MT, KT, NT, true, false, LEAN>(out, in, W, nullptr, lane);
+}
+
 // ---- token I/O: 64 features of one token <-> two accumulators (zeros when !valid).
 // The loads are UNCONDITIONAL (a branch per load would put every load in its own basic block and
 // serialise the memory latency): `p` must be a readable address even when !valid -- callers clamp

@@ -92,10 +92,19 @@ __device__ __forceinline__ void site_store(const SiteRegs<NTHR>& R, float* img_a
     *reinterpret_cast<f32x4*>(img_u + r * 64 + sw) = R.u[k];
     if (WITH_A) *reinterpret_cast<f32x4*>(img_a + r * 64 + sw) = R.a[k];
     if (WITH_T) {
+      // S^T as a bf16x6 A image: [3 planes][64 d][64 r'] bf16, row d = the r' order of stage_weight_b6
+      unsigned short* t16 = reinterpret_cast<unsigned short*>(img_t);
+      const int q = 4 * (r >> 5) + 2 * ((r >> 4) & 1) + ((r >> 2) & 1), e = 4 * ((r >> 3) & 1) + (r & 3);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int d = 4 * ch + e;
-        img_t[d * 64 + 4 * wswz(d, r >> 2) + (r & 3)] = R.s[k][e];
+      for (int pr = 0; pr < 2; ++pr) {
+        unsigned h, m, l;
+        split2(R.s[k][2 * pr], R.s[k][2 * pr + 1], h, m, l);
+        const int d0 = 4 * ch + 2 * pr, d1 = d0 + 1;
+        const int o0 = d0 * 64 + 8 * wswz6<8>(d0, q) + e, o1 = d1 * 64 + 8 * wswz6<8>(d1, q) + e;
+        t16[o0] = (unsigned short)h; t16[o1] = (unsigned short)(h >> 16);
+        t16[4096 + o0] = (unsigned short)m; t16[4096 + o1] = (unsigned short)(m >> 16);
+        t16[8192 + o0] = (unsigned short)l; t16[8192 + o1] = (unsigned short)(l >> 16);
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
   }
@@ -233,15 +242,15 @@ __global__ __launch_bounds__(64 * NW) void k_pair_score(RowSet rs, ScorerW w, co
                                                     const uint8_t* __restrict__ mask,
                                                     float* __restrict__ score_part, int mode, int n, int C,
                                                     int npairs, int ppad, int cs, int has_ctx) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];   // Wg | S0 | 2 x [img_t | img_s | img_u]
+  extern __shared__ __attribute__((aligned(16))) float smem[];   // Wg | S0 (bf16x6 images) | 2 x [img_t | img_s | img_u]
   float* Wg_l = smem;
-  float* S0_l = smem + 4096;
-  float* ring = smem + 8192;
+  float* S0_l = smem + b6_floats(64, 64);
+  float* ring = smem + 2 * b6_floats(64, 64);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5;
   const int sc = blockIdx.x, pg = blockIdx.y, b = blockIdx.z;
   const int c0 = sc * cs, c1 = min(C, c0 + cs);
-  stage_weight<64>(Wg_l, w.Wg, 64, tid, 64 * NW);
-  stage_weight<64>(S0_l, w.S0, 64, tid, 64 * NW);
+  stage_weight_b6<64>(Wg_l, w.Wg, 64, tid, 64 * NW);
+  stage_weight_b6<64>(S0_l, w.S0, 64, tid, 64 * NW);
   int pi[TPW], pj[TPW];
   bool any = false;
   f32x16 al[TPW][1][2];
@@ -259,15 +268,15 @@ __global__ __launch_bounds__(64 * NW) void k_pair_score(RowSet rs, ScorerW w, co
   SiteRegs<64 * NW> R;
   if (c0 < c1) {
     site_load<false, 64 * NW>(R, rs, b, n, C, c0, nullptr, tid);
-    site_store<false, true, 64 * NW>(R, nullptr, ring + 4096, ring + 8192, ring, tid);
+    site_store<false, true, 64 * NW>(R, nullptr, ring + 6144, ring + 10240, ring, tid);
   }
   __syncthreads();
   for (int c = c0; c < c1; ++c) {
-    float* cur = ring + ((c - c0) & 1) * 12288;
-    float* nxt = ring + (((c - c0) & 1) ^ 1) * 12288;
-    const float* img_t = cur;
-    const float* img_s = cur + 4096;
-    const float* img_u = cur + 8192;
+    float* cur = ring + ((c - c0) & 1) * 14336;
+    float* nxt = ring + (((c - c0) & 1) ^ 1) * 14336;
+    const float* img_t = cur;                          // bf16x6 image: 6144 floats
+    const float* img_s = cur + 6144;
+    const float* img_u = cur + 10240;
     const bool more = c + 1 < c1;
     if (more) site_load<false, 64 * NW>(R, rs, b, n, C, c + 1, nullptr, tid);   // in flight behind the MFMAs
     const float mc = (mask && mask[(size_t)b * C + c]) ? 0.f : 1.f;   // seq_mask (model.py:96)
@@ -278,8 +287,8 @@ __global__ __launch_bounds__(64 * NW) void k_pair_score(RowSet rs, ScorerW w, co
         gate_tile(x[0], img_s, img_u, w.bh, pi[tt], pj[tt], hh);
         if (has_ctx) {
           f32x16 xg[1][2], g[1][2];
-          linear_T_nb<2, 2, 1>(xg, al[tt], img_t, lane);
-          linear_T<2, 2, 1>(g, xg, Wg_l, w.bg, lane);
+          linear6_T_nb<2, 2, 1, true>(xg, al[tt], img_t, lane);
+          linear6_T<2, 2, 1, true>(g, xg, Wg_l, w.bg, lane);
 #pragma unroll
           for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -289,7 +298,7 @@ __global__ __launch_bounds__(64 * NW) void k_pair_score(RowSet rs, ScorerW w, co
             }
         }
         f32x16 s1[1][2];
-        linear_T<2, 2, 1>(s1, x, S0_l, w.s0, lane);
+        linear6_T<2, 2, 1, true>(s1, x, S0_l, w.s0, lane);
         float s = 0.f;
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
@@ -303,7 +312,7 @@ __global__ __launch_bounds__(64 * NW) void k_pair_score(RowSet rs, ScorerW w, co
         score[tt] += (s + w.s2b) * mc;
       }
     }
-    if (more) site_store<false, true, 64 * NW>(R, nullptr, nxt + 4096, nxt + 8192, nxt, tid);
+    if (more) site_store<false, true, 64 * NW>(R, nullptr, nxt + 6144, nxt + 10240, nxt, tid);
     __syncthreads();
   }
   if (hh == 0) {
@@ -327,13 +336,14 @@ struct IncLane {
   bool valid[2], r_first[2];     // r_first: r < m, i.e. the pair is (r, m) not (m, r)
 };
 template <int NT>
-__device__ __forceinline__ IncLane inc_lane(const RowSet& rs, const int* ij_prev, int b, int n, int lane) {
+__device__ __forceinline__ IncLane inc_lane(const RowSet& rs, const int* ij_prev, int b, int n, int lane,
+                                            int r0 = 0) {
   IncLane L;
   L.m = min(max(ij_prev[2 * b], 0), n - 1);
   L.slot_m = slot_of(rs, b, L.m);
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
-    const int r = 32 * nt + (lane & 31);
+    const int r = r0 + 32 * nt + (lane & 31);
     L.r[nt] = r;
     L.valid[nt] = r < n && r != L.m;
     L.slot_r[nt] = slot_of(rs, b, r < n ? r : 0);
@@ -457,107 +467,125 @@ __global__ __launch_bounds__(64 * NW) void k_inc_alpha(RowSet rs, ScorerW w, con
   }
 }
 
-// Phase B: scores of the new pairs.  The transposed site image S_c^T (A operand of
-// x_g^T = S_c^T alpha^T) is written by the wave itself from the rows its lanes hold.
-// part[b][sc*4+wave][pair r].
-template <int NT, bool CTX, int NW>
-__global__ __launch_bounds__(64 * NW) void k_inc_score(RowSet rs, ScorerW w, const int* __restrict__ ij_prev,
+// Phase B: scores of the new pairs.  Eight waves, one 32-pair tile each (two waves per SIMD: the partner
+// wave's MFMAs run beside this wave's VALU work).  The transposed site image S_c^T -- A operand of
+// x_g^T = S_c^T alpha^T, a bf16x6 image [64 d][32*KT r'] -- is written from the rows the lanes hold.
+// KT = 1 (n <= 32): every wave owns whole sites (c = c0 + wave, +8, ...), image private to the wave.
+// KT = 2 (n > 32): waves w and w+4 share site slot w&3 and build the 64-column image together, each the
+// columns of its 32 rows, between two pair barriers on an LDS counter (see k_tok1p).
+// part[b][sc*NSLOT+slot][pair r].
+__device__ __forceinline__ void pair_barrier_lds(int* cnt, int& epoch) {
+  epoch += 2;
+  asm volatile("" ::: "memory");
+  if ((threadIdx.x & 63) == 0) atomicAdd(cnt, 1);
+  for (int spins = 0; *reinterpret_cast<volatile int*>(cnt) < epoch && spins < (1 << 22); ++spins)
+    __builtin_amdgcn_s_sleep(1);
+  asm volatile("" ::: "memory");
+}
+template <int KT, bool CTX>
+__global__ __launch_bounds__(512) void k_inc_score(RowSet rs, ScorerW w, const int* __restrict__ ij_prev,
                                                    const float* __restrict__ alpha,
                                                    const uint8_t* __restrict__ mask,
                                                    float* __restrict__ score_part, int n, int C, int cs) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* Wg_l = smem;
-  float* S0_l = smem + 4096;
+  float* Wg_l = smem;                                      // bf16x6 images
+  float* S0_l = smem + b6_floats(64, 64);
   const int tid = threadIdx.x, lane = tid & 63, hh = lane >> 5, tok = lane & 31;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  constexpr int TLD = 32 * NT + 4;                          // row stride of the transposed image (conflict free)
-  float* img_t = smem + 8192 + wave * (64 * TLD);         // [64 d][TLD], no swizzle
+  constexpr int NSLOT = 8 / KT;                            // sites in flight per workgroup
+  const int slot = wave % NSLOT, tl = wave / NSLOT;        // tl: which 32 rows of the image this wave holds
+  constexpr int TCH = 4 * KT;                              // 16-byte chunks per image row
+  constexpr int IMG = b6_floats(64, 32 * KT);
+  float* img_t = smem + 2 * b6_floats(64, 64) + slot * IMG;
+  int* cnt = reinterpret_cast<int*>(smem + 2 * b6_floats(64, 64) + NSLOT * IMG) + slot;
   const int sc = blockIdx.x, b = blockIdx.y;
   const int c0 = sc * cs, c1 = min(C, c0 + cs);
-  stage_weight<64>(Wg_l, w.Wg, 64, tid, 64 * NW);
-  stage_weight<64>(S0_l, w.S0, 64, tid, 64 * NW);
+  stage_weight_b6<64>(Wg_l, w.Wg, 64, tid, 512);
+  stage_weight_b6<64>(S0_l, w.S0, 64, tid, 512);
+  if (tid < NSLOT) reinterpret_cast<int*>(smem + 2 * b6_floats(64, 64) + NSLOT * IMG)[tid] = 0;
   __syncthreads();
-  constexpr bool has_ctx = CTX;                            // CTX = (n > 2), model.py:111
-  const IncLane L = inc_lane<NT>(rs, ij_prev, b, n, lane);
+  int epoch = 0;
+  const IncLane L = inc_lane<1>(rs, ij_prev, b, n, lane, 32 * tl);
+  const int r = L.r[0];
   const size_t bo = (size_t)b * rs.bstride;
-  // alpha[pair][r'] (only r' < 32*NT can be non-zero) is re-read per site from L1/L2: keeping it
-  // in registers next to the prefetched rows would spill
-  float score[NT];
-#pragma unroll
-  for (int nt = 0; nt < NT; ++nt) score[nt] = 0.f;
-  IncRaw<NT> raw;
-  int c = c0 + wave;
-  if (c < c1) inc_load<NT>(raw, rs, L, bo, n, C, c, hh);
-  for (; c < c1; c += NW) {
-    f32x16 x[NT][2];
+  // position of column r in an image row (the r' order of stage_weight_b6)
+  const int q = 4 * tl + 2 * ((tok >> 4) & 1) + ((tok >> 2) & 1), e = 4 * ((tok >> 3) & 1) + (tok & 3);
+  float score = 0.f;
+  IncRaw<1> raw;
+  int c = c0 + slot;
+  if (c < c1) inc_load<1>(raw, rs, L, bo, n, C, c, hh);
+  for (; c < c1; c += NSLOT) {
+    asm volatile("" ::: "memory");
+    f32x16 x[1][2];
     {
       IncShared sh;
       inc_load_shared(sh, rs, L, bo, C, c, hh);
-      inc_gate<NT>(x, raw, sh, L, w.bh, hh);
+      inc_gate<1>(x, raw, sh, L, w.bh, hh);
     }
-    if constexpr (has_ctx) {
-      // S_c^T image: this lane's rows, feature f -> img_t[f][r]
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-        const int r = 32 * nt + tok;
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-          for (int g = 0; g < 4; ++g)
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-              img_t[(4 * hh) * TLD + r + (32 * mt + 8 * g + t) * TLD] = raw.sr[nt][mt][4 * g + t];
-            }
-      }
-    }
-    const float mc = (mask && mask[(size_t)b * C + c]) ? 0.f : 1.f;     // seq_mask (model.py:96)
-    const int cn = c + NW;
-    inc_load<NT>(raw, rs, L, bo, n, C, cn < c1 ? cn : c, hh);          // prefetch behind the MFMAs (last: harmless reload)
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {                                    // one 32-pair tile at a time
-      f32x16 xt[1][2] = {{x[nt][0], x[nt][1]}};
-      if constexpr (has_ctx) {
-        f32x16 xg[1][2], g[1][2], at[1][NT];
-        {
-          const float* ap = alpha + ((size_t)b * 64 + L.r[nt]) * 64;
-#pragma unroll
-          for (int kt = 0; kt < NT; ++kt)
-#pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-              const f32x4 v = *reinterpret_cast<const f32x4*>(ap + 32 * kt + 8 * g4 + 4 * hh);
-              at[0][kt][4 * g4] = v[0]; at[0][kt][4 * g4 + 1] = v[1]; at[0][kt][4 * g4 + 2] = v[2]; at[0][kt][4 * g4 + 3] = v[3];
-            }
-        }
-        linear_T_nb<2, NT, 1, TLD, false>(xg, at, img_t, lane);
-        linear_T<2, 2, 1>(g, xg, Wg_l, w.bg, lane);
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const float wg = sigmoidf_(g[0][mt][r]);
-            xt[0][mt][r] += wg * (xg[0][mt][r] - xt[0][mt][r]);   // (1-w)*x + w*x_g
-          }
-      }
-      f32x16 s1[1][2];
-      linear_T<2, 2, 1>(s1, xt, S0_l, w.s0, lane);
-      float s = 0.f;
+    if constexpr (CTX) {
+      if constexpr (KT == 2) pair_barrier_lds(cnt, epoch);   // the partner is done with the previous site's image
+      unsigned short* t16 = reinterpret_cast<unsigned short*>(img_t);
+      constexpr int PL = 64 * 32 * KT;                       // plane stride in bf16 elements
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const f32x4 w4 = *reinterpret_cast<const f32x4*>(w.s2w + 32 * mt + 8 * g + 4 * hh);
+        for (int g = 0; g < 4; ++g)
 #pragma unroll
-          for (int t = 0; t < 4; ++t) s += gelu_erf(s1[0][mt][4 * g + t]) * w4[t];
-        }
-      s += __shfl_xor(s, 32);
-      score[nt] += (s + w.s2b) * mc;
-      __builtin_amdgcn_sched_barrier(0);
+          for (int pr = 0; pr < 2; ++pr) {
+            unsigned h, m, l;
+            split2(raw.sr[0][mt][4 * g + 2 * pr], raw.sr[0][mt][4 * g + 2 * pr + 1], h, m, l);
+            const int d0 = 32 * mt + 8 * g + 4 * hh + 2 * pr, d1 = d0 + 1;
+            const int o0 = d0 * (32 * KT) + 8 * wswz6<TCH>(d0, q) + e, o1 = d1 * (32 * KT) + 8 * wswz6<TCH>(d1, q) + e;
+            t16[o0] = (unsigned short)h; t16[o1] = (unsigned short)(h >> 16);
+            t16[PL + o0] = (unsigned short)m; t16[PL + o1] = (unsigned short)(m >> 16);
+            t16[2 * PL + o0] = (unsigned short)l; t16[2 * PL + o1] = (unsigned short)(l >> 16);
+          }
+      if constexpr (KT == 2) pair_barrier_lds(cnt, epoch);   // all 64 columns are in the image
     }
+    const float mc = (mask && mask[(size_t)b * C + c]) ? 0.f : 1.f;     // seq_mask (model.py:96)
+    const int cn = c + NSLOT;
+    inc_load<1>(raw, rs, L, bo, n, C, cn < c1 ? cn : c, hh);           // prefetch behind the MFMAs (last: harmless reload)
+    if constexpr (CTX) {
+      // alpha[pair][r'] (only r' < 32*KT can be non-zero), re-read per site from L1/L2: keeping it in
+      // registers next to the prefetched rows would spill
+      f32x16 xg[1][2], g[1][2], at[1][KT];
+      {
+        const float* ap = alpha + ((size_t)b * 64 + r) * 64;
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+          for (int g4 = 0; g4 < 4; ++g4) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(ap + 32 * kt + 8 * g4 + 4 * hh);
+            at[0][kt][4 * g4] = v[0]; at[0][kt][4 * g4 + 1] = v[1]; at[0][kt][4 * g4 + 2] = v[2]; at[0][kt][4 * g4 + 3] = v[3];
+          }
+      }
+      linear6_T_nb<2, KT, 1, true>(xg, at, img_t, lane);
+      linear6_T<2, 2, 1, true>(g, xg, Wg_l, w.bg, lane);
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+          const float wg = sigmoidf_(g[0][mt][k]);
+          x[0][mt][k] += wg * (xg[0][mt][k] - x[0][mt][k]);   // (1-w)*x + w*x_g
+        }
+    }
+    f32x16 s1[1][2];
+    linear6_T<2, 2, 1, true>(s1, x, S0_l, w.s0, lane);
+    float s = 0.f;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 w4 = *reinterpret_cast<const f32x4*>(w.s2w + 32 * mt + 8 * g + 4 * hh);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) s += gelu_erf(s1[0][mt][4 * g + t]) * w4[t];
+      }
+    s += __shfl_xor(s, 32);
+    score += (s + w.s2b) * mc;
   }
   if (hh == 0) {
-    const int part = sc * NW + wave, nparts = gridDim.x * NW;
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) score_part[((size_t)b * nparts + part) * 64 + L.r[nt]] = score[nt];
+    const int part = sc * NSLOT + slot, nparts = gridDim.x * NSLOT;
+    score_part[((size_t)b * nparts + part) * 64 + r] = score;
   }
 }
 
