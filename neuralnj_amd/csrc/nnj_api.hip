@@ -289,11 +289,13 @@ int launch_encoder(nnj_handle* h, const uint8_t* codes, const float* onehot, con
         const int groups_per_b = (T * C + 255) / 256;
         const long ngroups = (long)groups_per_b * B;
         const unsigned grid = (unsigned)std::min<long>(ngroups, h->num_cu);
-        const size_t lds_ffn = (size_t)2 * 16384 * sizeof(float);
+        const size_t lds_ffn = (size_t)(b6_floats(128, 64) + b6_floats(64, 128)) * sizeof(float);
         if (int rc = set_lds(h, k_ffn, lds_ffn)) return rc;
-        hipLaunchKernelGGL(k_ffn, dim3(grid), dim3(512), lds_ffn, st, x, ffn_ptrs(h, h->lo[l]), B, T, C, groups_per_b);
+        // ctx (consumed by k_tok1 above, B*8*C*Epad >= B*T*C*64 floats) is the scratch of the two-pass FFN
+        hipLaunchKernelGGL(k_ffn, dim3(grid), dim3(512), lds_ffn, st, x, ctx, ffn_ptrs(h, h->lo[l]), B, T, C, groups_per_b);
         if (more) {
-          const size_t lds_qkv = (size_t)3 * 4096 * sizeof(float);
+          const size_t lds_qkv = (size_t)b6_floats(192, 64) * sizeof(float);
+          if (int rc = set_lds(h, k_qkv, lds_qkv)) return rc;
           const unsigned grid2 = (unsigned)std::min<long>(ngroups, 2L * h->num_cu);
           hipLaunchKernelGGL(k_qkv, dim3(grid2), dim3(512), lds_qkv, st, (const float*)x, mask,
                              attn_ptrs(h, h->lo[l + 1].row), Q, K, V, B, T, C, d.Epad, groups_per_b);

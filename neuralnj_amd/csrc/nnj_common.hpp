@@ -228,11 +228,20 @@ __device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
   const bf16x2 v = {(__bf16)lo, (__bf16)hi};
   return __builtin_bit_cast(unsigned, v);
 }
+// hides a value's provenance from the optimiser (no instruction): without it the compiler re-converts each
+// half separately instead of unpacking the pair it already has
+__device__ __forceinline__ void opaque(unsigned& x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm("" : "+v"(x));
+#endif
+}
 // two fp32 -> three packed bf16 pairs
 __device__ __forceinline__ void split2(float a, float b, unsigned& h, unsigned& m, unsigned& l) {
   h = cvt_pk_bf16(a, b);
+  opaque(h);
   const float ra = a - __uint_as_float(h << 16), rb = b - __uint_as_float(h & 0xffff0000u);
   m = cvt_pk_bf16(ra, rb);
+  opaque(m);
   const float la = ra - __uint_as_float(m << 16), lb = rb - __uint_as_float(m & 0xffff0000u);
   l = cvt_pk_bf16(la, lb);
 }
@@ -266,29 +275,34 @@ __device__ __forceinline__ f32x16 mfma_b6(const Frag3& a, const Frag3& b, f32x16
 // chunk q = 4*kt + 2*G + hh holds features 32kt + 16G + 8j + 4hh + t (j = 0,1; t = 0..3) in order
 // (j, t); chunks are XOR-swizzled by row & 7 (ds_read_b128 of 32 rows x 2 chunks: conflict free).
 // Plane stride = rows*IN*2 bytes.  One matrix takes rows*IN*6 bytes = 1.5x its fp32 image.
-// (rows of fewer than 8 chunks -- 32 in-features -- swizzle by the row PAIR: two rows share 128 bytes.)
+// A ds_read_b128 is served in four groups of 16 lanes ({0-3,12-15,20-27}, {4-11,16-19,28-31}, +32) over 64
+// banks = sixteen 16-byte slots per 256 bytes; a group reads 16 rows at one logical chunk.  The XOR below
+// sends those 16 rows to 16 different slots for every row length (rows of 64, 128 and >= 256 bytes).
 template <int CH>
 __device__ __forceinline__ int wswz6(int row, int chunk) {
-  return CH >= 8 ? chunk ^ (row & 7) : chunk ^ ((row >> 1) & 3);
+  return CH >= 16 ? chunk ^ (row & 15) : (CH == 8 ? chunk ^ ((row >> 1) & 7) : chunk ^ ((row >> 2) & 3));
 }
-template <int IN>
+// `g` is a [*, GLD] fp32 matrix; rows [0, rows) x columns [c0, c0+IN) of it go to image rows
+// [row0, row0+rows) of an image of `img_rows` rows (several matrices can share one image).
+template <int IN, int GLD = IN>
 __device__ __forceinline__ void stage_weight_b6(float* lds, const float* __restrict__ g, int rows, int tid,
-                                                int nthreads) {
+                                                int nthreads, int row0 = 0, int img_rows = 0, int c0 = 0) {
   constexpr int CH = IN / 8;
   u32x4* img = reinterpret_cast<u32x4*>(lds);
-  const int plane = rows * CH;                               // in 16-byte units
+  const int plane = (img_rows ? img_rows : rows) * CH;       // in 16-byte units
   for (int i = tid; i < rows * CH; i += nthreads) {
     const int r = i / CH, q = i % CH;
     const int f0 = 32 * (q >> 2) + 16 * ((q >> 1) & 1) + 4 * (q & 1);
-    const f32x4 v0 = *reinterpret_cast<const f32x4*>(g + (size_t)r * IN + f0);
-    const f32x4 v1 = *reinterpret_cast<const f32x4*>(g + (size_t)r * IN + f0 + 8);
+    const f32x4 v0 = *reinterpret_cast<const f32x4*>(g + (size_t)r * GLD + c0 + f0);
+    const f32x4 v1 = *reinterpret_cast<const f32x4*>(g + (size_t)r * GLD + c0 + f0 + 8);
     Frag3 f;
     unsigned h, m, l;
     split2(v0[0], v0[1], h, m, l); f.h[0] = h; f.m[0] = m; f.l[0] = l;
     split2(v0[2], v0[3], h, m, l); f.h[1] = h; f.m[1] = m; f.l[1] = l;
     split2(v1[0], v1[1], h, m, l); f.h[2] = h; f.m[2] = m; f.l[2] = l;
     split2(v1[2], v1[3], h, m, l); f.h[3] = h; f.m[3] = m; f.l[3] = l;
-    const int o = r * CH + wswz6<CH>(r, q);
+    const int ir = row0 + r;
+    const int o = ir * CH + wswz6<CH>(ir, q);
     img[o] = f.h; img[plane + o] = f.m; img[2 * plane + o] = f.l;
   }
 }

@@ -706,75 +706,92 @@ __device__ __forceinline__ void flat_token(int t, int R, int C, int& c, int& r, 
   r = valid ? t - c * R : 0;
 }
 
-__global__ __launch_bounds__(512) void k_ffn(float* __restrict__ x, FfnW wf, int B, int R, int C, int groups_per_b) {
+__global__ __launch_bounds__(512) void k_ffn(float* __restrict__ x, float* __restrict__ tmp, FfnW wf, int B, int R,
+                                             int C, int groups_per_b) {
+  // bf16x6 images of the two weight matrices take 192 KiB, more than the LDS: the hidden layer is done in
+  // two halves, each one pass of this workgroup over ITS token groups with the half's weights resident
+  // (W1 rows [128p,128p+128) | W2 columns [128p,128p+128): 96 KiB).  Pass 0 leaves b2 + W2a gelu(..) in
+  // `tmp` (same token layout as x; every lane re-reads only what it wrote itself), pass 1 adds the other
+  // half and the residual.  The additions happen in the same order as in a single pass.
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* W1l = smem;              // [256][64]
-  float* W2l = smem + 16384;      // [64][256]
+  float* W1l = smem;                         // two [64][64] images (hidden units 64q..64q+63 of the half)
+  float* W2l = smem + 2 * b6_floats(64, 64); // two [64][64] images
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5;
-  stage_weight<64>(W1l, wf.W1, 256, tid, 512);
-  stage_weight<256>(W2l, wf.W2, 64, tid, 512);
-  __syncthreads();
   const int ngroups = groups_per_b * B;
-  int grp = blockIdx.x;
-  if (grp >= ngroups) return;
+  if ((int)blockIdx.x >= ngroups) return;
   int c, r; bool valid;
   auto addr = [&](int g_) {
     const int b = g_ / groups_per_b;
     flat_token(((g_ % groups_per_b) * 8 + wave) * 32 + (lane & 31), R, C, c, r, valid);
-    return x + (((size_t)b * R + r) * C + c) * 64;
+    return (((size_t)b * R + r) * C + c) * 64;
   };
-  float* xp = addr(grp);
-  bool cur_valid = valid;
-  f32x16 xr[2];
-  load_token64(xr, xp, cur_valid, hh);
-  while (true) {
-    const int nxt = grp + gridDim.x;
-    f32x16 xn[2];
-    float* xpn = xp; bool nvalid = false;
-    if (nxt < ngroups) { xpn = addr(nxt); nvalid = valid; load_token64(xn, xpn, nvalid, hh); }   // prefetch
-    // compiler memory barrier: keeps the loop-invariant bias / LayerNorm parameter loads INSIDE the loop
-    // (hoisted, they would occupy ~200 VGPRs for the whole kernel and spill)
-    asm volatile("" ::: "memory");
-    f32x16 y[1][2], out[1][2];
-    layer_norm64(y[0], xr, wf.ln_w, wf.ln_b, hh);
+  static_for<0, 2>([&](auto pi) {
+    constexpr int pass = decltype(pi)::value;
+    if (pass) __syncthreads();               // everyone is done with the first half's images
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const f32x4 b4 = *reinterpret_cast<const f32x4*>(wf.b2 + 32 * mt + 8 * g + 4 * hh);
-        out[0][mt][4 * g] = b4[0]; out[0][mt][4 * g + 1] = b4[1]; out[0][mt][4 * g + 2] = b4[2]; out[0][mt][4 * g + 3] = b4[3];
-      }
-#pragma unroll 1
-    for (int half = 0; half < 2; ++half) {
-      asm volatile("" ::: "memory");
-      f32x16 hdn[1][4];
-      linear_T<4, 2, 1>(hdn, y, W1l + half * 128 * 64, wf.b1 + half * 128, lane);
-#pragma unroll
-      for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-        for (int k = 0; k < 16; ++k) hdn[0][mt][k] = gelu_erf(hdn[0][mt][k]);
-      linear_T_acc<2, 4, 1, 256>(out, hdn, W2l + half * 128, lane);
+    for (int q = 0; q < 2; ++q) {              // four [64][64] images: W1 rows / W2 columns 128*pass + 64*q ..
+      stage_weight_b6<64>(W1l + q * b6_floats(64, 64), wf.W1 + (size_t)(pass * 128 + q * 64) * 64, 64, tid, 512);
+      stage_weight_b6<64, 256>(W2l + q * b6_floats(64, 64), wf.W2, 64, tid, 512, 0, 0, 128 * pass + 64 * q);
     }
+    __syncthreads();
+    // No register prefetch of the next group: with the bf16x6 fragments next to the hidden tile it would
+    // spill, and a spilled prefetch is waited for at once.  Two waves per SIMD: one computes while the
+    // other waits for its tokens.
+    for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+      const size_t xo = addr(grp);
+      const bool cur_valid = valid;
+      // compiler memory barrier: keeps the loop-invariant bias / LayerNorm parameter loads INSIDE the loop
+      // (hoisted, they would occupy ~200 VGPRs for the whole kernel and spill)
+      asm volatile("" ::: "memory");
+      f32x16 y[1][2], out[1][2];
+      {
+        f32x16 xr[2];
+        load_token64(xr, x + xo, cur_valid, hh);
+        layer_norm64(y[0], xr, wf.ln_w, wf.ln_b, hh);
+      }
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) xr[mt] += out[0][mt];
-    store_token64(xr, xp, cur_valid, hh);
-    if (nxt >= ngroups) break;
-    grp = nxt; xp = xpn; cur_valid = nvalid;
-    xr[0] = xn[0]; xr[1] = xn[1];
-  }
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+          if (!pass) b4 = *reinterpret_cast<const f32x4*>(wf.b2 + 32 * mt + 8 * g + 4 * hh);
+          out[0][mt][4 * g] = b4[0]; out[0][mt][4 * g + 1] = b4[1]; out[0][mt][4 * g + 2] = b4[2]; out[0][mt][4 * g + 3] = b4[3];
+        }
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {              // 64 hidden units at a time
+        f32x16 hdn[1][2];
+        linear6_T<2, 2, 1>(hdn, y, W1l + q * b6_floats(64, 64), wf.b1 + pass * 128 + q * 64, lane);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+          for (int k = 0; k < 16; ++k) hdn[0][mt][k] = gelu_erf(hdn[0][mt][k]);
+        linear6_T_acc<2, 2, 1>(out, hdn, W2l + q * b6_floats(64, 64), lane);
+      }
+      if (pass) {
+        // x + (first half + second half): the token (L2) and the first half's sum are re-read here rather
+        // than kept in 64 registers through the GEMMs
+        f32x16 xo_[2], t0[2];
+        load_token64(xo_, x + xo, cur_valid, hh);
+        load_token64(t0, tmp + xo, cur_valid, hh);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) xo_[mt] += t0[mt] + out[0][mt];
+        store_token64(xo_, x + xo, cur_valid, hh);
+      } else {
+        store_token64(out[0], tmp + xo, cur_valid, hh);
+      }
+    }
+  });
 }
 
 __global__ __launch_bounds__(512) void k_qkv(const float* __restrict__ x, const uint8_t* __restrict__ mask, AttnW wn,
                                              float* __restrict__ Q, float* __restrict__ K, float* __restrict__ V,
                                              int B, int R, int C, int Epad, int groups_per_b) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* Wq_l = smem;
-  float* Wk_l = smem + 4096;
-  float* Wv_l = smem + 8192;
+  float* Wl = smem;                          // one bf16x6 image [Wq | Wk | Wv] of 192 rows: y is split once
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5;
-  stage_weight<64>(Wq_l, wn.Wq, 64, tid, 512);
-  stage_weight<64>(Wk_l, wn.Wk, 64, tid, 512);
-  stage_weight<64>(Wv_l, wn.Wv, 64, tid, 512);
+  stage_weight_b6<64>(Wl, wn.Wq, 64, tid, 512, 0, 192);
+  stage_weight_b6<64>(Wl, wn.Wk, 64, tid, 512, 64, 192);
+  stage_weight_b6<64>(Wl, wn.Wv, 64, tid, 512, 128, 192);
   __syncthreads();
   const int ngroups = groups_per_b * B;
   const float qs = rsqrtf((float)NNJ_DH) / sqrtf((float)R);
@@ -783,29 +800,28 @@ __global__ __launch_bounds__(512) void k_qkv(const float* __restrict__ x, const 
     int c, r; bool valid;
     flat_token(((grp % groups_per_b) * 8 + wave) * 32 + (lane & 31), R, C, c, r, valid);
     asm volatile("" ::: "memory");      // keep the parameter loads inside the loop (see k_ffn)
-    f32x16 xr[2], y[1][2], o[1][2];
+    f32x16 xr[2], y[1][2], o[1][6];
     load_token64(xr, x + (((size_t)b * R + r) * C + c) * 64, valid, hh);
     layer_norm64(y[0], xr, wn.ln_w, wn.ln_b, hh);
     const bool padded = mask && mask[(size_t)b * C + c];
     const float qscale = padded ? 0.0f : qs;
+    linear6_T_nb<6, 2, 1>(o, y, Wl, lane);
     // lane (token, hh) owns d = 4hh..4hh+3 of every head: 16-byte pieces at [b][h][c][r*8 + 4hh]
-    auto put = [&](float* dst, float scale) {
+    auto put = [&](float* dst, const float* bias, int m0, float scale) {
       if (!valid) return;
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const int h = 4 * mt + g;
-          f32x4 v = {o[0][mt][4 * g] * scale, o[0][mt][4 * g + 1] * scale, o[0][mt][4 * g + 2] * scale,
-                     o[0][mt][4 * g + 3] * scale};
+          const f32x4 b4 = *reinterpret_cast<const f32x4*>(bias + 32 * mt + 8 * g + 4 * hh);
+          f32x4 v = {(b4[0] + o[0][m0 + mt][4 * g]) * scale, (b4[1] + o[0][m0 + mt][4 * g + 1]) * scale,
+                     (b4[2] + o[0][m0 + mt][4 * g + 2]) * scale, (b4[3] + o[0][m0 + mt][4 * g + 3]) * scale};
           *reinterpret_cast<f32x4*>(dst + (((size_t)b * NNJ_NHEAD + h) * C + c) * Epad + r * 8 + 4 * hh) = v;
         }
     };
-    linear_T<2, 2, 1>(o, y, Wq_l, wn.bq, lane);
-    put(Q, qscale);
-    linear_T<2, 2, 1>(o, y, Wk_l, wn.bk, lane);
-    put(K, 1.0f);
-    linear_T<2, 2, 1>(o, y, Wv_l, wn.bv, lane);
-    put(V, 1.0f);
+    put(Q, wn.bq, 0, qscale);
+    put(K, wn.bk, 2, 1.0f);
+    put(V, wn.bv, 4, 1.0f);
   }
 }
