@@ -13,6 +13,7 @@
 
 #include "../../include/nnj.h"
 #include "nnj_encoder.hpp"
+#include "nnj_rowattn.hpp"
 #include "nnj_scorer.hpp"
 
 namespace {
@@ -20,12 +21,13 @@ namespace {
 enum ProfKind {
   PK_EMBED_QKV = 0, PK_ROW_ATTN, PK_TOK1, PK_TOK2, PK_ROW_XF, PK_PAIR_ALPHA, PK_ALPHA_SOFTMAX,
   PK_PAIR_SCORE, PK_ASSEMBLE, PK_AGG_ALPHA, PK_AGG_FINISH, PK_MISC, PK_PAIR_ALPHA_INCR, PK_PAIR_SCORE_INCR,
+  PK_ROW_QKV, PK_ROW_S, PK_ROW_PV,
   PK_COUNT
 };
 const char* const kProfNames[PK_COUNT] = {
     "k_embed_qkv", "k_row_attn", "k_tok1", "k_tok2", "k_row_xf", "k_pair_alpha", "k_alpha_softmax",
     "k_pair_score", "k_assemble_argmax", "k_agg_alpha", "k_agg_finish", "misc", "k_pair_alpha_incr",
-    "k_pair_score_incr"};
+    "k_pair_score_incr", "k_qkv6", "k_row_s", "k_row_pv"};
 
 char g_err[512] = "";
 
@@ -212,10 +214,29 @@ LoopWs loop_ws(int B, int T, int C) {
   return w;
 }
 
-size_t ws_floats(int B, int T, int C) {
+// encoder scratch (floats, after the state): ctx | Q6 | K6 | V6 | S | M | key classes
+struct EncWs { size_t ctx, q6, k6, v6, s, m, cls, end; };
+EncWs enc_ws(int B, int T, int C) {
   const EncDims d = enc_dims(B, T, C);
+  const Ra6 g = ra6_geom(T, C, d.Epad);
+  const size_t nbh = (size_t)B * NNJ_NHEAD;
+  EncWs w;
+  size_t o = 0;
+  auto take = [&](size_t n) { size_t r = o; o += align_up(n, 64); return r; };
+  w.ctx = take(d.hm);
+  w.q6 = take(nbh * g.qk_bh / 4);
+  w.k6 = take(nbh * g.qk_bh / 4);
+  w.v6 = take(nbh * g.v_bh / 4);
+  w.s = take(nbh * g.s_bh);
+  w.m = take(nbh * g.m_bh);
+  w.cls = take(((size_t)B * g.Cp + 3) / 4);
+  w.end = o;
+  return w;
+}
+
+size_t ws_floats(int B, int T, int C) {
   const size_t state = align_up((size_t)B * T * C * 64, 64);
-  const size_t enc = 4 * align_up(d.hm, 64);
+  const size_t enc = enc_ws(B, T, C).end;
   const size_t loop = loop_ws(B, T, C).end;
   return state + std::max(enc, loop) + 256;
 }
@@ -225,10 +246,16 @@ template <int NT>
 int launch_encoder(nnj_handle* h, const uint8_t* codes, const float* onehot, const uint8_t* mask, float* x,
                    float* scratch, int B, int T, int C, hipStream_t st) {
   const EncDims d = enc_dims(B, T, C);
-  float* Q = scratch;
-  float* K = Q + align_up(d.hm, 64);
-  float* V = K + align_up(d.hm, 64);
-  float* ctx = V + align_up(d.hm, 64);
+  const EncWs ew_ = enc_ws(B, T, C);
+  const Ra6 g6 = ra6_geom(T, C, d.Epad);
+  float* ctx = scratch + ew_.ctx;
+  uint8_t* Q6 = reinterpret_cast<uint8_t*>(scratch + ew_.q6);
+  uint8_t* K6 = reinterpret_cast<uint8_t*>(scratch + ew_.k6);
+  uint8_t* V6 = reinterpret_cast<uint8_t*>(scratch + ew_.v6);
+  float* Sbuf = scratch + ew_.s;
+  float* Mbuf = scratch + ew_.m;
+  uint8_t* cls = reinterpret_cast<uint8_t*>(scratch + ew_.cls);
+  const int nbh = B * NNJ_NHEAD;
   const int nl = h->cfg.num_layers;
   const unsigned colblocks = (unsigned)(((size_t)B * C + 3) / 4);
   const float* lut = h->d_w + h->olut;
@@ -239,8 +266,12 @@ int launch_encoder(nnj_handle* h, const uint8_t* codes, const float* onehot, con
     if (int rc = set_lds(h, k_embed_qkv<NT>, lds)) return rc;
     const float* wp = h->d_w;
     const EmbedW ew{wp + h->oE0, wp + h->oe0, wp + h->oE2, wp + h->oe2};
-    hipLaunchKernelGGL(k_embed_qkv<NT>, dim3(colblocks), dim3(256), lds, st, codes, onehot, ew, lut, mask, x, Q, K, V,
-                       nl > 0 ? attn_ptrs(h, h->lo[0].row) : none, B, T, C, d.Epad, nl > 0 ? 1 : 0);
+    hipLaunchKernelGGL(k_embed_qkv<NT>, dim3(colblocks), dim3(256), lds, st, codes, onehot, ew, lut, mask, x,
+                       (float*)nullptr, (float*)nullptr, (float*)nullptr, none, B, T, C, d.Epad, 0);
+    hipLaunchKernelGGL(k_key_classes, dim3((unsigned)(((size_t)B * g6.Cp + 255) / 256)), dim3(256), 0, st, mask, cls, B,
+                       C, g6.Cp);
+    // V6 keys beyond the alignment meet probabilities that are exactly 0: they only have to be finite
+    if (g6.Cp != C) HIPCHK(h, hipMemsetAsync(V6, 0, (size_t)nbh * g6.v_bh, st));
   }
   // reference no-grad chunking: one masked_fill(-10000) per row chunk, summed (axial_attention.py:35-64)
   int nchunks = 1;
@@ -248,21 +279,39 @@ int launch_encoder(nnj_handle* h, const uint8_t* codes, const float* onehot, con
   const float fill = -10000.0f * (float)nchunks;
   for (int l = 0; l < nl; ++l) {
     {
-      Scope sc(h, st, PK_ROW_ATTN);
-      const int nq = (C + 63) / 64;
-      const dim3 grid((unsigned)(B * NNJ_NHEAD * nq));
-      const int nkt = (C + RA_KEYS - 1) / RA_KEYS;
-#define NNJ_RA_CASE(N)                                                                                  \
-  case N: {                                                                                             \
-    const size_t lds = (size_t)2 * RaShape<N>::STAGE_F * sizeof(float) + (size_t)((nkt * RA_KEYS + 15) / 16 * 16); \
-    if (int rc = set_lds(h, k_row_attn<N>, lds)) return rc;                                             \
-    hipLaunchKernelGGL(k_row_attn<N>, grid, dim3(256), lds, st, Q, K, V, mask, ctx, B, C, fill);        \
+      Scope sc(h, st, PK_ROW_QKV);
+      const size_t lds_qkv = (size_t)b6_floats(192, 64) * sizeof(float);
+      if (int rc = set_lds(h, k_qkv6, lds_qkv)) return rc;
+      const long tiles = (long)((T + 1) / 2) * ((C + 15) / 16);
+      const long ngroups = ((tiles + 7) / 8) * B;
+      const unsigned grid = (unsigned)std::min<long>(ngroups, 2L * h->num_cu);
+      hipLaunchKernelGGL(k_qkv6, dim3(grid), dim3(512), lds_qkv, st, (const float*)x, mask,
+                         attn_ptrs(h, h->lo[l].row), Q6, K6, V6, g6, B);
+    }
+    {
+      Scope sc(h, st, PK_ROW_S);
+      const size_t lds = 3 * RS_STAGE;
+      if (int rc = set_lds(h, k_row_s, lds)) return rc;
+      const unsigned grid = (unsigned)((nbh + 7) / 8 * 8 * g6.nrb * g6.nrb);
+      hipLaunchKernelGGL(k_row_s, dim3(grid), dim3(256), lds, st, (const uint8_t*)Q6, (const uint8_t*)K6,
+                         (const uint8_t*)cls, Sbuf, Mbuf, g6, nbh, fill);
+    }
+    {
+      Scope sc(h, st, PK_ROW_PV);
+      const unsigned grid = (unsigned)((nbh + 7) / 8 * 8 * (g6.Cp / 128));
+#define NNJ_PV_CASE(N)                                                                                   \
+  case N: {                                                                                              \
+    const size_t lds = (size_t)3 * ((N * 3072 + 4095) / 4096 * 4096);                                   \
+    if (int rc = set_lds(h, k_row_pv<N>, lds)) return rc;                                                \
+    hipLaunchKernelGGL(k_row_pv<N>, dim3(grid), dim3(256), lds, st, (const uint8_t*)V6, (const float*)Sbuf, \
+                       (const float*)Mbuf, ctx, g6, nbh);                                                \
   } break;
-      switch (d.nte) {
-        NNJ_RA_CASE(4) NNJ_RA_CASE(8) NNJ_RA_CASE(12) NNJ_RA_CASE(16) NNJ_RA_CASE(20) NNJ_RA_CASE(25) NNJ_RA_CASE(32)
-        default: return fail(h, NNJ_ERR_UNSUPPORTED, "row attention: no instantiation for %d tiles", d.nte);
+      switch (g6.ET) {
+        NNJ_PV_CASE(1) NNJ_PV_CASE(2) NNJ_PV_CASE(4) NNJ_PV_CASE(6) NNJ_PV_CASE(8) NNJ_PV_CASE(10) NNJ_PV_CASE(13)
+        NNJ_PV_CASE(16)
+        default: return fail(h, NNJ_ERR_UNSUPPORTED, "row attention: no instantiation for %d head tiles", g6.ET);
       }
-#undef NNJ_RA_CASE
+#undef NNJ_PV_CASE
     }
     {
       Scope sc(h, st, PK_TOK1);
@@ -284,7 +333,6 @@ int launch_encoder(nnj_handle* h, const uint8_t* codes, const float* onehot, con
     {
       Scope sc(h, st, PK_TOK2);
       const size_t lds = (size_t)16384 * sizeof(float);
-      const bool more = l + 1 < nl;
       {   // persistent FFN / QKV kernels over flat 256-token groups, one workgroup per CU
         const int groups_per_b = (T * C + 255) / 256;
         const long ngroups = (long)groups_per_b * B;
@@ -293,13 +341,6 @@ int launch_encoder(nnj_handle* h, const uint8_t* codes, const float* onehot, con
         if (int rc = set_lds(h, k_ffn, lds_ffn)) return rc;
         // ctx (consumed by k_tok1 above, B*8*C*Epad >= B*T*C*64 floats) is the scratch of the two-pass FFN
         hipLaunchKernelGGL(k_ffn, dim3(grid), dim3(512), lds_ffn, st, x, ctx, ffn_ptrs(h, h->lo[l]), B, T, C, groups_per_b);
-        if (more) {
-          const size_t lds_qkv = (size_t)b6_floats(192, 64) * sizeof(float);
-          if (int rc = set_lds(h, k_qkv, lds_qkv)) return rc;
-          const unsigned grid2 = (unsigned)std::min<long>(ngroups, 2L * h->num_cu);
-          hipLaunchKernelGGL(k_qkv, dim3(grid2), dim3(512), lds_qkv, st, (const float*)x, mask,
-                             attn_ptrs(h, h->lo[l + 1].row), Q, K, V, B, T, C, d.Epad, groups_per_b);
-        }
       }
     }
   }

@@ -1,0 +1,428 @@
+// nnj_rowattn.hpp -- tied row attention of the MSA encoder on the bf16 matrix pipe
+// (restates reference axial_attention.py:6-138: q,k,v projections, q scaling and padding,
+//  attention over the C alignment columns with head dimension E = R*8, softmax over keys).
+//
+// The attention of one (batch element, head) is two fp32-accurate GEMMs with contraction lengths
+// E = 8R (scores) and C (context).  Both run as "bf16x6" (nnj_common.hpp): operands stored as three
+// bf16 planes, six piece products per fp32 product, fp32 accumulation.  A flash-style single kernel
+// would have to keep a query block stationary at 6 bytes per element (77 KiB per 32 queries at R = 50),
+// which neither the register file nor the LDS holds at a useful block size; the scores therefore make
+// one round trip through HBM (288 GB; 8.6 GB per layer at B = 256, C = 1024), which costs ~2 ms of
+// bandwidth per layer next to ~10 ms of matrix work:
+//
+//   k_qkv6    LN -> q,k,v projections -> Q6, K6 (row-major operand tiles) and V6 (transposed operand tiles),
+//             already split into planes and already in the LDS image order of the consumers
+//   k_row_s   S^T = K Q^T per 256x256 block, key classes applied (padded key -> fill, beyond C -> -inf),
+//             written as 32x32 C-layout register images + per-tile row maxima
+//   k_row_pv  per 128 queries: P = exp(S - max) (split in registers), O^T = V^T P^T, ctx = O / sum(P)
+//
+// Operand tile ("A tile"): [3 planes][rows][16 k] bf16 = 32 bytes per row and plane; the two 16-byte
+// halves of a row (k-slots 0-7, 8-15) are stored swapped when bit 3 of the row index is set, which makes
+// the ds_read_b128 of 32 rows x one half conflict free (16 lanes of a read group hit 16 different
+// 16-byte slots).  One MFMA k-step consumes one tile row per lane: lane (row r, half HH) reads its 8
+// bf16 with one ds_read_b128 per plane.
+//   Q6/K6: [bh][ks][row block of 256][plane][256 rows c][32 B]   k-slot 8*(r&1) + d, e = 8r + d, ks = r>>1
+//   V6   : [bh][k16][plane][ET*32 rows e][32 B]                  k-slot 8*HH + 4*jj + t for key
+//                                                                 16*k16 + 8*jj + 4*HH + t
+//          (the key order of registers 8G..8G+7 of a 32x32 C-layout tile, so that P^T is a B operand as is)
+//   S    : [bh][qt][kt][64 lanes][16] fp32: tile (32 keys x 32 queries) of S^T exactly as the accumulator
+//          registers of the wave that computed it; M: [bh][qt][kt][32 queries] tile maxima.
+#pragma once
+#include "nnj_encoder.hpp"
+
+struct Ra6 {
+  int C, T;        // alignment columns (keys = queries), rows
+  int KS;          // 16-wide k-steps of the head dimension: ceil(8T/16)
+  int Cp;          // C rounded up to 256
+  int ET;          // 32-row tiles of the head dimension in V6 / the context accumulators (bucketed)
+  int nrb;         // Cp / 256
+  int nt32;        // Cp / 32
+  int nk16;        // Cp / 16
+  int Epad;        // row length of ctx
+  size_t qk_bh;    // bytes of Q6 (= K6) per (b, h)
+  size_t v_bh;     // bytes of V6 per (b, h)
+  size_t s_bh;     // floats of S per (b, h)
+  size_t m_bh;     // floats of M per (b, h)
+};
+inline Ra6 ra6_geom(int T, int C, int Epad) {
+  Ra6 g;
+  g.C = C; g.T = T; g.Epad = Epad;
+  g.KS = (8 * T + 15) / 16;
+  g.Cp = (C + 255) / 256 * 256;
+  static const int buckets[] = {1, 2, 4, 6, 8, 10, 13, 16};
+  const int need = (16 * g.KS + 31) / 32;
+  g.ET = 16;
+  for (int k : buckets) if (need <= k) { g.ET = k; break; }
+  g.nrb = g.Cp / 256; g.nt32 = g.Cp / 32; g.nk16 = g.Cp / 16;
+  g.qk_bh = (size_t)g.KS * g.nrb * 3 * 8192;
+  g.v_bh = (size_t)g.nk16 * 3 * g.ET * 32 * 32;
+  g.s_bh = (size_t)g.nt32 * g.nt32 * 1024;
+  g.m_bh = (size_t)g.nt32 * g.nt32 * 32;
+  return g;
+}
+
+// key classes of a batch element: 0 = key, 1 = padded key (axial_attention.py:99-103), 2 = beyond C
+__global__ void k_key_classes(const uint8_t* __restrict__ mask, uint8_t* __restrict__ cls, int B, int C, int Cp) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)B * Cp) return;
+  const int b = (int)(i / Cp), c = (int)(i % Cp);
+  cls[i] = c >= C ? 2 : ((mask && mask[(size_t)b * C + c]) ? 1 : 0);
+}
+
+template <int OFF>
+__device__ __forceinline__ void lds_read_frag(u32x4& d, unsigned byte_addr) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(byte_addr), "n"(OFF));
+#endif
+}
+template <int N>
+__device__ __forceinline__ void wait_vmem_le() {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+#endif
+}
+__device__ __forceinline__ void pin_frag(Frag3& f) {
+  pin_after_wait(f.h); pin_after_wait(f.m); pin_after_wait(f.l);
+}
+__device__ __forceinline__ unsigned dpp_quad_xor1(unsigned x) {   // value of lane ^ 1
+  return (unsigned)__builtin_amdgcn_mov_dpp((int)x, 0xB1, 0xF, 0xF, true);
+}
+__device__ __forceinline__ unsigned dpp_quad_xor2(unsigned x) {   // value of lane ^ 2
+  return (unsigned)__builtin_amdgcn_mov_dpp((int)x, 0x4E, 0xF, 0xF, true);
+}
+
+// ------------------------------------------------------------------ k_qkv6
+// Persistent, 8 waves.  A wave owns 2 rows x 16 columns of the alignment (lane & 31 = 16*(r&1) + (c&15),
+// column block aligned to 16): with this shape every store instruction below fills whole 32-byte sectors
+// of both the row-major (Q6, K6) and the transposed (V6) tiles.  Tokens outside the alignment (odd R,
+// C % 16 != 0) are written as zeros: they pad the contraction of the score GEMM.
+__global__ __launch_bounds__(512) void k_qkv6(const float* __restrict__ x, const uint8_t* __restrict__ mask, AttnW wn,
+                                              uint8_t* __restrict__ Q6, uint8_t* __restrict__ K6,
+                                              uint8_t* __restrict__ V6, Ra6 g, int B) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Wl = smem;                          // one bf16x6 image [Wq | Wk | Wv] of 192 rows: y is split once
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5;
+  stage_weight_b6<64>(Wl, wn.Wq, 64, tid, 512, 0, 192);
+  stage_weight_b6<64>(Wl, wn.Wk, 64, tid, 512, 64, 192);
+  stage_weight_b6<64>(Wl, wn.Wv, 64, tid, 512, 128, 192);
+  __syncthreads();
+  const int R = g.T, C = g.C;
+  const int RP = (R + 1) / 2, CB = (C + 15) / 16;
+  const int tiles_per_b = RP * CB, groups_per_b = (tiles_per_b + 7) / 8;
+  const int ngroups = groups_per_b * B;
+  const float qs = rsqrtf((float)NNJ_DH) / sqrtf((float)R);
+  const int lam = lane & 31, c16 = lam & 15, rr = lam >> 4;
+  const unsigned sel = (lane & 1) ? 0x03020706u : 0x05040100u;      // see the 4x4 transpose below
+  const bool bit1 = (lane >> 1) & 1;
+  for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+    const int b = grp / groups_per_b;
+    const int tile = (grp % groups_per_b) * 8 + wave;
+    if (tile >= tiles_per_b) continue;                               // wave-uniform
+    const int rp = tile / CB, cb = tile % CB;
+    const int r = 2 * rp + rr, c = 16 * cb + c16;
+    const bool valid = r < R && c < C;
+    asm volatile("" ::: "memory");      // keep the parameter loads inside the loop (see k_ffn)
+    f32x16 xr[2], y[1][2], o[1][6];
+    load_token64(xr, x + (((size_t)b * R + (valid ? r : 0)) * C + (valid ? c : 0)) * 64, valid, hh);
+    layer_norm64(y[0], xr, wn.ln_w, wn.ln_b, hh);
+    const bool padded = mask && valid && mask[(size_t)b * C + c];
+    const float qscale = padded ? 0.0f : qs;
+    linear6_T_nb<6, 2, 1>(o, y, Wl, lane);
+    const int rb = c >> 8;
+    const size_t qk_row = (size_t)(c & 255) * 32 + 16 * (rr ^ ((c >> 3) & 1)) + 8 * hh;
+    const size_t v_col = 16 * (((c16 >> 2) & 1) ^ rr) + 8 * (c16 >> 3);
+    const int e_row = 8 * r + 4 * hh + (lane & 3);                   // the V6 row this lane stores after the transpose
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        const int h = 4 * mt + gq;
+        const size_t bh = (size_t)b * NNJ_NHEAD + h;
+        // ---- q and k: 8 bytes (d = 4hh..4hh+3) of the 16-byte half (row r) of column c's tile row
+#pragma unroll
+        for (int ten = 0; ten < 2; ++ten) {
+          const float* bias = ten ? wn.bk : wn.bq;
+          const float scale = ten ? 1.0f : qscale;
+          const f32x4 b4 = *reinterpret_cast<const f32x4*>(bias + 32 * mt + 8 * gq + 4 * hh);
+          float v[4];
+#pragma unroll
+          for (int t = 0; t < 4; ++t) v[t] = valid ? (b4[t] + o[0][2 * ten + mt][4 * gq + t]) * scale : 0.f;
+          unsigned p01[3], p23[3];
+          split2(v[0], v[1], p01[0], p01[1], p01[2]);
+          split2(v[2], v[3], p23[0], p23[1], p23[2]);
+          uint8_t* dst = (ten ? K6 : Q6) + bh * g.qk_bh + ((size_t)(rp * g.nrb + rb) * 3) * 8192 + qk_row;
+#pragma unroll
+          for (int p = 0; p < 3; ++p) *reinterpret_cast<uint2*>(dst + (size_t)p * 8192) = make_uint2(p01[p], p23[p]);
+        }
+        // ---- v: transposed.  The lane holds four rows e (t = 0..3) of ONE key; a 4x4 transpose over the
+        // quad (four consecutive keys) gives it one row e = 8r + 4hh + (lane&3) of FOUR keys = 8 bytes.
+        {
+          const f32x4 b4 = *reinterpret_cast<const f32x4*>(wn.bv + 32 * mt + 8 * gq + 4 * hh);
+          float v[4];
+#pragma unroll
+          for (int t = 0; t < 4; ++t) v[t] = valid ? b4[t] + o[0][4 + mt][4 * gq + t] : 0.f;
+          unsigned p01[3], p23[3];
+          split2(v[0], v[1], p01[0], p01[1], p01[2]);
+          split2(v[2], v[3], p23[0], p23[1], p23[2]);
+          uint8_t* dst = V6 + bh * g.v_bh + ((size_t)cb * 3 * (g.ET * 32) + e_row) * 32 + v_col;
+#pragma unroll
+          for (int p = 0; p < 3; ++p) {
+            // step 1 (lane ^ 1): even lanes collect element t=0 (and 2) of the key pair, odd lanes t=1 (and 3)
+            const unsigned x01 = dpp_quad_xor1(p01[p]), x23 = dpp_quad_xor1(p23[p]);
+            const unsigned q_lo = __builtin_amdgcn_perm(x01, p01[p], sel);
+            const unsigned q_hi = __builtin_amdgcn_perm(x23, p23[p], sel);
+            // step 2 (lane ^ 2): lanes 0,1 keep t = 0,1 and receive the other key pair; lanes 2,3 keep t = 2,3
+            const unsigned recv = dpp_quad_xor2(bit1 ? q_lo : q_hi);
+            const unsigned keep = bit1 ? q_hi : q_lo;
+            *reinterpret_cast<uint2*>(dst + (size_t)p * (g.ET * 32) * 32) =
+                bit1 ? make_uint2(recv, keep) : make_uint2(keep, recv);
+          }
+        }
+      }
+  }
+}
+
+// ------------------------------------------------------------------ k_row_s
+// S^T block [256 keys x 256 queries] of one (b, h): 4 waves, wave = 128 keys x 128 queries = 4x4 MFMA tiles
+// (256 accumulator registers), contraction over the KS operand tiles of 16.  Operand tiles stream
+// HBM/L2 -> LDS by LDS-DMA into a three-stage ring (stage = K tile 24 KiB | Q tile 24 KiB); fragments are
+// read with hand-issued ds_read_b128 (the compiler would drain the in-flight DMA before reads of its own);
+// the B fragment of query tile j+1 is in flight behind the 24 MFMAs of group j.  One workgroup barrier per
+// k-step (96 MFMAs per wave).
+#define RS_STAGE 49152u
+__global__ __launch_bounds__(256) void k_row_s(const uint8_t* __restrict__ Q6, const uint8_t* __restrict__ K6,
+                                               const uint8_t* __restrict__ cls, float* __restrict__ S,
+                                               float* __restrict__ M, Ra6 g, int nbh, float fill) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, HH = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tiles_per_bh = g.nrb * g.nrb;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;            // all blocks of one (b,h) on one XCD (one L2)
+  const int bh = (slot / tiles_per_bh) * 8 + xcd;
+  if (bh >= nbh) return;
+  const int tile = slot % tiles_per_bh, kb = tile / g.nrb, qb = tile % g.nrb;
+  const int kh = wave >> 1, qh = wave & 1;
+  const int KS = g.KS;
+  const uint8_t* Kt = K6 + (size_t)bh * g.qk_bh + (size_t)kb * 3 * 8192;
+  const uint8_t* Qt = Q6 + (size_t)bh * g.qk_bh + (size_t)qb * 3 * 8192;
+  const size_t ks_stride = (size_t)g.nrb * 3 * 8192;
+  auto issue = [&](int ks, int stage) {                              // 12 LDS-DMA instructions per wave
+    const int kk = ks < KS ? ks : KS - 1;                            // past the end: harmless reload into a free stage
+    const uint8_t* srcK = Kt + (size_t)kk * ks_stride;
+    const uint8_t* srcQ = Qt + (size_t)kk * ks_stride;
+    uint8_t* dst = reinterpret_cast<uint8_t*>(smem) + stage * RS_STAGE;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+      const int I = wave * 12 + i;                                   // wave-uniform
+      const uint8_t* src = (I < 24 ? srcK + I * 1024 : srcQ + (I - 24) * 1024) + lane * 16;
+      lds_dma16(reinterpret_cast<const float*>(src), reinterpret_cast<float*>(dst + I * 1024));
+    }
+  };
+  const unsigned half = 16u * (unsigned)(HH ^ ((l31 >> 3) & 1));
+  const unsigned aA = lds_addr(smem) + (unsigned)(kh * 128 + l31) * 32u + half;
+  const unsigned aB = lds_addr(smem) + 24576u + (unsigned)(qh * 128 + l31) * 32u + half;
+  f32x16 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  Frag3 A[4], Bf[2];
+  auto readA = [&](unsigned base) {
+    static_for<0, 4>([&](auto ii) {
+      constexpr int i = decltype(ii)::value;
+      lds_read_frag<i * 1024>(A[i].h, base);
+      lds_read_frag<i * 1024 + 8192>(A[i].m, base);
+      lds_read_frag<i * 1024 + 16384>(A[i].l, base);
+    });
+  };
+  auto readB = [&](Frag3& bfr, unsigned base, auto jj) {
+    constexpr int j = decltype(jj)::value;
+    lds_read_frag<j * 1024>(bfr.h, base);
+    lds_read_frag<j * 1024 + 8192>(bfr.m, base);
+    lds_read_frag<j * 1024 + 16384>(bfr.l, base);
+  };
+  issue(0, 0);
+  issue(1, 1);
+  for (int ks = 0; ks < KS; ++ks) {
+    const unsigned so = (unsigned)(ks % 3) * RS_STAGE;
+    wait_vmem_le<12>();                      // tile ks has landed (only tile ks+1 may still be in flight)
+    __syncthreads();                         // ... for every wave; every wave is done with tile ks-1
+    issue(ks + 2, (ks + 2) % 3);
+    readA(aA + so);
+    readB(Bf[0], aB + so, std::integral_constant<int, 0>{});
+    static_for<0, 4>([&](auto jj) {
+      constexpr int j = decltype(jj)::value;
+      lds_wait_all();
+      if constexpr (j == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) pin_frag(A[i]);
+      }
+      pin_frag(Bf[j & 1]);
+      if constexpr (j + 1 < 4) readB(Bf[(j + 1) & 1], aB + so, std::integral_constant<int, j + 1>{});
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[i][j] = mfma_b6(A[i], Bf[j & 1], acc[i][j]);
+    });
+  }
+  wait_vmem_le<0>();                         // nothing of the ring may still be landing when the workgroup ends
+  // ---- epilogue: key classes, tile maxima, register images
+  const int b = bh / NNJ_NHEAD;
+  const uint8_t* cl = cls + (size_t)b * g.Cp + kb * 256 + kh * 128 + 4 * HH;
+  float* Sb = S + (size_t)bh * g.s_bh;
+  float* Mb = M + (size_t)bh * g.m_bh;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    unsigned is1 = 0, is2 = 0;               // bit r: key of accumulator register r is padded / beyond C
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) {
+      const unsigned cw = *reinterpret_cast<const unsigned*>(cl + 32 * i + 8 * gq);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const unsigned c8 = (cw >> (8 * t)) & 0xffu;
+        is1 |= (c8 == 1u ? 1u : 0u) << (4 * gq + t);
+        is2 |= (c8 == 2u ? 1u : 0u) << (4 * gq + t);
+      }
+    }
+    const int kt = kb * 8 + kh * 4 + i;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int qt = qb * 8 + qh * 4 + j;
+      float tmax = -INFINITY;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float s = acc[i][j][r];
+        s = ((is1 >> r) & 1u) ? fill : s;
+        s = ((is2 >> r) & 1u) ? -INFINITY : s;
+        acc[i][j][r] = s;
+        tmax = fmaxf(tmax, s);
+      }
+      tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+      const size_t t = (size_t)qt * g.nt32 + kt;
+      if (HH == 0) Mb[t * 32 + l31] = tmax;
+      float* dst = Sb + t * 1024 + lane * 16;
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq)
+        *reinterpret_cast<f32x4*>(dst + 4 * gq) =
+            (f32x4){acc[i][j][4 * gq], acc[i][j][4 * gq + 1], acc[i][j][4 * gq + 2], acc[i][j][4 * gq + 3]};
+    }
+  }
+}
+
+// ------------------------------------------------------------------ k_row_pv
+// Context of 128 queries of one (b, h): 4 waves x 32 queries, O^T[e x query] in ET accumulators per wave.
+// Per 16 keys: the V6 tile (ET*3 KiB) arrives by LDS-DMA (three-stage ring, one barrier per k-step), the
+// lane's 8 probabilities exp(S - max) -- S read back as the register image k_row_s wrote, the next tile
+// prefetched -- are split into a B fragment in registers, and ET A fragments stream from LDS through a
+// two-deep software pipeline (hand-issued reads).  sum(P) is carried per lane; ctx = O / sum.
+template <int ET>
+__global__ __launch_bounds__(256) void k_row_pv(const uint8_t* __restrict__ V6, const float* __restrict__ S,
+                                                const float* __restrict__ M, float* __restrict__ ctx, Ra6 g,
+                                                int nbh) {
+  constexpr unsigned TILE = ET * 3072u;                               // bytes of one V6 tile
+  constexpr unsigned STG = (TILE + 4095u) / 4096u * 4096u;            // stage size: whole KiB per wave
+  constexpr int NIW = STG / 4096;                                     // DMA instructions per wave and tile
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, HH = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nqb = g.Cp / 128;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int bh = (slot / nqb) * 8 + xcd;
+  if (bh >= nbh) return;
+  const int qb = slot % nqb, qt = qb * 4 + wave;
+  const int nk16 = g.nk16;
+  const uint8_t* Vt = V6 + (size_t)bh * g.v_bh;
+  auto issue = [&](int k, int stage) {
+    const int kk = k < nk16 ? k : nk16 - 1;
+    const uint8_t* src = Vt + (size_t)kk * TILE;
+    uint8_t* dst = reinterpret_cast<uint8_t*>(smem) + stage * STG;
+#pragma unroll
+    for (int i = 0; i < NIW; ++i) {
+      const unsigned I = (unsigned)(wave * NIW + i);                  // wave-uniform
+      const unsigned so = I * 1024u < TILE ? I * 1024u : 0u;          // beyond the tile: filler into the stage's pad
+      lds_dma16(reinterpret_cast<const float*>(src + so + lane * 16), reinterpret_cast<float*>(dst + I * 1024u));
+    }
+  };
+  const float* Sq = S + (size_t)bh * g.s_bh + (size_t)qt * g.nt32 * 1024 + lane * 16;
+  const float* Mq = M + (size_t)bh * g.m_bh + (size_t)qt * g.nt32 * 32 + l31;
+  float m = -INFINITY;
+  for (int kt = 0; kt < g.nt32; ++kt) m = fmaxf(m, Mq[(size_t)kt * 32]);
+  auto loadS = [&](f32x16& s, int kt) {
+    const float* p = Sq + (size_t)kt * 1024;
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(p + 4 * gq);
+      s[4 * gq] = v[0]; s[4 * gq + 1] = v[1]; s[4 * gq + 2] = v[2]; s[4 * gq + 3] = v[3];
+    }
+  };
+  f32x16 acc[ET];
+#pragma unroll
+  for (int t = 0; t < ET; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  float lsum = 0.f;
+  f32x16 s_cur, s_nxt;
+  issue(0, 0);
+  loadS(s_cur, 0);
+  issue(1, 1);
+  s_nxt = s_cur;
+  const unsigned aA = lds_addr(smem) + (unsigned)l31 * 32u + 16u * (unsigned)(HH ^ ((l31 >> 3) & 1));
+  Frag3 bfr[2];
+  auto kstep = [&](int k, auto par) {
+    constexpr int P = decltype(par)::value;    // k & 1
+    wait_vmem_le<NIW>();                       // tile k (and the S image issued before tile k+1) has landed
+    __syncthreads();                           // ... for every wave; every wave is done with tile k-1
+    if constexpr (P == 0) {
+      if ((k >> 1) + 1 < g.nt32) loadS(s_nxt, (k >> 1) + 1);
+    }
+    issue(k + 2, (k + 2) % 3);
+    if constexpr (P == 0) {
+      // probabilities of the 32 keys of this S image; registers 0-7 feed this k-step, 8-15 the next
+      f32x16 p;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { p[r] = nnj_exp(s_cur[r] - m); lsum += p[r]; }
+      split8<0>(bfr[0], p);
+      split8<8>(bfr[1], p);
+    }
+    const Frag3& bf = bfr[P];
+    const unsigned so = aA + (unsigned)(k % 3) * STG;
+    Frag3 a[2];
+    lds_read_frag<0>(a[0].h, so);
+    lds_read_frag<ET * 1024>(a[0].m, so);
+    lds_read_frag<2 * ET * 1024>(a[0].l, so);
+    static_for<0, ET>([&](auto ti) {
+      constexpr int t = decltype(ti)::value;
+      lds_wait_all();
+      pin_frag(a[t & 1]);
+      if constexpr (t + 1 < ET) {
+        lds_read_frag<(t + 1) * 1024>(a[(t + 1) & 1].h, so);
+        lds_read_frag<(t + 1) * 1024 + ET * 1024>(a[(t + 1) & 1].m, so);
+        lds_read_frag<(t + 1) * 1024 + 2 * ET * 1024>(a[(t + 1) & 1].l, so);
+      }
+      acc[t] = mfma_b6(a[t & 1], bf, acc[t]);
+    });
+    if constexpr (P == 1) s_cur = s_nxt;
+  };
+  for (int k = 0; k < nk16; k += 2) {          // nk16 is even (Cp is a multiple of 256)
+    kstep(k, std::integral_constant<int, 0>{});
+    kstep(k + 1, std::integral_constant<int, 1>{});
+  }
+  wait_vmem_le<0>();
+  // ---- epilogue: ctx[b][h][q][e] = O / sum(P), e = 32t + 8g + 4HH + 0..3
+  lsum += __shfl_xor(lsum, 32);
+  const float inv = nnj_rcp(lsum);
+  const int q = qt * 32 + l31;
+  if (q < g.C) {
+    float* dst = ctx + ((size_t)bh * g.C + q) * g.Epad;
+    const int E = 8 * g.T;
+#pragma unroll
+    for (int t = 0; t < ET; ++t)
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        const int e = 32 * t + 8 * gq + 4 * HH;
+        if (e < E)
+          *reinterpret_cast<f32x4*>(dst + e) = (f32x4){acc[t][4 * gq] * inv, acc[t][4 * gq + 1] * inv,
+                                                       acc[t][4 * gq + 2] * inv, acc[t][4 * gq + 3] * inv};
+      }
+  }
+}
