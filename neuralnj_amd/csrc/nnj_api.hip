@@ -7,6 +7,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <initializer_list>
 #include <vector>
@@ -290,10 +291,12 @@ int launch_encoder(nnj_handle* h, const uint8_t* codes, const float* onehot, con
     }
     {
       Scope sc(h, st, PK_ROW_S);
-      const size_t lds = 3 * RS_STAGE;
-      if (int rc = set_lds(h, k_row_s, lds)) return rc;
-      const unsigned grid = (unsigned)((nbh + 7) / 8 * 8 * g6.nrb * g6.nrb);
-      hipLaunchKernelGGL(k_row_s, dim3(grid), dim3(256), lds, st, (const uint8_t*)Q6, (const uint8_t*)K6,
+      constexpr int QW = 128;
+      const size_t lds = (size_t)RsShape<QW>::NST * RsShape<QW>::STAGE;
+      if (int rc = set_lds(h, k_row_s<QW>, lds)) return rc;
+      const long nblocks = (long)(nbh + 7) / 8 * 8 * g6.nrb * (g6.Cp / QW);
+      const unsigned grid = (unsigned)nblocks;
+      hipLaunchKernelGGL(k_row_s<QW>, dim3(grid), dim3(256), lds, st, (const uint8_t*)Q6, (const uint8_t*)K6,
                          (const uint8_t*)cls, Sbuf, Mbuf, g6, nbh, fill);
     }
     {

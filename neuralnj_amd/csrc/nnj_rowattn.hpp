@@ -25,8 +25,8 @@
 //   V6   : [bh][k16][plane][ET*32 rows e][32 B]                  k-slot 8*HH + 4*jj + t for key
 //                                                                 16*k16 + 8*jj + 4*HH + t
 //          (the key order of registers 8G..8G+7 of a 32x32 C-layout tile, so that P^T is a B operand as is)
-//   S    : [bh][qt][kt][64 lanes][16] fp32: tile (32 keys x 32 queries) of S^T exactly as the accumulator
-//          registers of the wave that computed it; M: [bh][qt][kt][32 queries] tile maxima.
+//   S    : [bh][qt][kt][4][64 lanes][4] fp32: tile (32 keys x 32 queries) of S^T as the accumulator registers
+//          (group g = registers 4g..4g+3) of the wave that computed it; M: [bh][qt][kt][32 queries] tile maxima.
 #pragma once
 #include "nnj_encoder.hpp"
 
@@ -76,9 +76,24 @@ __device__ __forceinline__ void lds_read_frag(u32x4& d, unsigned byte_addr) {
 #endif
 }
 template <int N>
+__device__ __forceinline__ void lds_wait_le() {     // at most N LDS reads still in flight (they return in order)
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
+  __builtin_amdgcn_sched_barrier(0);
+#endif
+}
+template <int N>
 __device__ __forceinline__ void wait_vmem_le() {
 #if defined(__HIP_DEVICE_COMPILE__)
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+#endif
+}
+// Workgroup barrier WITHOUT the fence of __syncthreads(): the fence drains vmcnt to 0, i.e. it would wait
+// for the LDS-DMA of the tiles that are meant to stay in flight across the barrier.  The callers wait for
+// exactly the pieces they need (counted vmcnt) before it; LDS is only read by hand-issued reads after it.
+__device__ __forceinline__ void barrier_nofence() {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("s_barrier" ::: "memory");
 #endif
 }
 __device__ __forceinline__ void pin_frag(Frag3& f) {
@@ -189,43 +204,68 @@ __global__ __launch_bounds__(512) void k_qkv6(const float* __restrict__ x, const
 // read with hand-issued ds_read_b128 (the compiler would drain the in-flight DMA before reads of its own);
 // the B fragment of query tile j+1 is in flight behind the 24 MFMAs of group j.  One workgroup barrier per
 // k-step (96 MFMAs per wave).
-#define RS_STAGE 49152u
-__global__ __launch_bounds__(256) void k_row_s(const uint8_t* __restrict__ Q6, const uint8_t* __restrict__ K6,
-                                               const uint8_t* __restrict__ cls, float* __restrict__ S,
-                                               float* __restrict__ M, Ra6 g, int nbh, float fill) {
+// QW = queries per workgroup: 256 (wave = 128 keys x 128 queries, 256 accumulator registers, one
+// workgroup per CU, three-stage ring) or 128 (wave = 128 x 64, 128 accumulator registers, two-stage ring
+// of 36 KiB stages: TWO workgroups per CU, which are not synchronised with each other -- one computes while
+// the other issues DMA pieces, waits at its barrier or stores its tiles).
+template <int QW>
+struct RsShape {
+  static constexpr int NJ = QW / 64;                                 // query tiles per wave
+  static constexpr int NST = QW == 256 ? 3 : 2;
+  static constexpr unsigned QPL = QW * 32u;                          // bytes of one plane of the Q tile
+  static constexpr unsigned STAGE = 24576u + 3u * QPL;
+  static constexpr int NP = (24 + 3 * QW / 32) / 4;                  // DMA pieces per wave and k-step
+};
+template <int QW>
+__global__ __launch_bounds__(256, QW == 128 ? 2 : 1) void k_row_s(const uint8_t* __restrict__ Q6, const uint8_t* __restrict__ K6,
+                                                             const uint8_t* __restrict__ cls, float* __restrict__ S,
+                                                             float* __restrict__ M, Ra6 g, int nbh, float fill) {
+  using SH = RsShape<QW>;
+  constexpr int NJ = SH::NJ, NP = SH::NP, NST = SH::NST;
+  constexpr unsigned QPL = SH::QPL, STAGE = SH::STAGE;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, HH = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int tiles_per_bh = g.nrb * g.nrb;
+  const int nqb = g.Cp / QW;
+  const int tiles_per_bh = g.nrb * nqb;
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;            // all blocks of one (b,h) on one XCD (one L2)
   const int bh = (slot / tiles_per_bh) * 8 + xcd;
   if (bh >= nbh) return;
-  const int tile = slot % tiles_per_bh, kb = tile / g.nrb, qb = tile % g.nrb;
-  const int kh = wave >> 1, qh = wave & 1;
+  const int tile = slot % tiles_per_bh, kb = tile / nqb, qb = tile % nqb;
+  const int kh = wave >> 1, qh = wave & 1;                           // key half, query half
   const int KS = g.KS;
+  const int q0 = qb * QW;                                            // first query of the block
   const uint8_t* Kt = K6 + (size_t)bh * g.qk_bh + (size_t)kb * 3 * 8192;
-  const uint8_t* Qt = Q6 + (size_t)bh * g.qk_bh + (size_t)qb * 3 * 8192;
+  const uint8_t* Qt = Q6 + (size_t)bh * g.qk_bh + (size_t)(q0 >> 8) * 3 * 8192 + (size_t)(q0 & 255) * 32;
   const size_t ks_stride = (size_t)g.nrb * 3 * 8192;
-  auto issue = [&](int ks, int stage) {                              // 12 LDS-DMA instructions per wave
+  // DMA piece i (of NP per wave and tile pair): 1 KiB of the K tile (pieces 0..23 of the workgroup) or of one
+  // plane of the Q tile.  An LDS-DMA instruction costs 60-185 issue cycles: the pieces of the next tile are
+  // spread over the MFMA groups of a k-step instead of being issued in one burst.
+  auto issue_piece = [&](auto pi, int ks, int stage) {
+    constexpr int i = decltype(pi)::value;
     const int kk = ks < KS ? ks : KS - 1;                            // past the end: harmless reload into a free stage
-    const uint8_t* srcK = Kt + (size_t)kk * ks_stride;
-    const uint8_t* srcQ = Qt + (size_t)kk * ks_stride;
-    uint8_t* dst = reinterpret_cast<uint8_t*>(smem) + stage * RS_STAGE;
-#pragma unroll
-    for (int i = 0; i < 12; ++i) {
-      const int I = wave * 12 + i;                                   // wave-uniform
-      const uint8_t* src = (I < 24 ? srcK + I * 1024 : srcQ + (I - 24) * 1024) + lane * 16;
-      lds_dma16(reinterpret_cast<const float*>(src), reinterpret_cast<float*>(dst + I * 1024));
+    const int I = wave * NP + i;                                     // wave-uniform
+    const uint8_t* src;
+    if (I < 24) {
+      src = Kt + I * 1024;
+    } else {
+      const int J = I - 24, pl = J / (QW / 32), pc = J % (QW / 32);  // plane, 1-KiB piece of the plane
+      src = Qt + (size_t)pl * 8192 + pc * 1024;
     }
+    uint8_t* dst = reinterpret_cast<uint8_t*>(smem) + stage * STAGE + I * 1024;
+    lds_dma16(reinterpret_cast<const float*>(src + (size_t)kk * ks_stride + lane * 16), reinterpret_cast<float*>(dst));
+  };
+  auto issue = [&](int ks, int stage) {
+    static_for<0, NP>([&](auto pi) { issue_piece(pi, ks, stage); });
   };
   const unsigned half = 16u * (unsigned)(HH ^ ((l31 >> 3) & 1));
   const unsigned aA = lds_addr(smem) + (unsigned)(kh * 128 + l31) * 32u + half;
-  const unsigned aB = lds_addr(smem) + 24576u + (unsigned)(qh * 128 + l31) * 32u + half;
-  f32x16 acc[4][4];
+  const unsigned aB = lds_addr(smem) + 24576u + (unsigned)(qh * 32 * NJ + l31) * 32u + half;
+  f32x16 acc[4][NJ];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   Frag3 A[4], Bf[2];
@@ -240,19 +280,19 @@ __global__ __launch_bounds__(256) void k_row_s(const uint8_t* __restrict__ Q6, c
   auto readB = [&](Frag3& bfr, unsigned base, auto jj) {
     constexpr int j = decltype(jj)::value;
     lds_read_frag<j * 1024>(bfr.h, base);
-    lds_read_frag<j * 1024 + 8192>(bfr.m, base);
-    lds_read_frag<j * 1024 + 16384>(bfr.l, base);
+    lds_read_frag<j * 1024 + QPL>(bfr.m, base);
+    lds_read_frag<j * 1024 + 2 * QPL>(bfr.l, base);
   };
   issue(0, 0);
-  issue(1, 1);
+  if constexpr (NST == 3) issue(1, 1);
   for (int ks = 0; ks < KS; ++ks) {
-    const unsigned so = (unsigned)(ks % 3) * RS_STAGE;
-    wait_vmem_le<12>();                      // tile ks has landed (only tile ks+1 may still be in flight)
-    __syncthreads();                         // ... for every wave; every wave is done with tile ks-1
-    issue(ks + 2, (ks + 2) % 3);
+    const unsigned so = (unsigned)(ks % NST) * STAGE;
+    if constexpr (NST == 3) wait_vmem_le<NP>(); else wait_vmem_le<0>();   // tile ks has landed
+    barrier_nofence();                       // ... for every wave; every wave is done with tile ks-1
+    const int st2 = (ks + NST - 1) % NST;    // the stage of tile ks-1 takes tile ks+NST-1
     readA(aA + so);
     readB(Bf[0], aB + so, std::integral_constant<int, 0>{});
-    static_for<0, 4>([&](auto jj) {
+    static_for<0, NJ>([&](auto jj) {
       constexpr int j = decltype(jj)::value;
       lds_wait_all();
       if constexpr (j == 0) {
@@ -260,9 +300,17 @@ __global__ __launch_bounds__(256) void k_row_s(const uint8_t* __restrict__ Q6, c
         for (int i = 0; i < 4; ++i) pin_frag(A[i]);
       }
       pin_frag(Bf[j & 1]);
-      if constexpr (j + 1 < 4) readB(Bf[(j + 1) & 1], aB + so, std::integral_constant<int, j + 1>{});
-#pragma unroll
-      for (int i = 0; i < 4; ++i) acc[i][j] = mfma_b6(A[i], Bf[j & 1], acc[i][j]);
+      if constexpr (j + 1 < NJ) readB(Bf[(j + 1) & 1], aB + so, std::integral_constant<int, j + 1>{});
+      static_for<0, 4>([&](auto ii) {
+        constexpr int i = decltype(ii)::value;
+        acc[i][j] = mfma_b6(A[i], Bf[j & 1], acc[i][j]);
+        // pieces behind the first MFMA groups; a k-step with few groups takes two per group
+        constexpr int grp = 4 * j + i, per = (NP + 4 * NJ - 2) / (4 * NJ - 1);
+        static_for<0, per>([&](auto ee) {
+          constexpr int piece = grp * per + decltype(ee)::value;
+          if constexpr (piece < NP) issue_piece(std::integral_constant<int, piece>{}, ks + NST - 1, st2);
+        });
+      });
     });
   }
   wait_vmem_le<0>();                         // nothing of the ring may still be landing when the workgroup ends
@@ -286,8 +334,8 @@ __global__ __launch_bounds__(256) void k_row_s(const uint8_t* __restrict__ Q6, c
     }
     const int kt = kb * 8 + kh * 4 + i;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int qt = qb * 8 + qh * 4 + j;
+    for (int j = 0; j < NJ; ++j) {
+      const int qt = q0 / 32 + qh * NJ + j;
       float tmax = -INFINITY;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -300,10 +348,10 @@ __global__ __launch_bounds__(256) void k_row_s(const uint8_t* __restrict__ Q6, c
       tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
       const size_t t = (size_t)qt * g.nt32 + kt;
       if (HH == 0) Mb[t * 32 + l31] = tmax;
-      float* dst = Sb + t * 1024 + lane * 16;
+      float* dst = Sb + t * 1024 + lane * 4;   // image [4 register groups][64 lanes][4]: every store is 1 KiB contiguous
 #pragma unroll
       for (int gq = 0; gq < 4; ++gq)
-        *reinterpret_cast<f32x4*>(dst + 4 * gq) =
+        *reinterpret_cast<f32x4*>(dst + 256 * gq) =
             (f32x4){acc[i][j][4 * gq], acc[i][j][4 * gq + 1], acc[i][j][4 * gq + 2], acc[i][j][4 * gq + 3]};
     }
   }
@@ -332,18 +380,18 @@ __global__ __launch_bounds__(256) void k_row_pv(const uint8_t* __restrict__ V6, 
   const int qb = slot % nqb, qt = qb * 4 + wave;
   const int nk16 = g.nk16;
   const uint8_t* Vt = V6 + (size_t)bh * g.v_bh;
-  auto issue = [&](int k, int stage) {
+  auto issue_piece = [&](auto pi, int k, int stage) {              // DMA piece i of NIW per wave and tile
+    constexpr int i = decltype(pi)::value;
     const int kk = k < nk16 ? k : nk16 - 1;
-    const uint8_t* src = Vt + (size_t)kk * TILE;
-    uint8_t* dst = reinterpret_cast<uint8_t*>(smem) + stage * STG;
-#pragma unroll
-    for (int i = 0; i < NIW; ++i) {
-      const unsigned I = (unsigned)(wave * NIW + i);                  // wave-uniform
-      const unsigned so = I * 1024u < TILE ? I * 1024u : 0u;          // beyond the tile: filler into the stage's pad
-      lds_dma16(reinterpret_cast<const float*>(src + so + lane * 16), reinterpret_cast<float*>(dst + I * 1024u));
-    }
+    const unsigned I = (unsigned)(wave * NIW + i);                    // wave-uniform
+    const unsigned so = I * 1024u < TILE ? I * 1024u : 0u;            // beyond the tile: filler into the stage's pad
+    lds_dma16(reinterpret_cast<const float*>(Vt + (size_t)kk * TILE + so + lane * 16),
+              reinterpret_cast<float*>(reinterpret_cast<uint8_t*>(smem) + stage * STG + I * 1024u));
   };
-  const float* Sq = S + (size_t)bh * g.s_bh + (size_t)qt * g.nt32 * 1024 + lane * 16;
+  auto issue = [&](int k, int stage) {
+    static_for<0, NIW>([&](auto pi) { issue_piece(pi, k, stage); });
+  };
+  const float* Sq = S + (size_t)bh * g.s_bh + (size_t)qt * g.nt32 * 1024 + lane * 4;
   const float* Mq = M + (size_t)bh * g.m_bh + (size_t)qt * g.nt32 * 32 + l31;
   float m = -INFINITY;
   for (int kt = 0; kt < g.nt32; ++kt) m = fmaxf(m, Mq[(size_t)kt * 32]);
@@ -351,7 +399,7 @@ __global__ __launch_bounds__(256) void k_row_pv(const uint8_t* __restrict__ V6, 
     const float* p = Sq + (size_t)kt * 1024;
 #pragma unroll
     for (int gq = 0; gq < 4; ++gq) {
-      const f32x4 v = *reinterpret_cast<const f32x4*>(p + 4 * gq);
+      const f32x4 v = *reinterpret_cast<const f32x4*>(p + 256 * gq);
       s[4 * gq] = v[0]; s[4 * gq + 1] = v[1]; s[4 * gq + 2] = v[2]; s[4 * gq + 3] = v[3];
     }
   };
@@ -370,12 +418,15 @@ __global__ __launch_bounds__(256) void k_row_pv(const uint8_t* __restrict__ V6, 
   Frag3 bfr[2];
   auto kstep = [&](int k, auto par) {
     constexpr int P = decltype(par)::value;    // k & 1
-    wait_vmem_le<NIW>();                       // tile k (and the S image issued before tile k+1) has landed
-    __syncthreads();                           // ... for every wave; every wave is done with tile k-1
+    // tile k has landed.  Vector memory operations retire in order; younger than tile k's pieces are the
+    // pieces of tile k+1 and, on odd k, the 4 loads of the next S image issued at the top of k-1 (which has
+    // until the top of k+1: two k-steps of HBM latency)
+    if constexpr (P == 1) wait_vmem_le<NIW + 4>(); else wait_vmem_le<NIW>();
+    barrier_nofence();                         // ... for every wave; every wave is done with tile k-1
     if constexpr (P == 0) {
       if ((k >> 1) + 1 < g.nt32) loadS(s_nxt, (k >> 1) + 1);
     }
-    issue(k + 2, (k + 2) % 3);
+    const int st2 = (k + 2) % 3;                // its pieces go out between the MFMA groups below
     if constexpr (P == 0) {
       // probabilities of the 32 keys of this S image; registers 0-7 feed this k-step, 8-15 the next
       f32x16 p;
@@ -386,20 +437,24 @@ __global__ __launch_bounds__(256) void k_row_pv(const uint8_t* __restrict__ V6, 
     }
     const Frag3& bf = bfr[P];
     const unsigned so = aA + (unsigned)(k % 3) * STG;
-    Frag3 a[2];
-    lds_read_frag<0>(a[0].h, so);
-    lds_read_frag<ET * 1024>(a[0].m, so);
-    lds_read_frag<2 * ET * 1024>(a[0].l, so);
+    // A fragments: three buffers, two tiles ahead (one group of 6 MFMAs = 192 cycles is less than an LDS
+    // round trip under load)
+    Frag3 a[3];
+    auto rd = [&](auto ti) {
+      constexpr int t = decltype(ti)::value;
+      lds_read_frag<t * 1024>(a[t % 3].h, so);
+      lds_read_frag<t * 1024 + ET * 1024>(a[t % 3].m, so);
+      lds_read_frag<t * 1024 + 2 * ET * 1024>(a[t % 3].l, so);
+    };
+    rd(std::integral_constant<int, 0>{});
+    if constexpr (ET > 1) rd(std::integral_constant<int, 1>{});
     static_for<0, ET>([&](auto ti) {
       constexpr int t = decltype(ti)::value;
-      lds_wait_all();
-      pin_frag(a[t & 1]);
-      if constexpr (t + 1 < ET) {
-        lds_read_frag<(t + 1) * 1024>(a[(t + 1) & 1].h, so);
-        lds_read_frag<(t + 1) * 1024 + ET * 1024>(a[(t + 1) & 1].m, so);
-        lds_read_frag<(t + 1) * 1024 + 2 * ET * 1024>(a[(t + 1) & 1].l, so);
-      }
-      acc[t] = mfma_b6(a[t & 1], bf, acc[t]);
+      if constexpr (t + 1 < ET) lds_wait_le<3>(); else lds_wait_all();      // fragment t is in (t+1 may be landing)
+      pin_frag(a[t % 3]);
+      if constexpr (t + 2 < ET) rd(std::integral_constant<int, t + 2>{});
+      acc[t] = mfma_b6(a[t % 3], bf, acc[t]);
+      if constexpr (t < NIW) issue_piece(std::integral_constant<int, t>{}, k + 2, st2);
     });
     if constexpr (P == 1) s_cur = s_nxt;
   };
