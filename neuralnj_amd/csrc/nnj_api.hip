@@ -421,7 +421,7 @@ int launch_pair_scores(nnj_handle* h, const RowSet& rs, const int* ij_prev, cons
   if (has_ctx) {
     {
       Scope sc(h, st, PK_PAIR_ALPHA);
-      const size_t lds = 2 * 3 * 4096 * sizeof(float);
+      const size_t lds = 2 * 14336 * sizeof(float);
       if (int rc = set_lds(h, k_pair_alpha<1, 8>, lds)) return rc;
       hipLaunchKernelGGL((k_pair_alpha<1, 8>), grid, dim3(512), lds, st, rs, sw, ij_prev, base + w.alpha_part, mode, n, C,
                          g.npairs, g.ppad, g.cs);

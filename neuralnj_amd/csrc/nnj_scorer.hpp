@@ -90,7 +90,18 @@ __device__ __forceinline__ void site_store(const SiteRegs<NTHR>& R, float* img_a
     const int sw = 4 * wswz(r, ch);
     *reinterpret_cast<f32x4*>(img_s + r * 64 + sw) = R.s[k];
     *reinterpret_cast<f32x4*>(img_u + r * 64 + sw) = R.u[k];
-    if (WITH_A) *reinterpret_cast<f32x4*>(img_a + r * 64 + sw) = R.a[k];
+    if (WITH_A) {
+      // K' as a bf16x6 A image [3 planes][64 rows r][64 d] (the layout of stage_weight_b6): this thread's four
+      // features d = 4ch..4ch+3 are one half of chunk q = 4*kt + 2*G + hh  (d = 32kt + 16G + 8j + 4hh + t)
+      const int q = 4 * (ch >> 3) + 2 * ((ch >> 2) & 1) + (ch & 1), j = (ch >> 1) & 1;
+      unsigned h01, m01, l01, h23, m23, l23;
+      split2(R.a[k][0], R.a[k][1], h01, m01, l01);
+      split2(R.a[k][2], R.a[k][3], h23, m23, l23);
+      uint2* img = reinterpret_cast<uint2*>(img_a) + (r * 8 + wswz6<8>(r, q)) * 2 + j;   // 8-byte units
+      img[0] = make_uint2(h01, h23);
+      img[64 * 8 * 2] = make_uint2(m01, m23);
+      img[2 * 64 * 8 * 2] = make_uint2(l01, l23);
+    }
     if (WITH_T) {
       // S^T as a bf16x6 A image: [3 planes][64 d][64 r'] bf16, row d = the r' order of stage_weight_b6
       unsigned short* t16 = reinterpret_cast<unsigned short*>(img_t);
@@ -139,7 +150,7 @@ template <int TPW, int NW>
 __global__ __launch_bounds__(64 * NW) void k_pair_alpha(RowSet rs, ScorerW w, const int* __restrict__ ij_prev,
                                                     float* __restrict__ alpha_part, int mode, int n, int C,
                                                     int npairs, int ppad, int cs) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];   // 2 x [img_k | img_s | img_u]
+  extern __shared__ __attribute__((aligned(16))) float smem[];   // 2 x [img_k (bf16x6) | img_s | img_u]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5;
   const int sc = blockIdx.x, pg = blockIdx.y, b = blockIdx.z;
   const int c0 = sc * cs, c1 = min(C, c0 + cs);
@@ -161,23 +172,23 @@ __global__ __launch_bounds__(64 * NW) void k_pair_alpha(RowSet rs, ScorerW w, co
   SiteRegs<64 * NW> R;
   if (c0 < c1) {
     site_load<true, 64 * NW>(R, rs, b, n, C, c0, rs.Kp, tid);
-    site_store<true, false, 64 * NW>(R, smem, smem + 4096, smem + 8192, nullptr, tid);
+    site_store<true, false, 64 * NW>(R, smem, smem + 6144, smem + 10240, nullptr, tid);
   }
   __syncthreads();
   for (int c = c0; c < c1; ++c) {
-    float* cur = smem + ((c - c0) & 1) * 12288;
-    float* nxt = smem + (((c - c0) & 1) ^ 1) * 12288;
+    float* cur = smem + ((c - c0) & 1) * 14336;
+    float* nxt = smem + (((c - c0) & 1) ^ 1) * 14336;
     const bool more = c + 1 < c1;
     if (more) site_load<true, 64 * NW>(R, rs, b, n, C, c + 1, rs.Kp, tid);     // in flight behind the MFMAs
     if (any) {
 #pragma unroll
       for (int tt = 0; tt < TPW; ++tt) {
         f32x16 x[1][2];
-        gate_tile(x[0], cur + 4096, cur + 8192, w.bh, pi[tt], pj[tt], hh);
-        linear_T_acc<2, 2, 1>(acc[tt], x, cur, lane);
+        gate_tile(x[0], cur + 6144, cur + 10240, w.bh, pi[tt], pj[tt], hh);
+        linear6_T_acc<2, 2, 1, true>(acc[tt], x, cur, lane);
       }
     }
-    if (more) site_store<true, false, 64 * NW>(R, nxt, nxt + 4096, nxt + 8192, nullptr, tid);
+    if (more) site_store<true, false, 64 * NW>(R, nxt, nxt + 6144, nxt + 10240, nullptr, tid);
     __syncthreads();
   }
 #pragma unroll
