@@ -380,14 +380,13 @@ int launch_pair_scores(nnj_handle* h, const RowSet& rs, const int* ij_prev, cons
     if (has_ctx) {
       {
         Scope sc(h, st, PK_PAIR_ALPHA_INCR);
+        const size_t lds = (size_t)(b6_floats(64, 64) + 8 * b6_floats(32, 64) + 16) * sizeof(float);
         if (big) {
-          const size_t lds = (size_t)4 * 2 * 2 * 2048 * sizeof(float);
-          if (int rc = set_lds(h, k_inc_alpha<2, 4>, lds)) return rc;
-          hipLaunchKernelGGL((k_inc_alpha<2, 4>), grid, dim3(256), lds, st, rs, sw, ij_prev, base + w.alpha_part, n, C, g.cs);
+          if (int rc = set_lds(h, k_inc_alpha<2>, lds)) return rc;
+          hipLaunchKernelGGL((k_inc_alpha<2>), grid, dim3(512), lds, st, rs, sw, ij_prev, base + w.alpha_part, n, C, g.cs);
         } else {
-          const size_t lds = (size_t)8 * 2 * 1 * 2048 * sizeof(float);
-          if (int rc = set_lds(h, k_inc_alpha<1, 8>, lds)) return rc;
-          hipLaunchKernelGGL((k_inc_alpha<1, 8>), grid, dim3(512), lds, st, rs, sw, ij_prev, base + w.alpha_part, n, C, g.cs);
+          if (int rc = set_lds(h, k_inc_alpha<1>, lds)) return rc;
+          hipLaunchKernelGGL((k_inc_alpha<1>), grid, dim3(512), lds, st, rs, sw, ij_prev, base + w.alpha_part, n, C, g.cs);
         }
       }
       {

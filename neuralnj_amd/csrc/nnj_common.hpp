@@ -270,6 +270,37 @@ __device__ __forceinline__ f32x16 mfma_b6(const Frag3& a, const Frag3& b, f32x16
   return c;
 }
 
+// ---- hand-issued fragment reads and counted waits for kernels whose operand images arrive by LDS-DMA
+template <int OFF>
+__device__ __forceinline__ void lds_read_frag(u32x4& d, unsigned byte_addr) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(byte_addr), "n"(OFF));
+#endif
+}
+template <int N>
+__device__ __forceinline__ void lds_wait_le() {     // at most N LDS reads still in flight (they return in order)
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
+  __builtin_amdgcn_sched_barrier(0);
+#endif
+}
+template <int N>
+__device__ __forceinline__ void wait_vmem_le() {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+#endif
+}
+// Workgroup barrier WITHOUT the fence of __syncthreads(): the fence drains vmcnt to 0, i.e. it would wait
+// for the LDS-DMA of the tiles that are meant to stay in flight across the barrier.  The callers wait for
+// exactly the pieces they need (counted vmcnt) before it; LDS is only read by hand-issued reads after it.
+__device__ __forceinline__ void barrier_nofence() {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("s_barrier" ::: "memory");
+#endif
+}
+__device__ __forceinline__ void pin_frag(Frag3& f) {
+  pin_after_wait(f.h); pin_after_wait(f.m); pin_after_wait(f.l);
+}
 // LDS weight image for the bf16x6 layers: three planes (h, m, l) of [rows][IN] bf16.  Within a row the
 // in-features are permuted so that the eight a lane needs for one k-step are one 16-byte chunk:
 // chunk q = 4*kt + 2*G + hh holds features 32kt + 16G + 8j + 4hh + t (j = 0,1; t = 0..3) in order
@@ -303,6 +334,30 @@ __device__ __forceinline__ void stage_weight_b6(float* lds, const float* __restr
     split2(v1[2], v1[3], h, m, l); f.h[3] = h; f.m[3] = m; f.l[3] = l;
     const int ir = row0 + r;
     const int o = ir * CH + wswz6<CH>(ir, q);
+    img[o] = f.h; img[plane + o] = f.m; img[2 * plane + o] = f.l;
+  }
+}
+// the same image of the TRANSPOSE of a [IN][rows] fp32 matrix (image row r = column r of g)
+template <int IN>
+__device__ __forceinline__ void stage_weight_b6_T(float* lds, const float* __restrict__ g, int rows, int tid,
+                                                  int nthreads) {
+  constexpr int CH = IN / 8;
+  u32x4* img = reinterpret_cast<u32x4*>(lds);
+  const int plane = rows * CH;
+  for (int i = tid; i < rows * CH; i += nthreads) {
+    const int r = i / CH, q = i % CH;
+    const int f0 = 32 * (q >> 2) + 16 * ((q >> 1) & 1) + 4 * (q & 1);
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = g[(size_t)(f0 + (e & 3) + 8 * (e >> 2)) * rows + r];
+    Frag3 f;
+    unsigned h, m, l;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      split2(v[2 * e], v[2 * e + 1], h, m, l);
+      f.h[e] = h; f.m[e] = m; f.l[e] = l;
+    }
+    const int o = r * CH + wswz6<CH>(r, q);
     img[o] = f.h; img[plane + o] = f.m; img[2 * plane + o] = f.l;
   }
 }

@@ -69,36 +69,6 @@ __global__ void k_key_classes(const uint8_t* __restrict__ mask, uint8_t* __restr
   cls[i] = c >= C ? 2 : ((mask && mask[(size_t)b * C + c]) ? 1 : 0);
 }
 
-template <int OFF>
-__device__ __forceinline__ void lds_read_frag(u32x4& d, unsigned byte_addr) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(byte_addr), "n"(OFF));
-#endif
-}
-template <int N>
-__device__ __forceinline__ void lds_wait_le() {     // at most N LDS reads still in flight (they return in order)
-#if defined(__HIP_DEVICE_COMPILE__)
-  asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
-  __builtin_amdgcn_sched_barrier(0);
-#endif
-}
-template <int N>
-__device__ __forceinline__ void wait_vmem_le() {
-#if defined(__HIP_DEVICE_COMPILE__)
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-#endif
-}
-// Workgroup barrier WITHOUT the fence of __syncthreads(): the fence drains vmcnt to 0, i.e. it would wait
-// for the LDS-DMA of the tiles that are meant to stay in flight across the barrier.  The callers wait for
-// exactly the pieces they need (counted vmcnt) before it; LDS is only read by hand-issued reads after it.
-__device__ __forceinline__ void barrier_nofence() {
-#if defined(__HIP_DEVICE_COMPILE__)
-  asm volatile("s_barrier" ::: "memory");
-#endif
-}
-__device__ __forceinline__ void pin_frag(Frag3& f) {
-  pin_after_wait(f.h); pin_after_wait(f.m); pin_after_wait(f.l);
-}
 __device__ __forceinline__ unsigned dpp_quad_xor1(unsigned x) {   // value of lane ^ 1
   return (unsigned)__builtin_amdgcn_mov_dpp((int)x, 0xB1, 0xF, 0xF, true);
 }
