@@ -378,14 +378,22 @@ __device__ __forceinline__ void inc_load(IncRaw<NT>& raw, const RowSet& rs, cons
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
     const size_t o = bo + ((size_t)L.slot_r[nt] * C + c) * 64;
-    load_token64(raw.sr[nt], rs.S + o, L.r[nt] < n, hh);
-    load_token64(raw.ur[nt], rs.U + o, L.r[nt] < n, hh);
+    // lanes beyond the live rows read row 0 (slot_r is clamped) and are NOT zeroed: their pairs are never
+    // used, and as image rows/columns they only ever meet attention weights that are exactly 0
+    load_token64(raw.sr[nt], rs.S + o, true, hh);
+    load_token64(raw.ur[nt], rs.U + o, true, hh);
   }
 }
-// x = z*x_i + (1-z)*x_j with (i,j) = sort(m, r)  (model.py:105-108, 186-197)
+// x = z*x_i + (1-z)*x_j with (i,j) = sort(m, r), z = sigmoid(U_i - U_j + b)  (model.py:105-108, 186-197).
+// With 1 - sigmoid(t) = sigmoid(-t) both orders are one expression,
+//     x = S_m + sigmoid(U_r - U_m + s*b) * (S_r - S_m),   s = +1 if r < m else -1,
+// which needs no per-element selects (8 VALU instructions per element).
 template <int NT>
 __device__ __forceinline__ void inc_gate(f32x16 (&x)[NT][2], const IncRaw<NT>& raw, const IncShared& sh,
                                          const IncLane& L, const float* bh, int hh) {
+  float sgn[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) sgn[nt] = L.r_first[nt] ? 1.0f : -1.0f;
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -396,11 +404,8 @@ __device__ __forceinline__ void inc_gate(f32x16 (&x)[NT][2], const IncRaw<NT>& r
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
           const int k = 4 * g + t;
-          const float d = sh.um[mt][k] - raw.ur[nt][mt][k];
-          const float z = sigmoidf_((L.r_first[nt] ? -d : d) + b4[t]);
-          const float a = L.r_first[nt] ? raw.sr[nt][mt][k] : sh.sm[mt][k];
-          const float c2 = L.r_first[nt] ? sh.sm[mt][k] : raw.sr[nt][mt][k];
-          x[nt][mt][k] = c2 + z * (a - c2);                 // z*x_i + (1-z)*x_j
+          const float z = sigmoidf_((raw.ur[nt][mt][k] - sh.um[mt][k]) + sgn[nt] * b4[t]);
+          x[nt][mt][k] = sh.sm[mt][k] + z * (raw.sr[nt][mt][k] - sh.sm[mt][k]);
         }
     }
 }
