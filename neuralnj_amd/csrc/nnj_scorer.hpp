@@ -540,6 +540,19 @@ __global__ __launch_bounds__(512) void k_inc_score(RowSet rs, ScorerW w, const i
   if (c < c1) inc_load<1>(raw, rs, L, bo, n, C, c, hh);
   for (; c < c1; c += NSLOT) {
     asm volatile("" ::: "memory");
+    // alpha[pair][r'] (only r' < 32*KT can be non-zero) is re-read per site from L2 (keeping it in registers
+    // next to the prefetched rows would spill); issued first, it lands behind the gate and the image
+    f32x16 at[1][KT];
+    if constexpr (CTX) {
+      const float* ap = alpha + ((size_t)b * 64 + r) * 64;
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          const f32x4 v = *reinterpret_cast<const f32x4*>(ap + 32 * kt + 8 * g4 + 4 * hh);
+          at[0][kt][4 * g4] = v[0]; at[0][kt][4 * g4 + 1] = v[1]; at[0][kt][4 * g4 + 2] = v[2]; at[0][kt][4 * g4 + 3] = v[3];
+        }
+    }
     f32x16 x[1][2];
     {
       IncShared sh;
@@ -570,19 +583,7 @@ __global__ __launch_bounds__(512) void k_inc_score(RowSet rs, ScorerW w, const i
     const int cn = c + NSLOT;
     inc_load<1>(raw, rs, L, bo, n, C, cn < c1 ? cn : c, hh);           // prefetch behind the MFMAs (last: harmless reload)
     if constexpr (CTX) {
-      // alpha[pair][r'] (only r' < 32*KT can be non-zero), re-read per site from L1/L2: keeping it in
-      // registers next to the prefetched rows would spill
-      f32x16 xg[1][2], g[1][2], at[1][KT];
-      {
-        const float* ap = alpha + ((size_t)b * 64 + r) * 64;
-#pragma unroll
-        for (int kt = 0; kt < KT; ++kt)
-#pragma unroll
-          for (int g4 = 0; g4 < 4; ++g4) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(ap + 32 * kt + 8 * g4 + 4 * hh);
-            at[0][kt][4 * g4] = v[0]; at[0][kt][4 * g4 + 1] = v[1]; at[0][kt][4 * g4 + 2] = v[2]; at[0][kt][4 * g4 + 3] = v[3];
-          }
-      }
+      f32x16 xg[1][2], g[1][2];
       linear6_T_nb<2, KT, 1, true>(xg, at, img_t, lane);
       linear6_T<2, 2, 1, true>(g, xg, Wg_l, w.bg, lane);
 #pragma unroll
