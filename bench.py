@@ -30,6 +30,10 @@ from neuralnj_amd import synth, utils, weights  # noqa: E402
 from neuralnj_amd._lib import Nnj  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 / 16x16x4_f32
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 (v_mfma_f32_32x32x16_bf16, 32 cycles)
+# fp32 GEMMs run as "bf16x6": every fp32 product is 6 bf16 MFMA products (exact 3-way operand split, fp32
+# accumulate, fp32 accuracy), so the matrix-pipe ceiling for ALGORITHMIC fp32 flops is the bf16 peak / 6.
+PEAK_F32_VIA_BF16X6_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6.0
 PEAK_HBM_GBS = 8000.0
 
 
@@ -44,18 +48,24 @@ def kernel_models(B, T, L, layers):
     P = T * (T - 1) // 2
     row = C * D * 4
     m = {}
-    m["k_row_attn"] = dict(flops=B * 4.0 * C * C * T * D, bytes=B * 4.0 * 8 * C * E * 4)
-    m["k_tok1"] = dict(flops=B * (N * 10.0 * D * D + 4.0 * T * T * C * D), bytes=B * 3.0 * N * D * 4)
-    m["k_tok2"] = dict(flops=B * N * (4.0 * D * F + 6.0 * D * D), bytes=B * 5.0 * N * D * 4)
-    m["k_embed_qkv"] = dict(flops=B * N * (6.0 * D * D + 8.0 * D + 2.0 * D * D), bytes=B * (N + 4.0 * N * D * 4))
+    X6, F32 = PEAK_F32_VIA_BF16X6_TFLOPS, PEAK_F32_MFMA_TFLOPS
+    heads = 8
+    planes = heads * C * E * 6.0              # bytes of one of Q6/K6/V6 per tree (3 bf16 planes)
+    sbytes = heads * C * C * 4.0              # the score images of one tree
+    m["k_qkv6"] = dict(flops=B * N * 6.0 * D * D, bytes=B * (N * D * 4 + 3.0 * planes), peak=X6)
+    m["k_row_s"] = dict(flops=B * 2.0 * C * C * T * D, bytes=B * (2.0 * planes + sbytes), peak=X6)
+    m["k_row_pv"] = dict(flops=B * 2.0 * C * C * T * D, bytes=B * (planes + sbytes + heads * C * E * 4.0), peak=X6)
+    m["k_tok1"] = dict(flops=B * (N * 10.0 * D * D + 4.0 * T * T * C * D), bytes=B * 3.0 * N * D * 4, peak=F32)
+    m["k_tok2"] = dict(flops=B * N * 4.0 * D * F, bytes=B * 6.0 * N * D * 4, peak=X6)
+    m["k_embed_qkv"] = dict(flops=B * N * 8.0 * D, bytes=B * (N + N * D * 4.0), peak=F32)
     # reference per (pair, site): W_h 2D^2, W_q 2D^2, alpha 2nD | x_g 2nD, W_g 2D^2, s_out 2D^2+2D
-    m["k_pair_alpha"] = dict(flops=B * P * C * (4.0 * D * D + 2.0 * T * D), bytes=B * 3.0 * T * row)
-    m["k_pair_score"] = dict(flops=B * P * C * (2.0 * T * D + 4.0 * D * D + 2.0 * D), bytes=B * 2.0 * T * row)
+    m["k_pair_alpha"] = dict(flops=B * P * C * (4.0 * D * D + 2.0 * T * D), bytes=B * 3.0 * T * row, peak=X6)
+    m["k_pair_score"] = dict(flops=B * P * C * (2.0 * T * D + 4.0 * D * D + 2.0 * D), bytes=B * 2.0 * T * row, peak=X6)
     ns = list(range(T - 1, 1, -1))
     m["k_pair_alpha_incr"] = dict(flops=B * sum(n * C * (4.0 * D * D + 2.0 * n * D) for n in ns if n > 2) / max(1, len([n for n in ns if n > 2])),
-                                  bytes=B * sum(3.0 * n * row for n in ns) / len(ns))
+                                  bytes=B * sum(2.0 * n * row for n in ns) / len(ns), peak=X6)
     m["k_pair_score_incr"] = dict(flops=B * sum(n * C * (2.0 * n * D + 4.0 * D * D + 2.0 * D) for n in ns) / len(ns),
-                                  bytes=B * sum(2.0 * n * row for n in ns) / len(ns))
+                                  bytes=B * sum(2.0 * n * row for n in ns) / len(ns), peak=X6)
     return m
 
 
@@ -169,6 +179,8 @@ def main():
         "value": trees / elapsed, "unit": "trees/sec", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "precision": "fp32 results (GEMMs as exact 3-way bf16 operand splits on the bf16 matrix pipe, six piece "
+                     "products per fp32 product, fp32 accumulation; parity tests at the fp32 tolerances)",
         "config": {"workload": f"Batch={B} synthetic {T}x{L} MSAs per GPU, Argmax rollout (BASELINE configs[2]; "
                                f"configs[3] when sharded over 8 GPUs)",
                    "batch_per_gpu": B, "taxa": T, "sites": L, "gap_frac": 0.2, "model": "dim64 heads8 layers6 patch1",
@@ -188,8 +200,11 @@ def main():
                 if os.path.exists(tpath) and (B, T, L) == (256, 50, 1024):
                     # measured HBM bytes per launch (rocprofv3 PMC passes, see profiles/traffic.json "source")
                     traffic = json.load(open(tpath)).get("per_kind", {}).get(name, {}).get("hbm_bytes_per_launch")
-                roof = {"kernel": name, "bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS,
-                        "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
+                peak = models[name]["peak"]
+                roof = {"kernel": name, "bound": "mfma", "achieved": ach, "peak": peak,
+                        "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic,
+                        "peak_basis": ("dense bf16 MFMA peak / 6 (fp32 GEMM as six bf16 piece products, fp32 accumulate)"
+                                       if peak == PEAK_F32_VIA_BF16X6_TFLOPS else "dense fp32 MFMA peak"),
                         "avg_launch_ms": ms / cnt, "launches": cnt,
                         "share_of_kernel_time": ms / total_ms if total_ms else None,
                         "algorithmic_flops_per_launch": models[name]["flops"],
