@@ -56,8 +56,8 @@ def kernel_models(B, T, L, layers):
     m["k_row_s"] = dict(flops=B * 2.0 * C * C * T * D, bytes=B * (2.0 * planes + sbytes), peak=X6)
     m["k_row_pv"] = dict(flops=B * 2.0 * C * C * T * D, bytes=B * (planes + sbytes + heads * C * E * 4.0), peak=X6)
     m["k_tok1"] = dict(flops=B * (N * 10.0 * D * D + 4.0 * T * T * C * D), bytes=B * 3.0 * N * D * 4, peak=F32)
-    m["k_tok2"] = dict(flops=B * N * 4.0 * D * F, bytes=B * 6.0 * N * D * 4, peak=X6)
-    m["k_embed_qkv"] = dict(flops=B * N * 8.0 * D, bytes=B * (N + N * D * 4.0), peak=F32)
+    m["k_ffn"] = dict(flops=B * N * 4.0 * D * F, bytes=B * 6.0 * N * D * 4, peak=X6)
+    m["k_embed"] = dict(flops=B * N * 8.0 * D, bytes=B * (N + N * D * 4.0), peak=F32)
     # reference per (pair, site): W_h 2D^2, W_q 2D^2, alpha 2nD | x_g 2nD, W_g 2D^2, s_out 2D^2+2D
     m["k_pair_alpha"] = dict(flops=B * P * C * (4.0 * D * D + 2.0 * T * D), bytes=B * 3.0 * T * row, peak=X6)
     m["k_pair_score"] = dict(flops=B * P * C * (2.0 * T * D + 4.0 * D * D + 2.0 * D), bytes=B * 2.0 * T * row, peak=X6)

@@ -20,13 +20,13 @@
 namespace {
 
 enum ProfKind {
-  PK_EMBED_QKV = 0, PK_ROW_ATTN, PK_TOK1, PK_TOK2, PK_ROW_XF, PK_PAIR_ALPHA, PK_ALPHA_SOFTMAX,
+  PK_EMBED = 0, PK_TOK1, PK_FFN, PK_ROW_XF, PK_PAIR_ALPHA, PK_ALPHA_SOFTMAX,
   PK_PAIR_SCORE, PK_ASSEMBLE, PK_AGG_ALPHA, PK_AGG_FINISH, PK_MISC, PK_PAIR_ALPHA_INCR, PK_PAIR_SCORE_INCR,
   PK_ROW_QKV, PK_ROW_S, PK_ROW_PV,
   PK_COUNT
 };
 const char* const kProfNames[PK_COUNT] = {
-    "k_embed_qkv", "k_row_attn", "k_tok1", "k_tok2", "k_row_xf", "k_pair_alpha", "k_alpha_softmax",
+    "k_embed", "k_tok1", "k_ffn", "k_row_xf", "k_pair_alpha", "k_alpha_softmax",
     "k_pair_score", "k_assemble_argmax", "k_agg_alpha", "k_agg_finish", "misc", "k_pair_alpha_incr",
     "k_pair_score_incr", "k_qkv6", "k_row_s", "k_row_pv"};
 
@@ -136,15 +136,10 @@ int check_shape(nnj_handle* h, int B, int T, int L) {
   return NNJ_OK;
 }
 
-struct EncDims { int Epad, ld, NT, nte; size_t hm; };   // hm = floats of one head-major buffer
+struct EncDims { int Epad, NT; size_t hm; };   // hm = floats of the head-major context buffer
 EncDims enc_dims(int B, int T, int C) {
   EncDims d;
-  // head dim of the tied row attention, padded (with zeros) to a compiled tile count
-  static const int buckets[] = {4, 8, 12, 16, 20, 25, 32};
-  d.nte = 32;
-  for (int k : buckets) if (T * 8 <= 16 * k) { d.nte = k; break; }
-  d.Epad = 16 * d.nte;
-  d.ld = (d.Epad - 4 + 31) / 32 * 32 + 4;
+  d.Epad = (T * 8 + 15) / 16 * 16;             // row length of ctx [B,8,C,Epad]
   d.NT = T <= 32 ? 1 : 2;
   d.hm = (size_t)B * NNJ_NHEAD * C * d.Epad;
   return d;
@@ -260,15 +255,13 @@ int launch_encoder(nnj_handle* h, const uint8_t* codes, const float* onehot, con
   const int nl = h->cfg.num_layers;
   const unsigned colblocks = (unsigned)(((size_t)B * C + 3) / 4);
   const float* lut = h->d_w + h->olut;
-  AttnW none{};
   {
-    Scope sc(h, st, PK_EMBED_QKV);
-    const size_t lds = 4 * 4096 * sizeof(float);
-    if (int rc = set_lds(h, k_embed_qkv<NT>, lds)) return rc;
+    Scope sc(h, st, PK_EMBED);
+    const size_t lds = 4096 * sizeof(float);
+    if (int rc = set_lds(h, k_embed<NT>, lds)) return rc;
     const float* wp = h->d_w;
     const EmbedW ew{wp + h->oE0, wp + h->oe0, wp + h->oE2, wp + h->oe2};
-    hipLaunchKernelGGL(k_embed_qkv<NT>, dim3(colblocks), dim3(256), lds, st, codes, onehot, ew, lut, mask, x,
-                       (float*)nullptr, (float*)nullptr, (float*)nullptr, none, B, T, C, d.Epad, 0);
+    hipLaunchKernelGGL(k_embed<NT>, dim3(colblocks), dim3(256), lds, st, codes, onehot, ew, lut, x, B, T, C);
     hipLaunchKernelGGL(k_key_classes, dim3((unsigned)(((size_t)B * g6.Cp + 255) / 256)), dim3(256), 0, st, mask, cls, B,
                        C, g6.Cp);
     // V6 keys beyond the alignment meet probabilities that are exactly 0: they only have to be finite
@@ -332,9 +325,9 @@ int launch_encoder(nnj_handle* h, const uint8_t* codes, const float* onehot, con
                            attn_ptrs(h, h->lo[l].col), B, T, C, d.Epad, dbg);
       }
     }
-    if (l == 0 && (h->debug_stop == 1 || h->debug_stop == 2)) break;   // values >= 16 are timing ablations (tools/ablate.py)
+    if (l == 0 && (h->debug_stop == 1 || h->debug_stop == 2)) break;
     {
-      Scope sc(h, st, PK_TOK2);
+      Scope sc(h, st, PK_FFN);
       const size_t lds = (size_t)16384 * sizeof(float);
       {   // persistent FFN / QKV kernels over flat 256-token groups, one workgroup per CU
         const int groups_per_b = (T * C + 255) / 256;

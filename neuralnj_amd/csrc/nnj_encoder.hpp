@@ -1,19 +1,16 @@
 // nnj_encoder.hpp -- gfx950 kernels of the axial MSA encoder
 // (restates reference model.py:67-88, msa_modules.py:62-151, axial_attention.py:6-255).
 //
-// Tiling: one wave owns one alignment column (b, c) and all R rows of it ("column
-// wave", tokens = rows, NT = ceil(R/32) tiles of 32 tokens on the lanes); a workgroup
-// is 4 waves = 4 adjacent columns, so every row contributes 1 KiB contiguous bytes.
-// Token-local stages chain in registers (nnj_common.hpp); weights sit in LDS.
+// Tiling of the token-local stages: one wave owns one alignment column (b, c) and all R rows of it
+// ("column wave", tokens = rows, NT = ceil(R/32) tiles of 32 tokens on the lanes), or -- k_ffn -- 32 tokens
+// of a flat (column, row) order.  Token-local stages chain in registers (nnj_common.hpp); weights sit in LDS.
 //
-//   k_embed_qkv : embed (6-entry LUT of the site codes) -> x ; LN -> q,k,v (row attn, layer 0)
-//   k_row_attn  : tied row attention, flash style, head dim E = R*8, per (b, h, 64 queries)
-//   k_tok1      : ctx -> out_proj -> +x ; LN -> q,k,v -> column attention -> out_proj -> +x
-//   k_ffn/k_qkv : LN -> fc1 -> GELU -> fc2 -> +x ; LN -> q,k,v of the next layer's row attn (persistent,
-//                 flat token tiling)
+//   k_embed     : embed (6-entry LUT of the site codes, or the embed MLP on float input) -> x
+//   k_tok1/1p   : ctx -> out_proj -> +x ; LN -> q,k,v -> column attention -> out_proj -> +x
+//   k_ffn       : LN -> fc1 -> GELU -> fc2 -> +x   (persistent, flat token tiling, bf16x6)
+// The tied row attention (q,k,v projections, scores, context) lives in nnj_rowattn.hpp.
 //
-// HBM layouts: x [B,R,C,64]; Q/K/V/ctx head-major [B,8,C,Epad] with e = r*8 + d,
-// Epad = roundup(R*8,16) (zero padded) -- a (b,h) slice is a plain [C x Epad] matrix.
+// HBM layouts: x [B,R,C,64]; ctx head-major [B,8,C,Epad] with e = r*8 + d, Epad = roundup(R*8,16).
 #pragma once
 #include "nnj_common.hpp"
 
@@ -27,78 +24,18 @@ struct EmbedW {           // embed = Linear(4 -> 64), GELU, Linear(64 -> 64)  (r
   const float *E0, *e0, *E2, *e2;
 };
 
-// ------------------------------------------------------------------ QKV epilogue
-// Writes one of q/k/v (feature-major registers of the wave's column) to the
-// head-major buffer.  Rows r >= R inside the zero-padded Epad range are written as 0.
-template <int NT>
-__device__ __forceinline__ void store_headmajor(const f32x16 (&v)[NT][2], float* dst, int b, int c, int C,
-                                                int R, int Epad, float scale, int lane, int r0 = 0) {
-  const int tok = lane & 31, hh = lane >> 5;
-#pragma unroll
-  for (int nt = 0; nt < NT; ++nt) {
-    const int r = r0 + 32 * nt + tok;
-    if (r * 8 >= Epad) continue;
-    const bool live = r < R;
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int h = 4 * mt + g;
-        f32x4 o = {0.f, 0.f, 0.f, 0.f};
-        if (live) {
-          o[0] = v[nt][mt][4 * g + 0] * scale; o[1] = v[nt][mt][4 * g + 1] * scale;
-          o[2] = v[nt][mt][4 * g + 2] * scale; o[3] = v[nt][mt][4 * g + 3] * scale;
-        }
-        *reinterpret_cast<f32x4*>(dst + (((size_t)b * NNJ_NHEAD + h) * C + c) * Epad + r * 8 + 4 * hh) = o;
-      }
-  }
-}
-
-// LN + q,k,v projections of the row attention, written head-major.
-// q is pre-multiplied by head_dim^-0.5 / sqrt(R) and zeroed at padded columns
-// (reference axial_attention.py:31-33,77-82).
-template <int NT>
-__device__ __forceinline__ void row_qkv_stage(const f32x16 (&x)[NT][2], const AttnW& w, const float* Wq_l,
-                                              const float* Wk_l, const float* Wv_l, float* Q, float* K,
-                                              float* V, int b, int c, int C, int R, int Epad, bool padded,
-                                              int lane, int r0 = 0) {
-  const int hh = lane >> 5;
-  f32x16 y[NT][2];
-#pragma unroll
-  for (int nt = 0; nt < NT; ++nt) layer_norm64(y[nt], x[nt], w.ln_w, w.ln_b, hh);
-  const float qscale = padded ? 0.0f : (rsqrtf((float)NNJ_DH) / sqrtf((float)R));
-  f32x16 o[NT][2];
-  linear_T<2, 2, NT>(o, y, Wq_l, w.bq, lane);
-  store_headmajor<NT>(o, Q, b, c, C, R, Epad, qscale, lane, r0);
-  linear_T<2, 2, NT>(o, y, Wk_l, w.bk, lane);
-  store_headmajor<NT>(o, K, b, c, C, R, Epad, 1.0f, lane, r0);
-  linear_T<2, 2, NT>(o, y, Wv_l, w.bv, lane);
-  store_headmajor<NT>(o, V, b, c, C, R, Epad, 1.0f, lane, r0);
-}
-
-// ------------------------------------------------------------------ k_embed_qkv
+// ------------------------------------------------------------------ k_embed
 // codes uint8 [B,R,L] (patch_size 1: C == L); lut [6][64] = embed MLP of the six site
 // vectors (reference model.py:39-43,76-77 evaluated on phydata.py:38-46's vectors).
 template <int NT>
-__global__ __launch_bounds__(256) void k_embed_qkv(const uint8_t* __restrict__ codes,
+__global__ __launch_bounds__(256) void k_embed(const uint8_t* __restrict__ codes,
                                                    const float* __restrict__ onehot, EmbedW ew,
                                                    const float* __restrict__ lut,
-                                                   const uint8_t* __restrict__ mask, float* __restrict__ x,
-                                                   float* __restrict__ Q, float* __restrict__ K,
-                                                   float* __restrict__ V, AttnW w, int B, int R, int C,
-                                                   int Epad, int do_qkv) {
+                                                   float* __restrict__ x, int B, int R, int C) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* Wq_l = smem;
-  float* Wk_l = smem + 4096;
-  float* Wv_l = smem + 8192;
-  float* E2_l = smem + 12288;     // only staged for the general float input
+  float* E2_l = smem;             // only staged for the general float input
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (onehot) stage_weight<64>(E2_l, ew.E2, 64, tid, 256);
-  if (do_qkv) {
-    stage_weight<64>(Wq_l, w.Wq, 64, tid, 256);
-    stage_weight<64>(Wk_l, w.Wk, 64, tid, 256);
-    stage_weight<64>(Wv_l, w.Wv, 64, tid, 256);
-  }
   __syncthreads();
   const long col = (long)blockIdx.x * 4 + wave;   // (b, c) flattened
   if (col >= (long)B * C) return;
@@ -142,232 +79,6 @@ __global__ __launch_bounds__(256) void k_embed_qkv(const uint8_t* __restrict__ c
       if (!valid || code > 5) code = 5;
       load_token64(xr[nt], lut + code * 64, valid, hh);
       store_token64(xr[nt], x + (((size_t)b * R + r) * C + c) * 64, valid, hh);
-    }
-  }
-  if (do_qkv) {
-    const bool padded = mask && mask[(size_t)b * C + c];
-    row_qkv_stage<NT>(xr, w, Wq_l, Wk_l, Wv_l, Q, K, V, b, c, C, R, Epad, padded, lane);
-  }
-}
-
-// ------------------------------------------------------------------ k_row_attn
-// Tied row attention for one (b, h) and 64 query columns: standard attention over the
-// C columns with head dimension Epad = 16*NTE (reference axial_attention.py:97-114), online
-// softmax, fp32 MFMA 16x16x4.  Computes S^T = K Q^T so that the probabilities come out
-// in the A-operand layout of the P*V product.
-//   * K/V tiles of 16 keys stream HBM/L2 -> LDS by LDS-DMA (global_load_lds_dwordx4) into a
-//     two-stage ring: the DMA of tile t+1 is in flight while tile t is multiplied; one
-//     workgroup barrier per tile.
-//   * LDS rows are padded to LD = roundup(Epad-4,32)+4 floats (LD % 32 == 4 makes the float2
-//     K reads and the scalar V reads bank-conflict free); DMA lanes that land in the pad read a
-//     harmless address.
-//   * MFMA operands are read from LDS by hand-issued ds_reads in batches, software pipelined:
-//     the next batch is issued before the current batch's MFMAs and waited for after them.
-//   * the key-padding mask of the batch element sits in LDS (no global load inside the loop).
-#define RA_KEYS 16        // keys per tile
-template <int NTE>
-struct RaShape {
-  static constexpr int Epad = 16 * NTE;
-  static constexpr int LD = (Epad - 4 + 31) / 32 * 32 + 4;
-  static constexpr int CPR = LD / 4, CPE = Epad / 4;              // 16-byte chunks per LDS row / global row
-  static constexpr int KI = (RA_KEYS * CPR + 63) / 64;            // 1-KiB DMA instructions per K (or V) tile
-  static constexpr int NDMA = (2 * KI + 3) / 4;                   // LDS-DMA instructions per wave per tile
-  static constexpr int STAGE_F = NDMA * 4 * 256;                  // floats per ring stage: [K: KI KiB | V: KI KiB]
-  static constexpr int NS = 2 * NTE;                              // float2 k-steps of S^T
-};
-
-template <int NTE>
-__global__ __launch_bounds__(256) void k_row_attn(const float* __restrict__ Q, const float* __restrict__ K,
-                                                  const float* __restrict__ V,
-                                                  const uint8_t* __restrict__ mask, float* __restrict__ ctx,
-                                                  int B, int C, float fill) {
-  using SH = RaShape<NTE>;
-  constexpr int Epad = SH::Epad, LD = SH::LD, NS = SH::NS, NDMA = SH::NDMA;
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  // XCD-aware mapping: all query tiles of one (b,h) share blockIdx % 8 (one L2)
-  const int nq = (C + 63) / 64;
-  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-  const int bh = (slot / nq) * 8 + xcd;
-  const int qt = slot % nq;
-  if (bh >= B * NNJ_NHEAD) return;       // whole workgroup exits together
-  const int b = bh / NNJ_NHEAD;
-  const size_t base = (size_t)bh * C * Epad;
-  const int l15 = lane & 15, kq = lane >> 4;
-  const int q0 = qt * 64 + wave * 16;
-  const int qi = q0 + l15;               // this lane's query (B operand column)
-  const bool qvalid = qi < C;
-  const int nkt = (C + RA_KEYS - 1) / RA_KEYS;
-  unsigned char* maskl = reinterpret_cast<unsigned char*>(smem + 2 * SH::STAGE_F);   // [nkt*16]
-
-  // key classes for the whole (b) row: 0 = key, 1 = padded key (axial_attention.py:99-103), 2 = beyond C
-  for (int j = tid; j < nkt * RA_KEYS; j += 256)
-    maskl[j] = j >= C ? 2 : ((mask && mask[(size_t)b * C + j]) ? 1 : 0);
-
-  // DMA plan: the stage image is [K tile | V tile], each KI whole 1-KiB instructions, so every
-  // instruction has ONE wave-uniform source base (K or V tile start) plus a 32-bit per-lane offset
-  // (0 for lanes that land in the row pad: they re-read the tile's first bytes, harmless).
-  unsigned voff[NDMA];
-#pragma unroll
-  for (int i = 0; i < NDMA; ++i) {
-    const int I = wave * NDMA + i;                      // wave-uniform instruction index in the stage
-    const int q = (I < SH::KI ? I : I - SH::KI) * 64 + lane;
-    const int row = q / SH::CPR, cc = q - row * SH::CPR;
-    voff[i] = (row < RA_KEYS && cc < SH::CPE) ? (unsigned)(row * Epad + 4 * cc) : 0u;
-  }
-  auto issue_tile = [&](int kt, int stage) {
-    const int j0 = kt * RA_KEYS;
-    float* dst = smem + stage * SH::STAGE_F + wave * NDMA * 256;
-    const float* Kt = K + base + (size_t)j0 * Epad;     // wave-uniform tile bases
-    const float* Vt = V + base + (size_t)j0 * Epad;
-    if (j0 + RA_KEYS <= C) {                            // (wave-uniform) full tile: base + 32-bit offset
-#pragma unroll
-      for (int i = 0; i < NDMA; ++i) {
-        const int I = wave * NDMA + i;
-        if (I < 2 * SH::KI) lds_dma16((I < SH::KI ? Kt : Vt) + voff[i], dst + i * 256);
-      }
-    } else {                                            // last tile of an alignment with C % 16 != 0
-#pragma unroll
-      for (int i = 0; i < NDMA; ++i) {
-        const int I = wave * NDMA + i;
-        if (I < 2 * SH::KI) {
-          unsigned o = voff[i];
-          if ((j0 + (int)(o / Epad)) >= C) o = 0u;      // keys beyond the alignment: finite filler
-          lds_dma16((I < SH::KI ? Kt : Vt) + o, dst + i * 256);
-        }
-      }
-    }
-  };
-
-  // Q fragment: lane (query, kq) holds Q[query][8s + 2kq + u]
-  float qf[2 * NS];
-#pragma unroll
-  for (int s = 0; s < NS; ++s) {
-    const float2 v = *reinterpret_cast<const float2*>(Q + base + (size_t)(qvalid ? qi : 0) * Epad + 8 * s + 2 * kq);
-    qf[2 * s] = qvalid ? v.x : 0.f; qf[2 * s + 1] = qvalid ? v.y : 0.f;
-  }
-  f32x4 O[NTE];
-#pragma unroll
-  for (int t = 0; t < NTE; ++t) O[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  float m_run = -INFINITY, l_run = 0.f;
-
-  // LDS byte addresses of this lane's operand streams inside a stage
-  const unsigned smem_b = lds_addr(smem);
-  const unsigned ka0 = smem_b + (unsigned)(l15 * LD + 2 * kq) * 4u;                    // K[key l15][2kq + 8s]
-  const unsigned va0 = smem_b + (unsigned)(SH::KI * 256 + 4 * kq * LD + l15) * 4u;     // V[4kq + r][l15 + 16t]
-  const unsigned ma0 = lds_addr(maskl) + 4u * kq;
-
-  constexpr int KB = NS < 10 ? NS : 10;            // float2 reads per S batch
-  constexpr int NKB = (NS + KB - 1) / KB;
-
-  issue_tile(0, 0);
-  for (int kt = 0; kt < nkt; ++kt) {
-    wait_vmem_all();                      // my pieces of tile kt have landed
-    __syncthreads();                      // everyone's pieces landed; everyone is done with tile kt-1
-    if (kt + 1 < nkt) issue_tile(kt + 1, (kt + 1) & 1);
-    const unsigned sb_ = (unsigned)((kt & 1) * SH::STAGE_F) * 4u;
-    const unsigned ka = ka0 + sb_, va = va0 + sb_;
-    const int j0 = kt * RA_KEYS;
-
-    // ---- S^T[key x query]: A = K (lane: key l15, kq) from LDS, B = Q regs; two accumulation chains
-    f32x4 sa = {0.f, 0.f, 0.f, 0.f}, sbb = {0.f, 0.f, 0.f, 0.f};
-    f32x2 kA[KB], kB[KB];
-    float mk4;                             // 4 key-class bytes of this lane's keys
-    lds_read_b32<0>(mk4, ma0 + (unsigned)j0);
-    static_for<0, KB>([&](auto i) { lds_read_b64<32 * decltype(i)::value>(kA[decltype(i)::value], ka); });
-    lds_wait_all();
-    pin_after_wait(mk4);
-#pragma unroll
-    for (int i = 0; i < KB; ++i) pin_after_wait(kA[i]);
-    static_for<0, NKB>([&](auto bi) {
-      constexpr int b0 = decltype(bi)::value * KB;
-      constexpr int nb = (NS - b0) < KB ? (NS - b0) : KB;
-      constexpr int n0 = b0 + KB;
-      constexpr int nn = n0 >= NS ? 0 : ((NS - n0) < KB ? (NS - n0) : KB);
-      f32x2 (&cur)[KB] = (decltype(bi)::value & 1) ? kB : kA;
-      f32x2 (&nxt)[KB] = (decltype(bi)::value & 1) ? kA : kB;
-      static_for<0, nn>([&](auto i) { lds_read_b64<32 * (n0 + decltype(i)::value)>(nxt[decltype(i)::value], ka); });
-#pragma unroll
-      for (int i = 0; i < nb; ++i) {
-        sa = mfma16(cur[i][0], qf[2 * (b0 + i)], sa);
-        sbb = mfma16(cur[i][1], qf[2 * (b0 + i) + 1], sbb);
-      }
-      lds_wait_all();
-#pragma unroll
-      for (int i = 0; i < nn; ++i) pin_after_wait(nxt[i]);
-    });
-    // first V batch goes out now; it lands behind the softmax arithmetic
-    float vA[NTE], vB[NTE];
-    static_for<0, NTE>([&](auto t) { lds_read_b32<64 * decltype(t)::value>(vA[decltype(t)::value], va); });
-
-    // st[r] = S[query = l15][key = j0 + 4*kq + r]
-    const unsigned mbits = __float_as_uint(mk4);
-    float st[4];
-    float tmax = -INFINITY;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const unsigned cls = (mbits >> (8 * r)) & 0xffu;
-      float s = sa[r] + sbb[r];
-      s = cls == 2 ? -INFINITY : (cls == 1 ? fill : s);
-      st[r] = s;
-      tmax = fmaxf(tmax, s);
-    }
-    tmax = fmaxf(tmax, __shfl_xor(tmax, 16));
-    tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
-    const float m_new = fmaxf(m_run, tmax);
-    const float sc = nnj_exp(m_run - m_new);                 // 0 on the first tile (m_run = -inf)
-    float psum = 0.f;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float p = nnj_exp(st[r] - m_new);
-      st[r] = p;
-      psum += p;
-    }
-    psum += __shfl_xor(psum, 16);
-    psum += __shfl_xor(psum, 32);
-    l_run = l_run * sc + psum;
-    m_run = m_new;
-    // rescale O rows (row 4*kq+reg of the C/D layout is query 4*kq+reg; its scale lives in the lanes
-    // with (lane & 15) == that query); skipped when no running maximum moved in this wave
-    if (!__all(sc == 1.0f)) {
-      float scr[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) scr[r] = __shfl(sc, 4 * kq + r);
-#pragma unroll
-      for (int t = 0; t < NTE; ++t) { O[t][0] *= scr[0]; O[t][1] *= scr[1]; O[t][2] *= scr[2]; O[t][3] *= scr[3]; }
-    }
-    lds_wait_all();
-#pragma unroll
-    for (int t = 0; t < NTE; ++t) pin_after_wait(vA[t]);
-    // ---- O[query x e] += P[query x key] V[key x e]; A = P regs, B = V from LDS (one key row per batch)
-    static_for<0, 4>([&](auto ri) {
-      constexpr int r = decltype(ri)::value;
-      float (&cur)[NTE] = (r & 1) ? vB : vA;
-      float (&nxt)[NTE] = (r & 1) ? vA : vB;
-      if constexpr (r + 1 < 4)
-        static_for<0, NTE>([&](auto t) {
-          lds_read_b32<((r + 1) * LD + 16 * decltype(t)::value) * 4>(nxt[decltype(t)::value], va);
-        });
-#pragma unroll
-      for (int t = 0; t < NTE; ++t) O[t] = mfma16(st[r], cur[t], O[t]);
-      lds_wait_all();
-      if constexpr (r + 1 < 4) {
-#pragma unroll
-        for (int t = 0; t < NTE; ++t) pin_after_wait(nxt[t]);
-      }
-    });
-  }
-  // normalise and store: O[t][reg] is (query q0 + 4*kq + reg, e = 16 t + l15)
-  float linv[4];
-#pragma unroll
-  for (int r = 0; r < 4; ++r) linv[r] = nnj_rcp(__shfl(l_run, 4 * kq + r));
-#pragma unroll
-  for (int t = 0; t < NTE; ++t) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int qrow = q0 + 4 * kq + r;
-      if (qrow < C) ctx[base + (size_t)qrow * Epad + 16 * t + l15] = O[t][r] * linv[r];
     }
   }
 }
@@ -699,7 +410,6 @@ __global__ __launch_bounds__(512) void k_tok1p(const float* __restrict__ ctx, co
 // prefetched behind the MFMAs.  No barrier inside the loop.  (The per-group weight re-staging of a
 // non-persistent kernel moved 2.7x more bytes than the activations themselves.)
 //   k_ffn : LN -> fc1 -> GELU -> fc2 -> +x            LDS 128 KiB: W1 [256][64] | W2 [64][256]
-//   k_qkv : LN -> q,k,v of the row attention            LDS  48 KiB: Wq | Wk | Wv
 __device__ __forceinline__ void flat_token(int t, int R, int C, int& c, int& r, bool& valid) {
   valid = t < R * C;
   c = valid ? t / R : 0;
@@ -781,47 +491,4 @@ __global__ __launch_bounds__(512) void k_ffn(float* __restrict__ x, float* __res
       }
     }
   });
-}
-
-__global__ __launch_bounds__(512) void k_qkv(const float* __restrict__ x, const uint8_t* __restrict__ mask, AttnW wn,
-                                             float* __restrict__ Q, float* __restrict__ K, float* __restrict__ V,
-                                             int B, int R, int C, int Epad, int groups_per_b) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* Wl = smem;                          // one bf16x6 image [Wq | Wk | Wv] of 192 rows: y is split once
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5;
-  stage_weight_b6<64>(Wl, wn.Wq, 64, tid, 512, 0, 192);
-  stage_weight_b6<64>(Wl, wn.Wk, 64, tid, 512, 64, 192);
-  stage_weight_b6<64>(Wl, wn.Wv, 64, tid, 512, 128, 192);
-  __syncthreads();
-  const int ngroups = groups_per_b * B;
-  const float qs = rsqrtf((float)NNJ_DH) / sqrtf((float)R);
-  for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
-    const int b = grp / groups_per_b;
-    int c, r; bool valid;
-    flat_token(((grp % groups_per_b) * 8 + wave) * 32 + (lane & 31), R, C, c, r, valid);
-    asm volatile("" ::: "memory");      // keep the parameter loads inside the loop (see k_ffn)
-    f32x16 xr[2], y[1][2], o[1][6];
-    load_token64(xr, x + (((size_t)b * R + r) * C + c) * 64, valid, hh);
-    layer_norm64(y[0], xr, wn.ln_w, wn.ln_b, hh);
-    const bool padded = mask && mask[(size_t)b * C + c];
-    const float qscale = padded ? 0.0f : qs;
-    linear6_T_nb<6, 2, 1>(o, y, Wl, lane);
-    // lane (token, hh) owns d = 4hh..4hh+3 of every head: 16-byte pieces at [b][h][c][r*8 + 4hh]
-    auto put = [&](float* dst, const float* bias, int m0, float scale) {
-      if (!valid) return;
-#pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int h = 4 * mt + g;
-          const f32x4 b4 = *reinterpret_cast<const f32x4*>(bias + 32 * mt + 8 * g + 4 * hh);
-          f32x4 v = {(b4[0] + o[0][m0 + mt][4 * g]) * scale, (b4[1] + o[0][m0 + mt][4 * g + 1]) * scale,
-                     (b4[2] + o[0][m0 + mt][4 * g + 2]) * scale, (b4[3] + o[0][m0 + mt][4 * g + 3]) * scale};
-          *reinterpret_cast<f32x4*>(dst + (((size_t)b * NNJ_NHEAD + h) * C + c) * Epad + r * 8 + 4 * hh) = v;
-        }
-    };
-    put(Q, wn.bq, 0, qscale);
-    put(K, wn.bk, 2, 1.0f);
-    put(V, wn.bv, 4, 1.0f);
-  }
 }

@@ -37,7 +37,7 @@ def test_param_count_and_argument_errors():
     assert lib.nnj_create(C.byref(bad), C.byref(h)) == -2   # NNJ_ERR_UNSUPPORTED, stated loudly
     assert b"embed_dim=64" in lib.nnj_last_error(None)
     assert lib.nnj_profile_kinds() >= 12
-    assert lib.nnj_profile_kind_name(1) == b"k_row_attn"
+    assert lib.nnj_profile_kind_name(1) == b"k_tok1"
 
 
 def test_product_never_imports_the_oracle(repo_root):
