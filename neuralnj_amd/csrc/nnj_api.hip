@@ -16,6 +16,7 @@
 #include "nnj_encoder.hpp"
 #include "nnj_rowattn.hpp"
 #include "nnj_scorer.hpp"
+#include "nnj_scorer16.hpp"
 
 namespace {
 
@@ -146,7 +147,7 @@ EncDims enc_dims(int B, int T, int C) {
 }
 
 // pair-scorer launch geometry
-struct PairGeom { int npairs, tpw, pg, ppad, nsc, cs; };
+struct PairGeom { int npairs, tpw, pg, ppad, nsc, nsc_a, cs, blocks; };   // nsc / nsc_a: partial sets of the scores / of alpha
 PairGeom pair_geom(int mode, int n, int B, int C) {
   PairGeom g;
   if (mode == PAIRS_INCR) {
@@ -158,7 +159,11 @@ PairGeom pair_geom(int mode, int n, int B, int C) {
     if (blocks < 1) blocks = 1;
     g.cs = (C + blocks - 1) / blocks;
     blocks = (C + g.cs - 1) / g.cs;
-    g.nsc = blocks * (n > 32 ? 4 : 8);       // partial sets: one per wave (4 waves for n > 32, 8 otherwise)
+    // partial sets = one per site slot of a workgroup.  alpha: 16-row tiles, 12 waves / (1, 2 or 4 tiles that
+    // share a site).  scores: the same for n <= 16; above, the 32-row kernels (8 slots, or 4 pairs of waves)
+    g.blocks = blocks;
+    g.nsc_a = blocks * (T16_WAVES / (n > 32 ? 4 : (n > 16 ? 2 : 1)));
+    g.nsc = n <= 16 ? g.nsc_a : blocks * (n > 32 ? 4 : 8);
     return g;
   }
   g.npairs = mode == PAIRS_FULL ? n * (n - 1) / 2 : n;
@@ -172,6 +177,7 @@ PairGeom pair_geom(int mode, int n, int B, int C) {
   if (nsc < 1) nsc = 1;
   g.cs = (C + nsc - 1) / nsc;
   g.nsc = (C + g.cs - 1) / g.cs;
+  g.nsc_a = g.nsc; g.blocks = g.nsc;
   return g;
 }
 
@@ -190,10 +196,10 @@ LoopWs loop_ws(int B, int T, int C) {
   w.beta = take((size_t)B * T * nt32);
   size_t ap = 0, al = 0, sp = 0;
   for (int mode = 0; mode < 2; ++mode)
-    for (int n : {T, std::min(T, 32)}) {      // the incremental geometry changes at n = 32
+    for (int n : {T, std::min(T, 32), std::min(T, 16)}) {      // the incremental geometry changes at n = 32 and 16
       if (n < 2) continue;
       PairGeom g = pair_geom(mode, n, B, C);
-      ap = std::max(ap, (size_t)B * g.nsc * g.ppad * 64);
+      ap = std::max(ap, (size_t)B * g.nsc_a * g.ppad * 64);
       al = std::max(al, (size_t)B * g.ppad * 64);
       sp = std::max(sp, (size_t)B * g.nsc * g.ppad);
     }
@@ -368,42 +374,51 @@ int launch_pair_scores(nnj_handle* h, const RowSet& rs, const int* ij_prev, cons
   const ScorerW sw = scorer_ptrs(h);
   const int has_ctx = n > 2 ? 1 : 0;
   if (mode == PAIRS_INCR) {
-    const bool big = n > 32;
-    const dim3 grid((unsigned)(g.nsc / (big ? 4 : 8)), (unsigned)B);
+    const int ng = n > 32 ? 4 : (n > 16 ? 2 : 1);          // 16-row tiles (= waves) that share a site
+    const dim3 grid((unsigned)g.blocks, (unsigned)B);
+    const dim3 blk16(64 * T16_WAVES);
     if (has_ctx) {
       {
         Scope sc(h, st, PK_PAIR_ALPHA_INCR);
-        const size_t lds = (size_t)(b6_floats(64, 64) + 8 * b6_floats(32, 64) + 16) * sizeof(float);
-        if (big) {
-          if (int rc = set_lds(h, k_inc_alpha<2>, lds)) return rc;
-          hipLaunchKernelGGL((k_inc_alpha<2>), grid, dim3(512), lds, st, rs, sw, ij_prev, base + w.alpha_part, n, C, g.cs);
-        } else {
-          if (int rc = set_lds(h, k_inc_alpha<1>, lds)) return rc;
-          hipLaunchKernelGGL((k_inc_alpha<1>), grid, dim3(512), lds, st, rs, sw, ij_prev, base + w.alpha_part, n, C, g.cs);
-        }
+        const size_t lds = (size_t)(6144 + 18432 + 16) * sizeof(float);
+#define NNJ_IA(NG)                                                                                          \
+  case NG:                                                                                                  \
+    if (int rc = set_lds(h, k_inc_alpha16<NG>, lds)) return rc;                                             \
+    hipLaunchKernelGGL((k_inc_alpha16<NG>), grid, blk16, lds, st, rs, sw, ij_prev, base + w.alpha_part, n, C, g.cs); \
+    break;
+        switch (ng) { NNJ_IA(1) NNJ_IA(2) NNJ_IA(4) }
+#undef NNJ_IA
       }
       {
         Scope sc(h, st, PK_ALPHA_SOFTMAX);
         hipLaunchKernelGGL(k_alpha_softmax, dim3((unsigned)(g.ppad / 4), (unsigned)B), dim3(256), 0, st, rs, sw, ij_prev,
-                           base + w.alpha_part, base + w.alpha, mode, n, C, g.npairs, g.ppad, g.nsc);
+                           base + w.alpha_part, base + w.alpha, mode, n, C, g.npairs, g.ppad, g.nsc_a);
       }
     }
     {
       Scope sc(h, st, PK_PAIR_SCORE_INCR);
-      if (big) {
+      if (n <= 16) {
+        // 16-pair tiles: half the padding of the 32-pair kernels (measured 2x faster here); above 16 rows the
+        // group barriers of the shared image cost more than the padding saves
+        const size_t lds = (size_t)(12288 + 18432 + 16) * sizeof(float);
+        if (has_ctx) {
+          if (int rc = set_lds(h, k_inc_score16<1, true>, lds)) return rc;
+          hipLaunchKernelGGL((k_inc_score16<1, true>), grid, blk16, lds, st, rs, sw, ij_prev, base + w.alpha, mask,
+                             base + w.score_part, n, C, g.cs);
+        } else {
+          if (int rc = set_lds(h, k_inc_score16<1, false>, lds)) return rc;
+          hipLaunchKernelGGL((k_inc_score16<1, false>), grid, blk16, lds, st, rs, sw, ij_prev, base + w.alpha, mask,
+                             base + w.score_part, n, C, g.cs);
+        }
+      } else if (n > 32) {
         const size_t lds = (size_t)(2 * b6_floats(64, 64) + 4 * b6_floats(64, 64) + 16) * sizeof(float);
         if (int rc = set_lds(h, k_inc_score<2, true>, lds)) return rc;
         hipLaunchKernelGGL((k_inc_score<2, true>), grid, dim3(512), lds, st, rs, sw, ij_prev, base + w.alpha, mask,
                            base + w.score_part, n, C, g.cs);
-      } else if (has_ctx) {
+      } else {
         const size_t lds = (size_t)(2 * b6_floats(64, 64) + 8 * b6_floats(64, 32) + 16) * sizeof(float);
         if (int rc = set_lds(h, k_inc_score<1, true>, lds)) return rc;
         hipLaunchKernelGGL((k_inc_score<1, true>), grid, dim3(512), lds, st, rs, sw, ij_prev, base + w.alpha, mask,
-                           base + w.score_part, n, C, g.cs);
-      } else {
-        const size_t lds = (size_t)(2 * b6_floats(64, 64) + 8 * b6_floats(64, 32) + 16) * sizeof(float);
-        if (int rc = set_lds(h, k_inc_score<1, false>, lds)) return rc;
-        hipLaunchKernelGGL((k_inc_score<1, false>), grid, dim3(512), lds, st, rs, sw, ij_prev, base + w.alpha, mask,
                            base + w.score_part, n, C, g.cs);
       }
     }

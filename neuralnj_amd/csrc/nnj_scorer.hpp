@@ -410,16 +410,11 @@ __device__ __forceinline__ void inc_gate(f32x16 (&x)[NT][2], const IncRaw<NT>& r
     }
 }
 
-// Phase A: alpha partials of the new pairs.  grid (blocks, B), 8 waves, one 32-pair tile per wave.
-// This kernel is bound by the HBM bytes of the rows it streams, so it does not read K' at all:
-//     x . K'_r  =  x . (A S_r + a0)  =  (A^T x) . S_r  +  x . a0,
-// the last term is the same for every r and cancels in the softmax over r (k_alpha_softmax); the S rows are
-// in registers anyway (the gate needs them).  Per site: gate -> x; x' = A^T x (bf16x6, A^T resident in LDS);
-// the lanes write their S rows as a bf16x6 operand image [3 planes][ROWS r][64 d]; acc[pair][r] += x' . S_r.
-//   KT = 1 (n <= 32): image private to the wave, every wave owns whole sites (c = c0 + wave, +8, ...).
-//   KT = 2 (n  > 32): waves w and w+4 share site slot w&3 and build the 64-row image together, each the rows
-//            of its 32 lanes, between two pair barriers on an LDS counter (see k_tok1p).
-// part[b][sc*NSLOT+slot][pair r][r'].  Bytes per (row, site): 512 (S, U) instead of 768 with K'.
+// Phase A (alpha partials of the new pairs) lives in nnj_scorer16.hpp (k_inc_alpha16): 16-pair tiles, and no
+// K' at all --  x . K'_r = (A^T x) . S_r + x . a0, whose last term is the same for every r and cancels in the
+// softmax over r (k_alpha_softmax); the S rows are in registers anyway (the gate needs them).
+
+// barrier of the two waves that share a site slot (LDS counter; see k_tok1p's pair_barrier)
 __device__ __forceinline__ void pair_barrier_lds(int* cnt, int& epoch) {
   epoch += 2;
   asm volatile("" ::: "memory");
@@ -427,76 +422,6 @@ __device__ __forceinline__ void pair_barrier_lds(int* cnt, int& epoch) {
   for (int spins = 0; *reinterpret_cast<volatile int*>(cnt) < epoch && spins < (1 << 22); ++spins)
     __builtin_amdgcn_s_sleep(1);
   asm volatile("" ::: "memory");
-}
-template <int KT>
-__global__ __launch_bounds__(512) void k_inc_alpha(RowSet rs, ScorerW w, const int* __restrict__ ij_prev,
-                                                   float* __restrict__ alpha_part, int n, int C, int cs) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* At_l = smem;                                      // bf16x6 image of A^T
-  const int tid = threadIdx.x, lane = tid & 63, hh = lane >> 5, tok = lane & 31;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  constexpr int NSLOT = 8 / KT;
-  const int slot = wave % NSLOT, tl = wave / NSLOT;
-  constexpr int IMG = b6_floats(32 * KT, 64);              // [3 planes][32*KT rows][64 d]
-  float* img = smem + b6_floats(64, 64) + slot * IMG;
-  int* cnt = reinterpret_cast<int*>(smem + b6_floats(64, 64) + NSLOT * IMG) + slot;
-  const int sc = blockIdx.x, b = blockIdx.y;
-  const int c0 = sc * cs, c1 = min(C, c0 + cs);
-  stage_weight_b6_T<64>(At_l, w.A, 64, tid, 512);
-  if (tid < NSLOT) reinterpret_cast<int*>(smem + b6_floats(64, 64) + NSLOT * IMG)[tid] = 0;
-  __syncthreads();
-  int epoch = 0;
-  const IncLane L = inc_lane<1>(rs, ij_prev, b, n, lane, 32 * tl);
-  const int r = L.r[0];
-  const size_t bo = (size_t)b * rs.bstride;
-  f32x16 acc[1][KT];
-#pragma unroll
-  for (int mt = 0; mt < KT; ++mt)
-#pragma unroll
-    for (int k = 0; k < 16; ++k) acc[0][mt][k] = 0.f;
-  IncRaw<1> raw;
-  int c = c0 + slot;
-  if (c < c1) inc_load<1>(raw, rs, L, bo, n, C, c, hh);
-  u32x4* im4 = reinterpret_cast<u32x4*>(img);
-  constexpr int PL = 32 * KT * 8;                           // plane stride in 16-byte units
-  for (; c < c1; c += NSLOT) {
-    asm volatile("" ::: "memory");
-    f32x16 x[1][2];
-    {
-      IncShared sh;
-      inc_load_shared(sh, rs, L, bo, C, c, hh);
-      inc_gate<1>(x, raw, sh, L, w.bh, hh);
-    }
-    if constexpr (KT == 2) pair_barrier_lds(cnt, epoch);   // the partner is done with the previous site's image
-    // row r of the image: chunk 4*mt + 2*G + hh = registers 8G..8G+7 of tile mt
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-      Frag3 f0, f1;
-      split8<0>(f0, raw.sr[0][mt]);
-      split8<8>(f1, raw.sr[0][mt]);
-      const int o0 = r * 8 + wswz6<8>(r, 4 * mt + hh), o1 = r * 8 + wswz6<8>(r, 4 * mt + 2 + hh);
-      im4[o0] = f0.h; im4[PL + o0] = f0.m; im4[2 * PL + o0] = f0.l;
-      im4[o1] = f1.h; im4[PL + o1] = f1.m; im4[2 * PL + o1] = f1.l;
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    if constexpr (KT == 2) pair_barrier_lds(cnt, epoch);   // all 64 rows are in the image
-    const int cn = c + NSLOT;
-    inc_load<1>(raw, rs, L, bo, n, C, cn < c1 ? cn : c, hh);           // prefetch behind the MFMAs (last: harmless reload)
-    f32x16 xp[1][2];
-    linear6_T_nb<2, 2, 1, true>(xp, x, At_l, lane);                     // x' = A^T x
-    linear6_T_acc<KT, 2, 1, true>(acc, xp, img, lane);                  // acc[pair][r'] += x' . S_r'
-  }
-  const int part = sc * NSLOT + slot, nparts = gridDim.x * NSLOT;
-  float* dst = alpha_part + (((size_t)b * nparts + part) * 64 + r) * 64;
-#pragma unroll
-  for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (mt < KT) v = (f32x4){acc[0][mt < KT ? mt : 0][4 * g], acc[0][mt < KT ? mt : 0][4 * g + 1],
-                                acc[0][mt < KT ? mt : 0][4 * g + 2], acc[0][mt < KT ? mt : 0][4 * g + 3]};
-      *reinterpret_cast<f32x4*>(dst + 32 * mt + 8 * g + 4 * hh) = v;
-    }
 }
 
 // Phase B: scores of the new pairs.  Eight waves, one 32-pair tile each (two waves per SIMD: the partner

@@ -1,0 +1,352 @@
+// nnj_scorer16.hpp -- the incremental NJ-step scorer on 16-token tiles (alpha for every n, scores for n <= 16;
+// measured: with 17..64 rows the group barriers of the shared score image cost more than the padding saves, there
+// the 32-pair kernels of nnj_scorer.hpp are used).
+//
+// The per-site dependency chain of the pair scorer (gate -> image -> x_g -> W_g -> mix -> s_out -> GELU) is
+// latency bound at two waves per SIMD, and the 32-token feature-major tile (32 registers per 64-feature
+// vector) leaves no room for a third.  Here a wave owns 16 pairs: lane = (pair l&15, feature quarter
+// kq = l>>4), a 64-feature vector is four f32x4 tiles, element r of tile mt = feature 16*mt + 4*kq + r -- the
+// C/D layout of v_mfma_f32_16x16x32_bf16 -- so every tensor costs 16 registers, twelve waves fit a CU
+// (three per SIMD) and a step pads its n-1 pairs to a multiple of 16 instead of 32.
+// The B operand of k-step ks (32 features) is tiles 2ks, 2ks+1: k-slot 8*kq + 4*u + r = feature
+// 32*ks + 16*u + 4*kq + r; weight images store their columns in that order (stage_weight_t16).
+// Everything is bf16x6 (nnj_common.hpp).
+#pragma once
+#include "nnj_scorer.hpp"
+
+struct V64 { f32x4 t[4]; };
+
+__device__ __forceinline__ f32x4 mfma16_bf16(u32x4 a, u32x4 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0,
+                                                 0);
+}
+__device__ __forceinline__ f32x4 mfma16_b6(const Frag3& a, const Frag3& b, f32x4 c) {
+  c = mfma16_bf16(a.l, b.h, c);
+  c = mfma16_bf16(a.h, b.l, c);
+  c = mfma16_bf16(a.m, b.m, c);
+  c = mfma16_bf16(a.m, b.h, c);
+  c = mfma16_bf16(a.h, b.m, c);
+  c = mfma16_bf16(a.h, b.h, c);
+  return c;
+}
+// eight values -> one k-step fragment (k-slot order: a[0..3], b[0..3])
+__device__ __forceinline__ void split_8(Frag3& o, const f32x4& a, const f32x4& b) {
+  unsigned h, m, l;
+  split2(a[0], a[1], h, m, l); o.h[0] = h; o.m[0] = m; o.l[0] = l;
+  split2(a[2], a[3], h, m, l); o.h[1] = h; o.m[1] = m; o.l[1] = l;
+  split2(b[0], b[1], h, m, l); o.h[2] = h; o.m[2] = m; o.l[2] = l;
+  split2(b[2], b[3], h, m, l); o.h[3] = h; o.m[3] = m; o.l[3] = l;
+}
+__device__ __forceinline__ void load_v64(V64& v, const float* p, int kq) {
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) v.t[mt] = *reinterpret_cast<const f32x4*>(p + 16 * mt + 4 * kq);
+}
+// LDS image of a [rows][64] fp32 matrix for the 16-token linears: three planes of [rows][8 chunks of 16 B],
+// chunk q = 4*ks + kg holds in-features 32ks + 16u + 4kg + r in (u, r) order, XOR-swizzled like the 32-token
+// images (a ds_read_b128 of 16 rows x 4 chunks is conflict free).
+__device__ __forceinline__ void stage_weight_t16(float* lds, const float* __restrict__ g, int rows, int tid,
+                                                 int nthreads, bool transposed = false) {
+  u32x4* img = reinterpret_cast<u32x4*>(lds);
+  const int plane = rows * 8;
+  for (int i = tid; i < rows * 8; i += nthreads) {
+    const int r = i >> 3, q = i & 7;
+    const int f0 = 32 * (q >> 2) + 4 * (q & 3);
+    f32x4 v0, v1;
+    if (!transposed) {
+      v0 = *reinterpret_cast<const f32x4*>(g + (size_t)r * 64 + f0);
+      v1 = *reinterpret_cast<const f32x4*>(g + (size_t)r * 64 + f0 + 16);
+    } else {                                               // image row r = column r of g
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { v0[e] = g[(size_t)(f0 + e) * rows + r]; v1[e] = g[(size_t)(f0 + 16 + e) * rows + r]; }
+    }
+    Frag3 f;
+    split_8(f, v0, v1);
+    const int o = r * 8 + wswz6<8>(r, q);
+    img[o] = f.h; img[plane + o] = f.m; img[2 * plane + o] = f.l;
+  }
+}
+// out (MT tiles of 16 rows) = bias + W*in or += W*in; W = a [16*MT][64] image of the layout above
+template <int MT, bool ACC>
+__device__ __forceinline__ void linear_t16(f32x4 (&out)[MT], const V64& in, const float* W, const float* bias,
+                                           int lane) {
+  const int l15 = lane & 15, kq = lane >> 4;
+  if constexpr (!ACC) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      out[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (bias) out[mt] = *reinterpret_cast<const f32x4*>(bias + 16 * mt + 4 * kq);
+    }
+  }
+  const u32x4* img = reinterpret_cast<const u32x4*>(W);
+  constexpr int PLANE = 16 * MT * 8;
+  static_for<0, 2>([&](auto ki) {
+    constexpr int ks = decltype(ki)::value;
+    Frag3 b;
+    split_8(b, in.t[2 * ks], in.t[2 * ks + 1]);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int row = 16 * mt + l15;
+      const int o = row * 8 + wswz6<8>(row, 4 * ks + kq);
+      Frag3 a;
+      a.h = img[o]; a.m = img[PLANE + o]; a.l = img[2 * PLANE + o];
+      out[mt] = mfma16_b6(a, b, out[mt]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  });
+}
+
+// barrier of the NG waves that share a site slot (LDS counter; see k_tok1p's pair_barrier)
+template <int NG>
+__device__ __forceinline__ void group_barrier_lds(int* cnt, int& epoch) {
+  epoch += NG;
+  asm volatile("" ::: "memory");
+  if ((threadIdx.x & 63) == 0) atomicAdd(cnt, 1);
+  for (int spins = 0; *reinterpret_cast<volatile int*>(cnt) < epoch && spins < (1 << 22); ++spins)
+    __builtin_amdgcn_s_sleep(1);
+  asm volatile("" ::: "memory");
+}
+
+struct Inc16 {            // per-lane description of the step: pair (m, r)
+  int r, slot_r, slot_m;
+  float sgn;              // +1 if r < m (the pair is (r, m)), -1 otherwise
+};
+__device__ __forceinline__ Inc16 inc16(const RowSet& rs, const int* ij_prev, int b, int n, int r) {
+  Inc16 L;
+  const int m = min(max(ij_prev[2 * b], 0), n - 1);
+  L.r = r;
+  L.slot_m = slot_of(rs, b, m);
+  L.slot_r = slot_of(rs, b, r < n ? r : 0);              // lanes beyond the rows read row 0 (never used)
+  L.sgn = r < m ? 1.0f : -1.0f;
+  return L;
+}
+// x = S_m + sigmoid(U_r - U_m + s*b) (S_r - S_m)   (see inc_gate)
+__device__ __forceinline__ void gate16(V64& x, const V64& sr, const V64& ur, const V64& sm, const V64& um,
+                                       const float* bh, float sgn, int kq) {
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) {
+    const f32x4 b4 = *reinterpret_cast<const f32x4*>(bh + 16 * mt + 4 * kq);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float z = sigmoidf_((ur.t[mt][e] - um.t[mt][e]) + sgn * b4[e]);
+      x.t[mt][e] = sm.t[mt][e] + z * (sr.t[mt][e] - sm.t[mt][e]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+constexpr int T16_WAVES = 12;
+
+// ------------------------------------------------------------------ k_inc_alpha16
+// alpha partials of the new pairs (see k_inc_alpha: (A^T x).S_r, K' never read).  NG waves (16 pairs each)
+// share a site: together they write its 16*NG S rows as a weight-like image [3 planes][16*NG r][64 d] (each
+// lane one 16-byte chunk per k-step and plane) and each multiplies its x' with all rows.
+// part[b][sc*NSLOT+slot][pair r][r'].
+template <int NG>
+__global__ __launch_bounds__(64 * T16_WAVES) void k_inc_alpha16(RowSet rs, ScorerW w, const int* __restrict__ ij_prev,
+                                                                float* __restrict__ alpha_part, int n, int C, int cs) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int NSLOT = T16_WAVES / NG;
+  constexpr int IMG = 16 * NG * 64 * 3 / 2;                // floats of an image
+  float* At_l = smem;                                      // A^T, 6144 floats
+  const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, kq = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int slot = wave % NSLOT, tl = wave / NSLOT;
+  float* img = smem + 6144 + slot * IMG;
+  int* cnt0 = reinterpret_cast<int*>(smem + 6144 + NSLOT * IMG);
+  const int sc = blockIdx.x, b = blockIdx.y;
+  const int c0 = sc * cs, c1 = min(C, c0 + cs);
+  stage_weight_t16(At_l, w.A, 64, tid, 64 * T16_WAVES, true);
+  if (tid < NSLOT) cnt0[tid] = 0;
+  __syncthreads();
+  int* cnt = cnt0 + slot;
+  int epoch = 0;
+  const Inc16 L = inc16(rs, ij_prev, b, n, 16 * tl + l15);
+  const size_t bo = (size_t)b * rs.bstride;
+  const float* Sr = rs.S + bo + (size_t)L.slot_r * C * 64;
+  const float* Ur = rs.U + bo + (size_t)L.slot_r * C * 64;
+  const float* Sm = rs.S + bo + (size_t)L.slot_m * C * 64;
+  const float* Um = rs.U + bo + (size_t)L.slot_m * C * 64;
+  f32x4 acc[NG];
+#pragma unroll
+  for (int mt = 0; mt < NG; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  u32x4* im4 = reinterpret_cast<u32x4*>(img);
+  constexpr int PL = 16 * NG * 8;
+  V64 sr, ur;
+  int c = c0 + slot;
+  if (c < c1) { load_v64(sr, Sr + (size_t)c * 64, kq); load_v64(ur, Ur + (size_t)c * 64, kq); }
+  for (; c < c1; c += NSLOT) {
+    asm volatile("" ::: "memory");
+    V64 x;
+    {
+      V64 sm, um;
+      load_v64(sm, Sm + (size_t)c * 64, kq);
+      load_v64(um, Um + (size_t)c * 64, kq);
+      gate16(x, sr, ur, sm, um, w.bh, L.sgn, kq);
+    }
+    if constexpr (NG > 1) group_barrier_lds<NG>(cnt, epoch);     // everyone is done with the previous image
+    // row r of the image: chunk 4*ks + kq = this lane's tiles 2ks, 2ks+1
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      Frag3 f;
+      split_8(f, sr.t[2 * ks], sr.t[2 * ks + 1]);
+      const int o = L.r * 8 + wswz6<8>(L.r, 4 * ks + kq);
+      im4[o] = f.h; im4[PL + o] = f.m; im4[2 * PL + o] = f.l;
+    }
+    if constexpr (NG > 1) group_barrier_lds<NG>(cnt, epoch);     // all rows are in the image
+    const int cn = c + NSLOT < c1 ? c + NSLOT : c;               // prefetch behind the MFMAs (last: harmless reload)
+    load_v64(sr, Sr + (size_t)cn * 64, kq);
+    load_v64(ur, Ur + (size_t)cn * 64, kq);
+    V64 xp;
+    linear_t16<4, false>(xp.t, x, At_l, nullptr, lane);          // x' = A^T x
+    linear_t16<NG, true>(acc, xp, img, nullptr, lane);           // acc[r'][pair] += S_r' . x'
+  }
+  const int part = sc * NSLOT + slot, nparts = gridDim.x * NSLOT;
+  float* dst = alpha_part + (((size_t)b * nparts + part) * 64 + L.r) * 64 + 4 * kq;
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) {
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (mt < NG) v = acc[mt < NG ? mt : 0];
+    *reinterpret_cast<f32x4*>(dst + 16 * mt) = v;
+  }
+}
+
+// ------------------------------------------------------------------ k_inc_score16
+// scores of the new pairs.  The NG waves of a site build its transposed image S^T [3 planes][64 d][16*NG r']
+// (natural r' order; A operand of x_g^T = S^T alpha^T) together, each the columns of its 16 rows.
+// part[b][sc*NSLOT+slot][pair r].
+template <int NG>
+__device__ __forceinline__ int tswz(int d, int chunk) {     // conflict-free chunk swizzle per row length
+  return NG == 4 ? chunk ^ ((d >> 1) & 7) : (NG == 2 ? chunk ^ ((-(d >> 2)) & 3) : chunk);
+}
+template <int NG, bool CTX>
+__global__ __launch_bounds__(64 * T16_WAVES) void k_inc_score16(RowSet rs, ScorerW w, const int* __restrict__ ij_prev,
+                                                                const float* __restrict__ alpha,
+                                                                const uint8_t* __restrict__ mask,
+                                                                float* __restrict__ score_part, int n, int C, int cs) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int NSLOT = T16_WAVES / NG;
+  constexpr int CH = 2 * NG;                               // 16-byte chunks per image row (8 r' each)
+  constexpr int KSX = NG == 4 ? 2 : 1;                     // k-steps of the x_g GEMM (32 r' each)
+  constexpr int IMG = 64 * 16 * NG * 3 / 2;                // floats of an image
+  float* Wg_l = smem;
+  float* S0_l = smem + 6144;
+  const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, kq = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int slot = wave % NSLOT, tl = wave / NSLOT;
+  float* img = smem + 12288 + slot * IMG;
+  int* cnt0 = reinterpret_cast<int*>(smem + 12288 + NSLOT * IMG);
+  const int sc = blockIdx.x, b = blockIdx.y;
+  const int c0 = sc * cs, c1 = min(C, c0 + cs);
+  stage_weight_t16(Wg_l, w.Wg, 64, tid, 64 * T16_WAVES);
+  stage_weight_t16(S0_l, w.S0, 64, tid, 64 * T16_WAVES);
+  if (tid < NSLOT) cnt0[tid] = 0;
+  __syncthreads();
+  int* cnt = cnt0 + slot;
+  int epoch = 0;
+  const Inc16 L = inc16(rs, ij_prev, b, n, 16 * tl + l15);
+  const size_t bo = (size_t)b * rs.bstride;
+  const float* Sr = rs.S + bo + (size_t)L.slot_r * C * 64;
+  const float* Ur = rs.U + bo + (size_t)L.slot_r * C * 64;
+  const float* Sm = rs.S + bo + (size_t)L.slot_m * C * 64;
+  const float* Um = rs.U + bo + (size_t)L.slot_m * C * 64;
+  const float* ap = alpha + ((size_t)b * 64 + L.r) * 64 + 8 * kq;
+  // column r of the image: chunk r>>3, element r&7
+  unsigned short* t16 = reinterpret_cast<unsigned short*>(img);
+  constexpr int RL = 16 * NG;                              // bf16 per image row
+  constexpr int PLH = 64 * RL;                             // plane stride in bf16
+  const int wchunk = 2 * tl + (l15 >> 3), we = l15 & 7;
+  const u32x4* im4 = reinterpret_cast<const u32x4*>(img);
+  constexpr int PL4 = 64 * CH;                             // plane stride in 16-byte units
+  float score = 0.f;
+  for (int c = c0 + slot; c < c1; c += NSLOT) {
+    asm volatile("" ::: "memory");
+    // no register prefetch of the next site: three waves per SIMD hide the row loads, and the 32 registers
+    // would push the kernel over the 168 of that occupancy
+    V64 sr, ur;
+    load_v64(sr, Sr + (size_t)c * 64, kq);
+    load_v64(ur, Ur + (size_t)c * 64, kq);
+    // alpha[pair][r'] of this lane's pair, k-slot 8kq + j of k-step ks = r' = 32ks + 8kq + j (exactly 0 beyond
+    // the live rows): issued first, it lands behind the gate and the image
+    f32x4 al[KSX][2];
+    if constexpr (CTX) {
+#pragma unroll
+      for (int ks = 0; ks < KSX; ++ks) {
+        al[ks][0] = *reinterpret_cast<const f32x4*>(ap + 32 * ks);
+        al[ks][1] = *reinterpret_cast<const f32x4*>(ap + 32 * ks + 4);
+      }
+    }
+    V64 x;
+    {
+      V64 sm, um;
+      load_v64(sm, Sm + (size_t)c * 64, kq);
+      load_v64(um, Um + (size_t)c * 64, kq);
+      gate16(x, sr, ur, sm, um, w.bh, L.sgn, kq);
+    }
+    if constexpr (CTX) {
+      if constexpr (NG > 1) group_barrier_lds<NG>(cnt, epoch);   // everyone is done with the previous image
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr) {
+          unsigned h, m, l;
+          split2(sr.t[mt][2 * pr], sr.t[mt][2 * pr + 1], h, m, l);
+          const int d0 = 16 * mt + 4 * kq + 2 * pr, d1 = d0 + 1;
+          const int o0 = d0 * RL + 8 * tswz<NG>(d0, wchunk) + we, o1 = d1 * RL + 8 * tswz<NG>(d1, wchunk) + we;
+          t16[o0] = (unsigned short)h; t16[o1] = (unsigned short)(h >> 16);
+          t16[PLH + o0] = (unsigned short)m; t16[PLH + o1] = (unsigned short)(m >> 16);
+          t16[2 * PLH + o0] = (unsigned short)l; t16[2 * PLH + o1] = (unsigned short)(l >> 16);
+          __builtin_amdgcn_sched_barrier(0);                     // bounded live ranges (three waves per SIMD: 168 registers)
+        }
+      if constexpr (NG > 1) group_barrier_lds<NG>(cnt, epoch);   // all columns are in the image
+    }
+    const float mc = (mask && mask[(size_t)b * C + c]) ? 0.f : 1.f;      // seq_mask (model.py:96)
+    if constexpr (CTX) {
+      V64 xg, g;
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) xg.t[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      static_for<0, KSX>([&](auto ki) {
+        constexpr int ks = decltype(ki)::value;
+        Frag3 bfr;
+        split_8(bfr, al[ks][0], al[ks][1]);
+        // lanes whose chunk lies beyond a short row read the row's last chunk instead: finite data against
+        // alpha values that are exactly 0
+        const int lc = min(4 * ks + kq, CH - 1);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+          const int d = 16 * mt + l15;
+          const int o = d * CH + tswz<NG>(d, lc);
+          Frag3 a;
+          a.h = im4[o]; a.m = im4[PL4 + o]; a.l = im4[2 * PL4 + o];
+          xg.t[mt] = mfma16_b6(a, bfr, xg.t[mt]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      });
+      linear_t16<4, false>(g.t, xg, Wg_l, w.bg, lane);
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float wg = sigmoidf_(g.t[mt][e]);
+          x.t[mt][e] += wg * (xg.t[mt][e] - x.t[mt][e]);          // (1-w)*x + w*x_g
+          if (e == 3) __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    V64 s1;
+    linear_t16<4, false>(s1.t, x, S0_l, w.s0, lane);
+    float s = 0.f;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      const f32x4 w4 = *reinterpret_cast<const f32x4*>(w.s2w + 16 * mt + 4 * kq);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) s += gelu_erf(s1.t[mt][e]) * w4[e];
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    s += __shfl_xor(s, 16);
+    s += __shfl_xor(s, 32);
+    score += (s + w.s2b) * mc;
+  }
+  if (kq == 0) {
+    const int part = sc * NSLOT + slot, nparts = gridDim.x * NSLOT;
+    score_part[((size_t)b * nparts + part) * 64 + L.r] = score;
+  }
+}
