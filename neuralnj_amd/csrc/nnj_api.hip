@@ -162,8 +162,8 @@ PairGeom pair_geom(int mode, int n, int B, int C) {
     // partial sets = one per site slot of a workgroup.  alpha: 16-row tiles, 12 waves / (1, 2 or 4 tiles that
     // share a site).  scores: the same for n <= 16; above, the 32-row kernels (8 slots, or 4 pairs of waves)
     g.blocks = blocks;
-    g.nsc_a = blocks * (T16_WAVES / (n > 32 ? 4 : (n > 16 ? 2 : 1)));
-    g.nsc = n <= 16 ? g.nsc_a : blocks * (n > 32 ? 4 : 8);
+    g.nsc_a = blocks * (T16_WAVES / (n > 48 ? 4 : (n > 32 ? 3 : (n > 16 ? 2 : 1))));
+    g.nsc = n <= 16 ? g.nsc_a : blocks * (n > 32 ? 4 : 8);       // (4 also for the 3-wave 16-row variant: 12 / 3)
     return g;
   }
   g.npairs = mode == PAIRS_FULL ? n * (n - 1) / 2 : n;
@@ -196,7 +196,7 @@ LoopWs loop_ws(int B, int T, int C) {
   w.beta = take((size_t)B * T * nt32);
   size_t ap = 0, al = 0, sp = 0;
   for (int mode = 0; mode < 2; ++mode)
-    for (int n : {T, std::min(T, 32), std::min(T, 16)}) {      // the incremental geometry changes at n = 32 and 16
+    for (int n : {T, std::min(T, 48), std::min(T, 32), std::min(T, 16)}) {      // the incremental geometry changes at n = 48, 32 and 16
       if (n < 2) continue;
       PairGeom g = pair_geom(mode, n, B, C);
       ap = std::max(ap, (size_t)B * g.nsc_a * g.ppad * 64);
@@ -374,7 +374,7 @@ int launch_pair_scores(nnj_handle* h, const RowSet& rs, const int* ij_prev, cons
   const ScorerW sw = scorer_ptrs(h);
   const int has_ctx = n > 2 ? 1 : 0;
   if (mode == PAIRS_INCR) {
-    const int ng = n > 32 ? 4 : (n > 16 ? 2 : 1);          // 16-row tiles (= waves) that share a site
+    const int ng = n > 48 ? 4 : (n > 32 ? 3 : (n > 16 ? 2 : 1));          // 16-row tiles (= waves) that share a site
     const dim3 grid((unsigned)g.blocks, (unsigned)B);
     const dim3 blk16(64 * T16_WAVES);
     if (has_ctx) {
@@ -386,7 +386,7 @@ int launch_pair_scores(nnj_handle* h, const RowSet& rs, const int* ij_prev, cons
     if (int rc = set_lds(h, k_inc_alpha16<NG>, lds)) return rc;                                             \
     hipLaunchKernelGGL((k_inc_alpha16<NG>), grid, blk16, lds, st, rs, sw, ij_prev, base + w.alpha_part, n, C, g.cs); \
     break;
-        switch (ng) { NNJ_IA(1) NNJ_IA(2) NNJ_IA(4) }
+        switch (ng) { NNJ_IA(1) NNJ_IA(2) NNJ_IA(3) NNJ_IA(4) }
 #undef NNJ_IA
       }
       {
@@ -410,6 +410,11 @@ int launch_pair_scores(nnj_handle* h, const RowSet& rs, const int* ij_prev, cons
           hipLaunchKernelGGL((k_inc_score16<1, false>), grid, blk16, lds, st, rs, sw, ij_prev, base + w.alpha, mask,
                              base + w.score_part, n, C, g.cs);
         }
+      } else if (n > 32 && n <= 48) {                      // three 16-row tiles: 48 instead of 64 padded pairs
+        const size_t lds = (size_t)(12288 + 4 * 6144 + 16) * sizeof(float);
+        if (int rc = set_lds(h, k_inc_score16<3, true>, lds)) return rc;
+        hipLaunchKernelGGL((k_inc_score16<3, true>), grid, blk16, lds, st, rs, sw, ij_prev, base + w.alpha, mask,
+                           base + w.score_part, n, C, g.cs);
       } else if (n > 32) {
         const size_t lds = (size_t)(2 * b6_floats(64, 64) + 4 * b6_floats(64, 64) + 16) * sizeof(float);
         if (int rc = set_lds(h, k_inc_score<2, true>, lds)) return rc;

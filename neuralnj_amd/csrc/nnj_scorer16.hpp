@@ -1,6 +1,7 @@
-// nnj_scorer16.hpp -- the incremental NJ-step scorer on 16-token tiles (alpha for every n, scores for n <= 16;
-// measured: with 17..64 rows the group barriers of the shared score image cost more than the padding saves, there
-// the 32-pair kernels of nnj_scorer.hpp are used).
+// nnj_scorer16.hpp -- the incremental NJ-step scorer on 16-token tiles: alpha for every n; scores for n <= 16
+// and for 33..48 rows (three tiles = 48 instead of 64 padded pairs).  Measured: with 17..32 and 49..64 rows the
+// group barriers of the shared score image cost more than the padding saves; there the 32-pair kernels of
+// nnj_scorer.hpp are used.
 //
 // The per-site dependency chain of the pair scorer (gate -> image -> x_g -> W_g -> mix -> s_out -> GELU) is
 // latency bound at two waves per SIMD, and the 32-token feature-major tile (32 registers per 64-feature
@@ -214,9 +215,9 @@ __global__ __launch_bounds__(64 * T16_WAVES) void k_inc_alpha16(RowSet rs, Score
 // scores of the new pairs.  The NG waves of a site build its transposed image S^T [3 planes][64 d][16*NG r']
 // (natural r' order; A operand of x_g^T = S^T alpha^T) together, each the columns of its 16 rows.
 // part[b][sc*NSLOT+slot][pair r].
-template <int NG>
+template <int NC>                                           // NC = 16-column groups of an image row (1, 2 or 4)
 __device__ __forceinline__ int tswz(int d, int chunk) {     // conflict-free chunk swizzle per row length
-  return NG == 4 ? chunk ^ ((d >> 1) & 7) : (NG == 2 ? chunk ^ ((-(d >> 2)) & 3) : chunk);
+  return NC == 4 ? chunk ^ ((d >> 1) & 7) : (NC == 2 ? chunk ^ ((-(d >> 2)) & 3) : chunk);
 }
 template <int NG, bool CTX>
 __global__ __launch_bounds__(64 * T16_WAVES) void k_inc_score16(RowSet rs, ScorerW w, const int* __restrict__ ij_prev,
@@ -225,9 +226,10 @@ __global__ __launch_bounds__(64 * T16_WAVES) void k_inc_score16(RowSet rs, Score
                                                                 float* __restrict__ score_part, int n, int C, int cs) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int NSLOT = T16_WAVES / NG;
-  constexpr int CH = 2 * NG;                               // 16-byte chunks per image row (8 r' each)
-  constexpr int KSX = NG == 4 ? 2 : 1;                     // k-steps of the x_g GEMM (32 r' each)
-  constexpr int IMG = 64 * 16 * NG * 3 / 2;                // floats of an image
+  constexpr int NC = NG == 3 ? 4 : NG;                     // image geometry: 16*NC columns (3 waves use the 64-column one)
+  constexpr int CH = 2 * NC;                               // 16-byte chunks per image row (8 r' each)
+  constexpr int KSX = NC == 4 ? 2 : 1;                     // k-steps of the x_g GEMM (32 r' each)
+  constexpr int IMG = 64 * 16 * NC * 3 / 2;                // floats of an image
   float* Wg_l = smem;
   float* S0_l = smem + 6144;
   const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, kq = lane >> 4;
@@ -240,6 +242,9 @@ __global__ __launch_bounds__(64 * T16_WAVES) void k_inc_score16(RowSet rs, Score
   stage_weight_t16(Wg_l, w.Wg, 64, tid, 64 * T16_WAVES);
   stage_weight_t16(S0_l, w.S0, 64, tid, 64 * T16_WAVES);
   if (tid < NSLOT) cnt0[tid] = 0;
+  if constexpr (NG == 3) {                                 // columns 48..63 are never written: they meet alpha = 0 but must be finite
+    for (int i = tid; i < NSLOT * IMG; i += 64 * T16_WAVES) smem[12288 + i] = 0.f;
+  }
   __syncthreads();
   int* cnt = cnt0 + slot;
   int epoch = 0;
@@ -252,7 +257,7 @@ __global__ __launch_bounds__(64 * T16_WAVES) void k_inc_score16(RowSet rs, Score
   const float* ap = alpha + ((size_t)b * 64 + L.r) * 64 + 8 * kq;
   // column r of the image: chunk r>>3, element r&7
   unsigned short* t16 = reinterpret_cast<unsigned short*>(img);
-  constexpr int RL = 16 * NG;                              // bf16 per image row
+  constexpr int RL = 16 * NC;                              // bf16 per image row
   constexpr int PLH = 64 * RL;                             // plane stride in bf16
   const int wchunk = 2 * tl + (l15 >> 3), we = l15 & 7;
   const u32x4* im4 = reinterpret_cast<const u32x4*>(img);
@@ -291,7 +296,7 @@ __global__ __launch_bounds__(64 * T16_WAVES) void k_inc_score16(RowSet rs, Score
           unsigned h, m, l;
           split2(sr.t[mt][2 * pr], sr.t[mt][2 * pr + 1], h, m, l);
           const int d0 = 16 * mt + 4 * kq + 2 * pr, d1 = d0 + 1;
-          const int o0 = d0 * RL + 8 * tswz<NG>(d0, wchunk) + we, o1 = d1 * RL + 8 * tswz<NG>(d1, wchunk) + we;
+          const int o0 = d0 * RL + 8 * tswz<NC>(d0, wchunk) + we, o1 = d1 * RL + 8 * tswz<NC>(d1, wchunk) + we;
           t16[o0] = (unsigned short)h; t16[o1] = (unsigned short)(h >> 16);
           t16[PLH + o0] = (unsigned short)m; t16[PLH + o1] = (unsigned short)(m >> 16);
           t16[2 * PLH + o0] = (unsigned short)l; t16[2 * PLH + o1] = (unsigned short)(l >> 16);
@@ -314,7 +319,7 @@ __global__ __launch_bounds__(64 * T16_WAVES) void k_inc_score16(RowSet rs, Score
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
           const int d = 16 * mt + l15;
-          const int o = d * CH + tswz<NG>(d, lc);
+          const int o = d * CH + tswz<NC>(d, lc);
           Frag3 a;
           a.h = im4[o]; a.m = im4[PL4 + o]; a.l = im4[2 * PL4 + o];
           xg.t[mt] = mfma16_b6(a, bfr, xg.t[mt]);
