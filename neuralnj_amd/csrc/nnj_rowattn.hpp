@@ -99,17 +99,30 @@ __global__ __launch_bounds__(512) void k_qkv6(const float* __restrict__ x, const
   const int lam = lane & 31, c16 = lam & 15, rr = lam >> 4;
   const unsigned sel = (lane & 1) ? 0x03020706u : 0x05040100u;      // see the 4x4 transpose below
   const bool bit1 = (lane >> 1) & 1;
+  // token address of this lane in group g_ (tokens outside the alignment read token (0,0) of the batch element)
+  auto tok_addr = [&](int g_) {
+    const int b_ = g_ / groups_per_b;
+    const int tile_ = min((g_ % groups_per_b) * 8 + wave, tiles_per_b - 1);
+    const int r_ = 2 * (tile_ / CB) + rr, c_ = 16 * (tile_ % CB) + c16;
+    const bool v_ = r_ < R && c_ < C;
+    return x + (((size_t)b_ * R + (v_ ? r_ : 0)) * C + (v_ ? c_ : 0)) * 64;
+  };
+  f32x16 xr[2];
+  if ((int)blockIdx.x < ngroups) load_token64(xr, tok_addr(blockIdx.x), true, hh);
   for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
     const int b = grp / groups_per_b;
     const int tile = (grp % groups_per_b) * 8 + wave;
-    if (tile >= tiles_per_b) continue;                               // wave-uniform
+    const bool tile_ok = tile < tiles_per_b;                         // wave-uniform
     const int rp = tile / CB, cb = tile % CB;
     const int r = 2 * rp + rr, c = 16 * cb + c16;
-    const bool valid = r < R && c < C;
+    const bool valid = tile_ok && r < R && c < C;
     asm volatile("" ::: "memory");      // keep the parameter loads inside the loop (see k_ffn)
-    f32x16 xr[2], y[1][2], o[1][6];
-    load_token64(xr, x + (((size_t)b * R + (valid ? r : 0)) * C + (valid ? c : 0)) * 64, valid, hh);
+    f32x16 y[1][2], o[1][6];
     layer_norm64(y[0], xr, wn.ln_w, wn.ln_b, hh);
+    // the next group's tokens go into the registers LayerNorm has just consumed: their HBM latency runs
+    // behind the GEMM and the stores
+    if (grp + (int)gridDim.x < ngroups) load_token64(xr, tok_addr(grp + gridDim.x), true, hh);
+    if (!tile_ok) continue;
     const bool padded = mask && valid && mask[(size_t)b * C + c];
     const float qscale = padded ? 0.0f : qs;
     linear6_T_nb<6, 2, 1>(o, y, Wl, lane);
