@@ -339,10 +339,10 @@ int launch_encoder(nnj_handle* h, const uint8_t* codes, const float* onehot, con
         const int groups_per_b = (T * C + 255) / 256;
         const long ngroups = (long)groups_per_b * B;
         const unsigned grid = (unsigned)std::min<long>(ngroups, h->num_cu);
-        const size_t lds_ffn = (size_t)(b6_floats(128, 64) + b6_floats(64, 128)) * sizeof(float);
-        if (int rc = set_lds(h, k_ffn, lds_ffn)) return rc;
+        const size_t lds_ffn = (size_t)4 * 6144 * sizeof(float);
         // ctx (consumed by k_tok1 above, B*8*C*Epad >= B*T*C*64 floats) is the scratch of the two-pass FFN
-        hipLaunchKernelGGL(k_ffn, dim3(grid), dim3(512), lds_ffn, st, x, ctx, ffn_ptrs(h, h->lo[l]), B, T, C, groups_per_b);
+        if (int rc = set_lds(h, k_ffn16, lds_ffn)) return rc;
+        hipLaunchKernelGGL(k_ffn16, dim3(grid), dim3(1024), lds_ffn, st, x, ctx, ffn_ptrs(h, h->lo[l]), B, T, C, groups_per_b);
       }
     }
   }

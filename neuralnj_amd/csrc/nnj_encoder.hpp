@@ -2,12 +2,12 @@
 // (restates reference model.py:67-88, msa_modules.py:62-151, axial_attention.py:6-255).
 //
 // Tiling of the token-local stages: one wave owns one alignment column (b, c) and all R rows of it
-// ("column wave", tokens = rows, NT = ceil(R/32) tiles of 32 tokens on the lanes), or -- k_ffn -- 32 tokens
+// ("column wave", tokens = rows, NT = ceil(R/32) tiles of 32 tokens on the lanes), or -- k_ffn16 -- 16 tokens
 // of a flat (column, row) order.  Token-local stages chain in registers (nnj_common.hpp); weights sit in LDS.
 //
 //   k_embed     : embed (6-entry LUT of the site codes, or the embed MLP on float input) -> x
 //   k_tok1/1p   : ctx -> out_proj -> +x ; LN -> q,k,v -> column attention -> out_proj -> +x
-//   k_ffn       : LN -> fc1 -> GELU -> fc2 -> +x   (persistent, flat token tiling, bf16x6)
+//   k_ffn16     : LN -> fc1 -> GELU -> fc2 -> +x   (persistent, flat token tiling, 16-token tiles, bf16x6)
 // The tied row attention (q,k,v projections, scores, context) lives in nnj_rowattn.hpp.
 //
 // HBM layouts: x [B,R,C,64]; ctx head-major [B,8,C,Epad] with e = r*8 + d, Epad = roundup(R*8,16).
@@ -111,7 +111,7 @@ __global__ __launch_bounds__(256) void k_tok1(const float* __restrict__ ctx, con
   const int tok = lane & 31, hh = lane >> 5;
   const long ncols = (long)B * C;
   for (long col = (long)blockIdx.x * 4 + wave; col < ncols; col += (long)gridDim.x * 4) {
-  asm volatile("" ::: "memory");            // keep bias / LayerNorm parameter loads inside the loop (see k_ffn)
+  asm volatile("" ::: "memory");            // keep bias / LayerNorm parameter loads inside the loop (hoisted, they would occupy ~200 VGPRs)
   const int b = (int)(col / C), c = (int)(col % C);
   const bool padded = mask && mask[(size_t)b * C + c];
 
@@ -301,7 +301,7 @@ __global__ __launch_bounds__(512) void k_tok1p(const float* __restrict__ ctx, co
   const long ncols = (long)B * C;
   const float scaling = rsqrtf((float)NNJ_DH);         // axial_attention.py:214
   for (long col = (long)blockIdx.x * 4 + slot; col < ncols; col += (long)gridDim.x * 4) {
-    asm volatile("" ::: "memory");                      // keep parameter loads inside the loop (see k_ffn)
+    asm volatile("" ::: "memory");                      // keep parameter loads inside the loop (hoisted, they would occupy ~200 VGPRs)
     const int b = (int)(col / C), c = (int)(col % C);
     const bool padded = mask && mask[(size_t)b * C + c];
     float* xp = x + (((size_t)b * R + (valid ? r : 0)) * C + c) * 64;
@@ -404,35 +404,35 @@ __global__ __launch_bounds__(512) void k_tok1p(const float* __restrict__ ctx, co
   }
 }
 
-// ------------------------------------------------------------------ persistent token kernels
-// One workgroup per CU, weights staged into LDS ONCE, then a loop over 256-token groups (flat
-// (column,row) token order, 8 waves x 32 tokens, two waves per SIMD) with the next group's tokens
-// prefetched behind the MFMAs.  No barrier inside the loop.  (The per-group weight re-staging of a
+// ------------------------------------------------------------------ k_ffn16 (persistent)
+// One workgroup per CU, weights staged into LDS once per pass, then a loop over 256-token groups (flat
+// (column,row) token order).  No barrier inside the loop.  (The per-group weight re-staging of a
 // non-persistent kernel moved 2.7x more bytes than the activations themselves.)
-//   k_ffn : LN -> fc1 -> GELU -> fc2 -> +x            LDS 128 KiB: W1 [256][64] | W2 [64][256]
 __device__ __forceinline__ void flat_token(int t, int R, int C, int& c, int& r, bool& valid) {
   valid = t < R * C;
   c = valid ? t / R : 0;
   r = valid ? t - c * R : 0;
 }
 
-__global__ __launch_bounds__(512) void k_ffn(float* __restrict__ x, float* __restrict__ tmp, FfnW wf, int B, int R,
-                                             int C, int groups_per_b) {
-  // bf16x6 images of the two weight matrices take 192 KiB, more than the LDS: the hidden layer is done in
-  // two halves, each one pass of this workgroup over ITS token groups with the half's weights resident
-  // (W1 rows [128p,128p+128) | W2 columns [128p,128p+128): 96 KiB).  Pass 0 leaves b2 + W2a gelu(..) in
-  // `tmp` (same token layout as x; every lane re-reads only what it wrote itself), pass 1 adds the other
-  // half and the residual.  The additions happen in the same order as in a single pass.
+// FFN on 16-token tiles: 16 waves x 16 tokens = 256-token groups, 16 registers per tensor, four waves per SIMD
+// (<= 128 registers): the LayerNorm -> fc1 -> GELU -> fc2 chain of one wave is latency bound, the other three
+// fill its gaps (no register prefetch needed).  bf16x6 images of the two weight matrices take 192 KiB, more than
+// the LDS: the hidden layer is done in two halves, each one pass of this workgroup over ITS token groups with the
+// half's weights resident (W1 rows [128p,128p+128) | W2 columns [128p,128p+128): 96 KiB).  Pass 0 leaves
+// b2 + W2a gelu(..) in `tmp` (same token layout as x; every lane re-reads only what it wrote itself), pass 1
+// adds the other half and the residual.
+__global__ __launch_bounds__(1024) void k_ffn16(float* __restrict__ x, float* __restrict__ tmp, FfnW wf, int B, int R,
+                                                int C, int groups_per_b) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* W1l = smem;                         // two [64][64] images (hidden units 64q..64q+63 of the half)
-  float* W2l = smem + 2 * b6_floats(64, 64); // two [64][64] images
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5;
+  float* W2l = smem + 2 * 6144;              // two [64][64] images
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, kq = lane >> 4;
   const int ngroups = groups_per_b * B;
   if ((int)blockIdx.x >= ngroups) return;
   int c, r; bool valid;
   auto addr = [&](int g_) {
     const int b = g_ / groups_per_b;
-    flat_token(((g_ % groups_per_b) * 8 + wave) * 32 + (lane & 31), R, C, c, r, valid);
+    flat_token(((g_ % groups_per_b) * 16 + wave) * 16 + l15, R, C, c, r, valid);
     return (((size_t)b * R + r) * C + c) * 64;
   };
   static_for<0, 2>([&](auto pi) {
@@ -440,55 +440,49 @@ __global__ __launch_bounds__(512) void k_ffn(float* __restrict__ x, float* __res
     if (pass) __syncthreads();               // everyone is done with the first half's images
 #pragma unroll
     for (int q = 0; q < 2; ++q) {              // four [64][64] images: W1 rows / W2 columns 128*pass + 64*q ..
-      stage_weight_b6<64>(W1l + q * b6_floats(64, 64), wf.W1 + (size_t)(pass * 128 + q * 64) * 64, 64, tid, 512);
-      stage_weight_b6<64, 256>(W2l + q * b6_floats(64, 64), wf.W2, 64, tid, 512, 0, 0, 128 * pass + 64 * q);
+      stage_weight_t16(W1l + q * 6144, wf.W1 + (size_t)(pass * 128 + q * 64) * 64, 64, tid, 1024);
+      stage_weight_t16(W2l + q * 6144, wf.W2, 64, tid, 1024, false, 256, 128 * pass + 64 * q);
     }
     __syncthreads();
-    // No register prefetch of the next group: with the bf16x6 fragments next to the hidden tile it would
-    // spill, and a spilled prefetch is waited for at once.  Two waves per SIMD: one computes while the
-    // other waits for its tokens.
     for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
       const size_t xo = addr(grp);
       const bool cur_valid = valid;
-      // compiler memory barrier: keeps the loop-invariant bias / LayerNorm parameter loads INSIDE the loop
-      // (hoisted, they would occupy ~200 VGPRs for the whole kernel and spill)
-      asm volatile("" ::: "memory");
-      f32x16 y[1][2], out[1][2];
+      asm volatile("" ::: "memory");          // keep the parameter loads inside the loop (hoisted, they would occupy ~200 VGPRs)
+      V64 y, out;
       {
-        f32x16 xr[2];
-        load_token64(xr, x + xo, cur_valid, hh);
-        layer_norm64(y[0], xr, wf.ln_w, wf.ln_b, hh);
+        V64 xr;
+        load_v64(xr, x + xo, kq);
+        layer_norm_v64(y, xr, wf.ln_w, wf.ln_b, kq);
       }
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
-          if (!pass) b4 = *reinterpret_cast<const f32x4*>(wf.b2 + 32 * mt + 8 * g + 4 * hh);
-          out[0][mt][4 * g] = b4[0]; out[0][mt][4 * g + 1] = b4[1]; out[0][mt][4 * g + 2] = b4[2]; out[0][mt][4 * g + 3] = b4[3];
-        }
+      for (int mt = 0; mt < 4; ++mt) {
+        out.t[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (!pass) out.t[mt] = *reinterpret_cast<const f32x4*>(wf.b2 + 16 * mt + 4 * kq);
+      }
 #pragma unroll
       for (int q = 0; q < 2; ++q) {              // 64 hidden units at a time
-        f32x16 hdn[1][2];
-        linear6_T<2, 2, 1>(hdn, y, W1l + q * b6_floats(64, 64), wf.b1 + pass * 128 + q * 64, lane);
+        V64 hdn;
+        linear_t16<4, false>(hdn.t, y, W1l + q * 6144, wf.b1 + pass * 128 + q * 64, lane);
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
+        for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-          for (int k = 0; k < 16; ++k) hdn[0][mt][k] = gelu_erf(hdn[0][mt][k]);
-        linear6_T_acc<2, 2, 1>(out, hdn, W2l + q * b6_floats(64, 64), lane);
+          for (int e = 0; e < 4; ++e) hdn.t[mt][e] = gelu_erf(hdn.t[mt][e]);
+        linear_t16<4, true>(out.t, hdn, W2l + q * 6144, nullptr, lane);
       }
+      if (!cur_valid) continue;
       if (pass) {
-        // x + (first half + second half): the token (L2) and the first half's sum are re-read here rather
-        // than kept in 64 registers through the GEMMs
-        f32x16 xo_[2], t0[2];
-        load_token64(xo_, x + xo, cur_valid, hh);
-        load_token64(t0, tmp + xo, cur_valid, hh);
+        // x + (first half + second half): the token (L2) and the first half's sum are re-read here
+        V64 xo_, t0;
+        load_v64(xo_, x + xo, kq);
+        load_v64(t0, tmp + xo, kq);
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) xo_[mt] += t0[mt] + out[0][mt];
-        store_token64(xo_, x + xo, cur_valid, hh);
+        for (int mt = 0; mt < 4; ++mt)
+          *reinterpret_cast<f32x4*>(x + xo + 16 * mt + 4 * kq) = xo_.t[mt] + (t0.t[mt] + out.t[mt]);
       } else {
-        store_token64(out[0], tmp + xo, cur_valid, hh);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) *reinterpret_cast<f32x4*>(tmp + xo + 16 * mt + 4 * kq) = out.t[mt];
       }
     }
   });
 }
+

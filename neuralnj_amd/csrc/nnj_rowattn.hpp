@@ -116,7 +116,7 @@ __global__ __launch_bounds__(512) void k_qkv6(const float* __restrict__ x, const
     const int rp = tile / CB, cb = tile % CB;
     const int r = 2 * rp + rr, c = 16 * cb + c16;
     const bool valid = tile_ok && r < R && c < C;
-    asm volatile("" ::: "memory");      // keep the parameter loads inside the loop (see k_ffn)
+    asm volatile("" ::: "memory");      // keep the parameter loads inside the loop (hoisted, they would occupy ~200 VGPRs)
     f32x16 y[1][2], o[1][6];
     layer_norm64(y[0], xr, wn.ln_w, wn.ln_b, hh);
     // the next group's tokens go into the registers LayerNorm has just consumed: their HBM latency runs

@@ -15,87 +15,6 @@
 #pragma once
 #include "nnj_scorer.hpp"
 
-struct V64 { f32x4 t[4]; };
-
-__device__ __forceinline__ f32x4 mfma16_bf16(u32x4 a, u32x4 b, f32x4 c) {
-  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0,
-                                                 0);
-}
-__device__ __forceinline__ f32x4 mfma16_b6(const Frag3& a, const Frag3& b, f32x4 c) {
-  c = mfma16_bf16(a.l, b.h, c);
-  c = mfma16_bf16(a.h, b.l, c);
-  c = mfma16_bf16(a.m, b.m, c);
-  c = mfma16_bf16(a.m, b.h, c);
-  c = mfma16_bf16(a.h, b.m, c);
-  c = mfma16_bf16(a.h, b.h, c);
-  return c;
-}
-// eight values -> one k-step fragment (k-slot order: a[0..3], b[0..3])
-__device__ __forceinline__ void split_8(Frag3& o, const f32x4& a, const f32x4& b) {
-  unsigned h, m, l;
-  split2(a[0], a[1], h, m, l); o.h[0] = h; o.m[0] = m; o.l[0] = l;
-  split2(a[2], a[3], h, m, l); o.h[1] = h; o.m[1] = m; o.l[1] = l;
-  split2(b[0], b[1], h, m, l); o.h[2] = h; o.m[2] = m; o.l[2] = l;
-  split2(b[2], b[3], h, m, l); o.h[3] = h; o.m[3] = m; o.l[3] = l;
-}
-__device__ __forceinline__ void load_v64(V64& v, const float* p, int kq) {
-#pragma unroll
-  for (int mt = 0; mt < 4; ++mt) v.t[mt] = *reinterpret_cast<const f32x4*>(p + 16 * mt + 4 * kq);
-}
-// LDS image of a [rows][64] fp32 matrix for the 16-token linears: three planes of [rows][8 chunks of 16 B],
-// chunk q = 4*ks + kg holds in-features 32ks + 16u + 4kg + r in (u, r) order, XOR-swizzled like the 32-token
-// images (a ds_read_b128 of 16 rows x 4 chunks is conflict free).
-__device__ __forceinline__ void stage_weight_t16(float* lds, const float* __restrict__ g, int rows, int tid,
-                                                 int nthreads, bool transposed = false) {
-  u32x4* img = reinterpret_cast<u32x4*>(lds);
-  const int plane = rows * 8;
-  for (int i = tid; i < rows * 8; i += nthreads) {
-    const int r = i >> 3, q = i & 7;
-    const int f0 = 32 * (q >> 2) + 4 * (q & 3);
-    f32x4 v0, v1;
-    if (!transposed) {
-      v0 = *reinterpret_cast<const f32x4*>(g + (size_t)r * 64 + f0);
-      v1 = *reinterpret_cast<const f32x4*>(g + (size_t)r * 64 + f0 + 16);
-    } else {                                               // image row r = column r of g
-#pragma unroll
-      for (int e = 0; e < 4; ++e) { v0[e] = g[(size_t)(f0 + e) * rows + r]; v1[e] = g[(size_t)(f0 + 16 + e) * rows + r]; }
-    }
-    Frag3 f;
-    split_8(f, v0, v1);
-    const int o = r * 8 + wswz6<8>(r, q);
-    img[o] = f.h; img[plane + o] = f.m; img[2 * plane + o] = f.l;
-  }
-}
-// out (MT tiles of 16 rows) = bias + W*in or += W*in; W = a [16*MT][64] image of the layout above
-template <int MT, bool ACC>
-__device__ __forceinline__ void linear_t16(f32x4 (&out)[MT], const V64& in, const float* W, const float* bias,
-                                           int lane) {
-  const int l15 = lane & 15, kq = lane >> 4;
-  if constexpr (!ACC) {
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-      out[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      if (bias) out[mt] = *reinterpret_cast<const f32x4*>(bias + 16 * mt + 4 * kq);
-    }
-  }
-  const u32x4* img = reinterpret_cast<const u32x4*>(W);
-  constexpr int PLANE = 16 * MT * 8;
-  static_for<0, 2>([&](auto ki) {
-    constexpr int ks = decltype(ki)::value;
-    Frag3 b;
-    split_8(b, in.t[2 * ks], in.t[2 * ks + 1]);
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-      const int row = 16 * mt + l15;
-      const int o = row * 8 + wswz6<8>(row, 4 * ks + kq);
-      Frag3 a;
-      a.h = img[o]; a.m = img[PLANE + o]; a.l = img[2 * PLANE + o];
-      out[mt] = mfma16_b6(a, b, out[mt]);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-  });
-}
-
 // barrier of the NG waves that share a site slot (LDS counter; see k_tok1p's pair_barrier)
 template <int NG>
 __device__ __forceinline__ void group_barrier_lds(int* cnt, int& epoch) {
