@@ -155,18 +155,14 @@ __global__ __launch_bounds__(64 * T16_WAVES) void k_inc_score16(RowSet rs, Score
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int slot = wave % NSLOT, tl = wave / NSLOT;
   float* img = smem + 12288 + slot * IMG;
-  int* cnt0 = reinterpret_cast<int*>(smem + 12288 + NSLOT * IMG);
   const int sc = blockIdx.x, b = blockIdx.y;
   const int c0 = sc * cs, c1 = min(C, c0 + cs);
   stage_weight_t16(Wg_l, w.Wg, 64, tid, 64 * T16_WAVES);
   stage_weight_t16(S0_l, w.S0, 64, tid, 64 * T16_WAVES);
-  if (tid < NSLOT) cnt0[tid] = 0;
   if constexpr (NG == 3) {                                 // columns 48..63 are never written: they meet alpha = 0 but must be finite
     for (int i = tid; i < NSLOT * IMG; i += 64 * T16_WAVES) smem[12288 + i] = 0.f;
   }
   __syncthreads();
-  int* cnt = cnt0 + slot;
-  int epoch = 0;
   const Inc16 L = inc16(rs, ij_prev, b, n, 16 * tl + l15);
   const size_t bo = (size_t)b * rs.bstride;
   const float* Sr = rs.S + bo + (size_t)L.slot_r * C * 64;
@@ -182,8 +178,13 @@ __global__ __launch_bounds__(64 * T16_WAVES) void k_inc_score16(RowSet rs, Score
   const u32x4* im4 = reinterpret_cast<const u32x4*>(img);
   constexpr int PL4 = 64 * CH;                             // plane stride in 16-byte units
   float score = 0.f;
-  for (int c = c0 + slot; c < c1; c += NSLOT) {
+  // the waves that share an image meet at WORKGROUP barriers (measured faster here than LDS-counter group
+  // barriers): every wave runs the same number of iterations, the surplus ones on the last site with weight 0
+  const int c_end = NG > 1 ? c0 + (c1 - c0 + NSLOT - 1) / NSLOT * NSLOT : c1;
+  for (int c_ = c0 + slot; c_ < c_end; c_ += NSLOT) {
     asm volatile("" ::: "memory");
+    const bool act = c_ < c1;
+    const int c = act ? c_ : c1 - 1;
     // no register prefetch of the next site: three waves per SIMD hide the row loads, and the 32 registers
     // would push the kernel over the 168 of that occupancy
     V64 sr, ur;
@@ -207,7 +208,7 @@ __global__ __launch_bounds__(64 * T16_WAVES) void k_inc_score16(RowSet rs, Score
       gate16(x, sr, ur, sm, um, w.bh, L.sgn, kq);
     }
     if constexpr (CTX) {
-      if constexpr (NG > 1) group_barrier_lds<NG>(cnt, epoch);   // everyone is done with the previous image
+      if constexpr (NG > 1) __syncthreads();                     // everyone is done with the previous image
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
@@ -221,9 +222,9 @@ __global__ __launch_bounds__(64 * T16_WAVES) void k_inc_score16(RowSet rs, Score
           t16[2 * PLH + o0] = (unsigned short)l; t16[2 * PLH + o1] = (unsigned short)(l >> 16);
           __builtin_amdgcn_sched_barrier(0);                     // bounded live ranges (three waves per SIMD: 168 registers)
         }
-      if constexpr (NG > 1) group_barrier_lds<NG>(cnt, epoch);   // all columns are in the image
+      if constexpr (NG > 1) __syncthreads();                     // all columns are in the image
     }
-    const float mc = (mask && mask[(size_t)b * C + c]) ? 0.f : 1.f;      // seq_mask (model.py:96)
+    const float mc = (!act || (mask && mask[(size_t)b * C + c])) ? 0.f : 1.f;      // seq_mask (model.py:96)
     if constexpr (CTX) {
       V64 xg, g;
 #pragma unroll
