@@ -303,7 +303,7 @@ int launch_encoder(nnj_handle* h, const uint8_t* codes, const float* onehot, con
       const unsigned grid = (unsigned)((nbh + 7) / 8 * 8 * (g6.Cp / 128));
 #define NNJ_PV_CASE(N)                                                                                   \
   case N: {                                                                                              \
-    const size_t lds = (size_t)3 * ((N * 3072 + 4095) / 4096 * 4096);                                   \
+    const size_t stg = (N * 3072 + 4095) / 4096 * 4096, lds = (4 * stg <= 163840 ? 4 : 3) * stg;        \
     if (int rc = set_lds(h, k_row_pv<N>, lds)) return rc;                                                \
     hipLaunchKernelGGL(k_row_pv<N>, dim3(grid), dim3(256), lds, st, (const uint8_t*)V6, (const float*)Sbuf, \
                        (const float*)Mbuf, ctx, g6, nbh);                                                \

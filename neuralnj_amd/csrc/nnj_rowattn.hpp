@@ -342,7 +342,7 @@ __global__ __launch_bounds__(256, QW == 128 ? 2 : 1) void k_row_s(const uint8_t*
 
 // ------------------------------------------------------------------ k_row_pv
 // Context of 128 queries of one (b, h): 4 waves x 32 queries, O^T[e x query] in ET accumulators per wave.
-// Per 16 keys: the V6 tile (ET*3 KiB) arrives by LDS-DMA (three-stage ring, one barrier per k-step), the
+// Per 16 keys: the V6 tile (ET*3 KiB) arrives by LDS-DMA (four-stage ring, one barrier per two k-steps), the
 // lane's 8 probabilities exp(S - max) -- S read back as the register image k_row_s wrote, the next tile
 // prefetched -- are split into a B fragment in registers, and ET A fragments stream from LDS through a
 // two-deep software pipeline (hand-issued reads).  sum(P) is carried per lane; ctx = O / sum.
@@ -353,6 +353,7 @@ __global__ __launch_bounds__(256) void k_row_pv(const uint8_t* __restrict__ V6, 
   constexpr unsigned TILE = ET * 3072u;                               // bytes of one V6 tile
   constexpr unsigned STG = (TILE + 4095u) / 4096u * 4096u;            // stage size: whole KiB per wave
   constexpr int NIW = STG / 4096;                                     // DMA instructions per wave and tile
+  constexpr int NST = 4 * STG <= 163840 ? 4 : 3;                      // ring stages (160 KiB of LDS)
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, HH = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -401,15 +402,26 @@ __global__ __launch_bounds__(256) void k_row_pv(const uint8_t* __restrict__ V6, 
   Frag3 bfr[2];
   auto kstep = [&](int k, auto par) {
     constexpr int P = decltype(par)::value;    // k & 1
-    // tile k has landed.  Vector memory operations retire in order; younger than tile k's pieces are the
-    // pieces of tile k+1 and, on odd k, the 4 loads of the next S image issued at the top of k-1 (which has
-    // until the top of k+1: two k-steps of HBM latency)
-    if constexpr (P == 1) wait_vmem_le<NIW + 4>(); else wait_vmem_le<NIW>();
-    barrier_nofence();                         // ... for every wave; every wave is done with tile k-1
+    if constexpr (NST == 4) {
+      // Four-stage ring, ONE barrier per two k-steps (= per S image): at an even k the tiles k and k+1 (issued
+      // during k-2 and k-1) and the S image prefetched at k-2 are waited for (vmcnt 0: they are everything
+      // this wave has in flight), the barrier makes that true for every wave and tells that tiles k-2, k-1 are
+      // read: their stages take tiles k+2 (issued during k) and k+3 (during k+1).
+      if constexpr (P == 0) {
+        wait_vmem_le<0>();
+        barrier_nofence();
+      }
+    } else {
+      // Three stages (the 16-tile head dimension): one barrier per k-step.  Vector memory operations retire in
+      // order; younger than tile k's pieces are the pieces of tile k+1 and, on odd k, the 4 loads of the next S
+      // image issued at the top of k-1.
+      if constexpr (P == 1) wait_vmem_le<NIW + 4>(); else wait_vmem_le<NIW>();
+      barrier_nofence();
+    }
     if constexpr (P == 0) {
       if ((k >> 1) + 1 < g.nt32) loadS(s_nxt, (k >> 1) + 1);
     }
-    const int st2 = (k + 2) % 3;                // its pieces go out between the MFMA groups below
+    const int st2 = (k + 2) % NST;              // its pieces go out between the MFMA groups below
     if constexpr (P == 0) {
       // probabilities of the 32 keys of this S image; registers 0-7 feed this k-step, 8-15 the next
       f32x16 p;
@@ -419,7 +431,7 @@ __global__ __launch_bounds__(256) void k_row_pv(const uint8_t* __restrict__ V6, 
       split8<8>(bfr[1], p);
     }
     const Frag3& bf = bfr[P];
-    const unsigned so = aA + (unsigned)(k % 3) * STG;
+    const unsigned so = aA + (unsigned)(k % NST) * STG;
     // A fragments: three buffers, two tiles ahead (one group of 6 MFMAs = 192 cycles is less than an LDS
     // round trip under load)
     Frag3 a[3];
