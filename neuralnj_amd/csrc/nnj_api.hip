@@ -159,11 +159,10 @@ PairGeom pair_geom(int mode, int n, int B, int C) {
     if (blocks < 1) blocks = 1;
     g.cs = (C + blocks - 1) / blocks;
     blocks = (C + g.cs - 1) / g.cs;
-    // partial sets = one per site slot of a workgroup.  alpha: 16-row tiles, 12 waves / (1, 2 or 4 tiles that
-    // share a site).  scores: the same for n <= 16; above, the 32-row kernels (8 slots, or 4 pairs of waves)
+    // one partial set per workgroup (the site slots of a workgroup are summed in LDS, in slot order)
     g.blocks = blocks;
-    g.nsc_a = blocks * (T16_WAVES / (n > 48 ? 4 : (n > 32 ? 3 : (n > 16 ? 2 : 1))));
-    g.nsc = n <= 16 ? g.nsc_a : blocks * (n > 32 ? 4 : 8);       // (4 also for the 3-wave 16-row variant: 12 / 3)
+    g.nsc_a = blocks;
+    g.nsc = blocks;
     return g;
   }
   g.npairs = mode == PAIRS_FULL ? n * (n - 1) / 2 : n;

@@ -533,9 +533,17 @@ __global__ __launch_bounds__(512) void k_inc_score(RowSet rs, ScorerW w, const i
     s += __shfl_xor(s, 32);
     score += (s + w.s2b) * mc;
   }
-  if (hh == 0) {
-    const int part = sc * NSLOT + slot, nparts = gridDim.x * NSLOT;
-    score_part[((size_t)b * nparts + part) * 64 + r] = score;
+  // one partial set per WORKGROUP: the slots' sums meet in LDS (the images are dead) and are added in slot order
+  __syncthreads();
+  float* red = smem + 2 * b6_floats(64, 64);              // [NSLOT][64]
+  if (hh == 0) red[slot * 64 + r] = score;
+  if (KT == 1 && lane >= 32) red[slot * 64 + lane] = 0.f;  // pair rows 32..63 have no wave
+  __syncthreads();
+  if (tid < 64) {
+    float v = 0.f;
+#pragma unroll
+    for (int s_ = 0; s_ < NSLOT; ++s_) v += red[s_ * 64 + tid];
+    score_part[((size_t)b * gridDim.x + sc) * 64 + tid] = v;
   }
 }
 

@@ -120,14 +120,25 @@ __global__ __launch_bounds__(64 * T16_WAVES) void k_inc_alpha16(RowSet rs, Score
     linear_t16<4, false>(xp.t, x, At_l, nullptr, lane);          // x' = A^T x
     linear_t16<NG, true>(acc, xp, img, nullptr, lane);           // acc[r'][pair] += S_r' . x'
   }
-  const int part = sc * NSLOT + slot, nparts = gridDim.x * NSLOT;
-  float* dst = alpha_part + (((size_t)b * nparts + part) * 64 + L.r) * 64 + 4 * kq;
+  // one partial set per WORKGROUP: the slots add their tiles into one LDS tile [64 pairs][64 r'] in slot order
+  // (fixed order: bitwise reproducible), the images are dead by then
+  __syncthreads();
+  float* red = smem + 6144;                                // 4096 floats
+  for (int i = tid; i < 4096; i += 64 * T16_WAVES) red[i] = 0.f;
+  __syncthreads();
+  for (int s_ = 0; s_ < NSLOT; ++s_) {
+    if (slot == s_) {
 #pragma unroll
-  for (int mt = 0; mt < 4; ++mt) {
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (mt < NG) v = acc[mt < NG ? mt : 0];
-    *reinterpret_cast<f32x4*>(dst + 16 * mt) = v;
+      for (int mt = 0; mt < NG; ++mt) {
+        f32x4* d4 = reinterpret_cast<f32x4*>(red + L.r * 64 + 16 * mt + 4 * kq);
+        *d4 = *d4 + acc[mt];
+      }
+    }
+    __syncthreads();
   }
+  float* dst = alpha_part + ((size_t)b * gridDim.x + sc) * 4096;
+  for (int i = tid; i < 1024; i += 64 * T16_WAVES)
+    reinterpret_cast<f32x4*>(dst)[i] = reinterpret_cast<const f32x4*>(red)[i];
 }
 
 // ------------------------------------------------------------------ k_inc_score16
@@ -270,8 +281,17 @@ __global__ __launch_bounds__(64 * T16_WAVES) void k_inc_score16(RowSet rs, Score
     s += __shfl_xor(s, 32);
     score += (s + w.s2b) * mc;
   }
-  if (kq == 0) {
-    const int part = sc * NSLOT + slot, nparts = gridDim.x * NSLOT;
-    score_part[((size_t)b * nparts + part) * 64 + L.r] = score;
+  // one partial set per WORKGROUP: the slots' sums meet in LDS (the images are dead) and are added in slot order
+  __syncthreads();
+  float* red = smem + 12288;                               // [NSLOT][64]
+  if (16 * NG < 64 && tl == 0) red[slot * 64 + lane] = 0.f;                 // pair rows without a wave
+  __syncthreads();
+  if (kq == 0) red[slot * 64 + L.r] = score;
+  __syncthreads();
+  if (tid < 64) {
+    float v = 0.f;
+#pragma unroll
+    for (int s_ = 0; s_ < NSLOT; ++s_) v += red[s_ * 64 + tid];
+    score_part[((size_t)b * gridDim.x + sc) * 64 + tid] = v;
   }
 }
