@@ -304,6 +304,7 @@ __global__ __launch_bounds__(512) void k_tok1p(const float* __restrict__ ctx, co
     asm volatile("" ::: "memory");                      // keep parameter loads inside the loop (hoisted, they would occupy ~200 VGPRs)
     const int b = (int)(col / C), c = (int)(col % C);
     const bool padded = mask && mask[(size_t)b * C + c];
+    const float qscale = padded ? 0.f : scaling;
     float* xp = x + (((size_t)b * R + (valid ? r : 0)) * C + c) * 64;
     f32x16 xr[1][2];
     {
@@ -357,23 +358,24 @@ __global__ __launch_bounds__(512) void k_tok1p(const float* __restrict__ ctx, co
 #pragma unroll
           for (int k = 0; k < 16; ++k) sc_[jt][k] = 0.f;
 #pragma unroll
-          for (int t = 0; t < 4; ++t) sc_[jt] = mfma32(ka[t], qh[0][0][4 * g + t] * scaling, sc_[jt]);
+          for (int t = 0; t < 4; ++t) sc_[jt] = mfma32(ka[t], qh[0][0][4 * g + t] * qscale, sc_[jt]);
         }
-        // element k of tile jt is key j = 32*jt + (k&3) + 8*(k>>2) + 4*hh
+        // element k of tile jt is key j = 32*jt + (k&3) + 8*(k>>2) + 4*hh.  A padded column gets the same score
+        // for every key (axial_attention.py:220-224: -10000 everywhere): its q is scaled by 0 instead, the
+        // softmax of equal scores is the same.  Keys beyond the rows exist only in the second tile (R > 32).
         float m = -INFINITY;
 #pragma unroll
         for (int jt = 0; jt < 2; ++jt)
 #pragma unroll
           for (int k = 0; k < 16; ++k) {
-            const int j = 32 * jt + (k & 3) + 8 * (k >> 2) + 4 * hh;
             float v = sc_[jt][k];
-            if (padded) v = -10000.0f;                  // every key of a padded column (axial_attention.py:220-224)
-            if (j >= R) v = -INFINITY;
+            if (jt == 1 && 32 + (k & 3) + 8 * (k >> 2) + 4 * hh >= R) v = -INFINITY;
             sc_[jt][k] = v;
             m = fmaxf(m, v);
           }
         m = fmaxf(m, __shfl_xor(m, 32));
-        float l = 0.f, o8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        float l = 0.f;
+        f32x2 o2[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};       // packed FMAs: two d per instruction
 #pragma unroll
         for (int jt = 0; jt < 2; ++jt)
 #pragma unroll
@@ -383,9 +385,13 @@ __global__ __launch_bounds__(512) void k_tok1p(const float* __restrict__ ctx, co
             const float* vp = vimg + (32 * jt + (k & 3) + 8 * (k >> 2) + 4 * hh) * 32 + 8 * g;
             const f32x4 v0 = *reinterpret_cast<const f32x4*>(vp);
             const f32x4 v1 = *reinterpret_cast<const f32x4*>(vp + 4);
-#pragma unroll
-            for (int t = 0; t < 4; ++t) { o8[t] += p * v0[t]; o8[4 + t] += p * v1[t]; }
+            const f32x2 pp = {p, p};
+            o2[0] += pp * (f32x2){v0[0], v0[1]};
+            o2[1] += pp * (f32x2){v0[2], v0[3]};
+            o2[2] += pp * (f32x2){v1[0], v1[1]};
+            o2[3] += pp * (f32x2){v1[2], v1[3]};
           }
+        const float o8[8] = {o2[0][0], o2[0][1], o2[1][0], o2[1][1], o2[2][0], o2[2][1], o2[3][0], o2[3][1]};
         l += __shfl_xor(l, 32);
         const float inv = nnj_rcp(l);
 #pragma unroll
