@@ -300,32 +300,49 @@ __global__ __launch_bounds__(512) void k_tok1p(const float* __restrict__ ctx, co
   const bool valid = r < R;
   const long ncols = (long)B * C;
   const float scaling = rsqrtf((float)NNJ_DH);         // axial_attention.py:214
-  for (long col = (long)blockIdx.x * 4 + slot; col < ncols; col += (long)gridDim.x * 4) {
+  // The token and its row-attention context of the NEXT column are loaded (raw: rows beyond R read row 0, they
+  // are masked as keys and never stored) while the output projection of the current one runs: the two gathers
+  // were 12-15k exposed cycles per column at the top of the loop.
+  const int rc_ = valid ? r : 0;
+  auto load_col = [&](long col_, f32x16 (&xo)[2], f32x16 (&co)[2]) {
+    const int b_ = (int)(col_ / C), c_ = (int)(col_ % C);
+    load_token64(xo, x + (((size_t)b_ * R + rc_) * C + c_) * 64, true, hh);
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int h = 4 * mt + g;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(ctx + (((size_t)b_ * NNJ_NHEAD + h) * C + c_) * Epad + rc_ * 8 + 4 * hh);
+        co[mt][4 * g + 0] = v[0]; co[mt][4 * g + 1] = v[1]; co[mt][4 * g + 2] = v[2]; co[mt][4 * g + 3] = v[3];
+      }
+  };
+  const long cstride = (long)gridDim.x * 4;
+  f32x16 xn[2], cn[2];
+  {
+    const long col0 = (long)blockIdx.x * 4 + slot;
+    if (col0 < ncols) load_col(col0, xn, cn);
+  }
+  for (long col = (long)blockIdx.x * 4 + slot; col < ncols; col += cstride) {
     asm volatile("" ::: "memory");                      // keep parameter loads inside the loop (hoisted, they would occupy ~200 VGPRs)
     const int b = (int)(col / C), c = (int)(col % C);
     const bool padded = mask && mask[(size_t)b * C + c];
     const float qscale = padded ? 0.f : scaling;
-    float* xp = x + (((size_t)b * R + (valid ? r : 0)) * C + c) * 64;
+    float* xp = x + (((size_t)b * R + rc_) * C + c) * 64;
     f32x16 xr[1][2];
     {
       // ---- row attention: out_proj(context) + residual
       f32x16 cx[1][2], o[1][2];
-      load_token64(xr[0], xp, valid, hh);
-#pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int h = 4 * mt + g;
-          const f32x4 v = *reinterpret_cast<const f32x4*>(ctx + (((size_t)b * NNJ_NHEAD + h) * C + c) * Epad +
-                                                          (valid ? r : 0) * 8 + 4 * hh);
-          cx[0][mt][4 * g + 0] = valid ? v[0] : 0.f; cx[0][mt][4 * g + 1] = valid ? v[1] : 0.f;
-          cx[0][mt][4 * g + 2] = valid ? v[2] : 0.f; cx[0][mt][4 * g + 3] = valid ? v[3] : 0.f;
-        }
+      xr[0][0] = xn[0]; xr[0][1] = xn[1];
+      cx[0][0] = cn[0]; cx[0][1] = cn[1];
       linear_T<2, 2, 1>(o, cx, W0, wr.bo, lane);
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt) xr[0][mt] += o[0][mt];
     }
-    if (skip_col & 3) { store_token64(xr[0], xp, valid, hh); continue; }
+    if (skip_col & 3) {
+      store_token64(xr[0], xp, valid, hh);
+      load_col(col + cstride < ncols ? col + cstride : col, xn, cn);
+      continue;
+    }
 
     // ---- column attention over the 2 x 32 rows of the column
     f32x16 cx[1][2];
@@ -402,7 +419,8 @@ __global__ __launch_bounds__(512) void k_tok1p(const float* __restrict__ ctx, co
         }
       }
     }
-    f32x16 o[1][2];
+    load_col(col + cstride < ncols ? col + cstride : col, xn, cn);      // (last column: harmless reload; unconditional, so
+    f32x16 o[1][2];                                                      //  the old values are dead across the iteration)
     linear_T<2, 2, 1>(o, cx, Wo_l, wc.bo, lane);
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) xr[0][mt] += o[0][mt];
