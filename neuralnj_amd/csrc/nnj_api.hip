@@ -48,6 +48,7 @@ struct nnj_handle {
   std::vector<LayerOff> lo;
   size_t oE0, oe0, oE2, oe2, oWh, obh, oWg, obg, oWgq, obgq, oWgk, obgk, oS0, os0, os2w, os2b;
   size_t oA, oa0, ou, olut;      // derived (after the packed block)
+  size_t oWhS, obhS, oWgS, obgS; // derived: -log2(e) x (W_h, b_h, W_g, b_g): the sigmoids take exp2 arguments directly
   float t0 = 0.f, s2b = 0.f;
   int debug_stop = 0;            // encoder debug tap (nnj_debug_encoder_stop)
   int num_cu = 256;              // compute units of the device (persistent-kernel grid size)
@@ -97,7 +98,7 @@ FfnW ffn_ptrs(const nnj_handle* h, const LayerOff& l) {
 ScorerW scorer_ptrs(const nnj_handle* h) {
   const float* w = h->d_w;
   ScorerW s;
-  s.Wh = w + h->oWh; s.bh = w + h->obh; s.Wg = w + h->oWg; s.bg = w + h->obg;
+  s.Wh = w + h->oWhS; s.bh = w + h->obhS; s.Wg = w + h->oWgS; s.bg = w + h->obgS;   // pre-scaled by -log2(e)
   s.A = w + h->oA; s.a0 = w + h->oa0; s.u = w + h->ou; s.t0 = h->t0;
   s.S0 = w + h->oS0; s.s0 = w + h->os0; s.s2w = w + h->os2w; s.s2b = h->s2b;
   return s;
@@ -570,7 +571,8 @@ int nnj_load_weights(nnj_handle* h, const float* p, size_t n) {
   // derived tensors, computed in double and rounded once (see nnj_scorer.hpp header)
   const size_t base = align_up(need, 64);
   h->oA = base; h->oa0 = base + D * D; h->ou = h->oa0 + D; h->olut = h->ou + D;
-  const size_t total = h->olut + 6 * D;
+  h->oWhS = h->olut + 6 * D; h->obhS = h->oWhS + D * D; h->oWgS = h->obhS + D; h->obgS = h->oWgS + D * D;
+  const size_t total = h->obgS + D;
   std::vector<float> host(total, 0.f);
   memcpy(host.data(), p, need * sizeof(float));
   const float *Wq = p + h->oWgq, *bq = p + h->obgq, *Wk = p + h->oWgk, *bk = p + h->obgk;
@@ -586,6 +588,17 @@ int nnj_load_weights(nnj_handle* h, const float* p, size_t n) {
     double su = 0;
     for (size_t e = 0; e < D; ++e) su += (double)bq[e] * (double)Wk[e * D + d1];
     host[h->ou + d1] = (float)su;
+  }
+  {
+    const double nl2e = -1.4426950408889634;           // sigmoid(t) = 1 / (1 + 2^(-log2(e) t))
+    for (size_t i = 0; i < D * D; ++i) {
+      host[h->oWhS + i] = (float)(nl2e * (double)p[h->oWh + i]);
+      host[h->oWgS + i] = (float)(nl2e * (double)p[h->oWg + i]);
+    }
+    for (size_t i = 0; i < D; ++i) {
+      host[h->obhS + i] = (float)(nl2e * (double)p[h->obh + i]);
+      host[h->obgS + i] = (float)(nl2e * (double)p[h->obg + i]);
+    }
   }
   double t0 = 0;
   for (size_t e = 0; e < D; ++e) t0 += (double)bq[e] * (double)bk[e];

@@ -136,7 +136,7 @@ __device__ __forceinline__ void gate_tile(f32x16 (&x)[2], const float* img_s, co
       const f32x4 b4 = *reinterpret_cast<const f32x4*>(bh + 4 * ch);
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
-        const float z = sigmoidf_(ui[t] - uj[t] + b4[t]);
+        const float z = sigmoid_l2(ui[t] - uj[t] + b4[t]);
         x[mt][4 * g + t] = sj[t] + z * (si[t] - sj[t]);     // z*x_i + (1-z)*x_j
       }
       if (g & 1) __builtin_amdgcn_sched_barrier(0);         // at most 8 row pieces in flight: bounded live range
@@ -304,7 +304,7 @@ __global__ __launch_bounds__(64 * NW) void k_pair_score(RowSet rs, ScorerW w, co
           for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-              const float wg = sigmoidf_(g[0][mt][r]);
+              const float wg = sigmoid_l2(g[0][mt][r]);
               x[0][mt][r] += wg * (xg[0][mt][r] - x[0][mt][r]);   // (1-w)*x + w*x_g
             }
         }
@@ -404,7 +404,7 @@ __device__ __forceinline__ void inc_gate(f32x16 (&x)[NT][2], const IncRaw<NT>& r
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
           const int k = 4 * g + t;
-          const float z = sigmoidf_((raw.ur[nt][mt][k] - sh.um[mt][k]) + sgn[nt] * b4[t]);
+          const float z = sigmoid_l2((raw.ur[nt][mt][k] - sh.um[mt][k]) + sgn[nt] * b4[t]);
           x[nt][mt][k] = sh.sm[mt][k] + z * (raw.sr[nt][mt][k] - sh.sm[mt][k]);
         }
     }
@@ -515,7 +515,7 @@ __global__ __launch_bounds__(512) void k_inc_score(RowSet rs, ScorerW w, const i
       for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
-          const float wg = sigmoidf_(g[0][mt][k]);
+          const float wg = sigmoid_l2(g[0][mt][k]);
           x[0][mt][k] += wg * (xg[0][mt][k] - x[0][mt][k]);   // (1-w)*x + w*x_g
         }
     }
@@ -619,7 +619,7 @@ __global__ __launch_bounds__(256) void k_agg_alpha(RowSet rs, ScorerW w, const i
     const f32x4 b4 = *reinterpret_cast<const f32x4*>(w.bh + (e & 63));
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-      const float z = sigmoidf_(ui[t] - uj[t] + b4[t]);
+      const float z = sigmoid_l2(ui[t] - uj[t] + b4[t]);
       x[t] = sj[t] + z * (si[t] - sj[t]);
     }
   }
@@ -711,7 +711,7 @@ __global__ __launch_bounds__(256) void k_agg_finish(RowSet rs, ScorerW w, const 
         const f32x4 b4 = *reinterpret_cast<const f32x4*>(w.bh + 32 * mt + 8 * g + 4 * hh);
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-          const float z = sigmoidf_(ui[mt][4 * g + t] - uj[mt][4 * g + t] + b4[t]);
+          const float z = sigmoid_l2(ui[mt][4 * g + t] - uj[mt][4 * g + t] + b4[t]);
           x[0][mt][4 * g + t] = sj[mt][4 * g + t] + z * (si[mt][4 * g + t] - sj[mt][4 * g + t]);
         }
       }
@@ -735,7 +735,7 @@ __global__ __launch_bounds__(256) void k_agg_finish(RowSet rs, ScorerW w, const 
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float wg = sigmoidf_(g[0][mt][r]);
+        const float wg = sigmoid_l2(g[0][mt][r]);
         x[0][mt][r] += wg * (xg[0][mt][r] - x[0][mt][r]);
       }
   }

@@ -47,7 +47,7 @@ __device__ __forceinline__ void gate16(V64& x, const V64& sr, const V64& ur, con
     const f32x4 b4 = *reinterpret_cast<const f32x4*>(bh + 16 * mt + 4 * kq);
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const float z = sigmoidf_((ur.t[mt][e] - um.t[mt][e]) + sgn * b4[e]);
+      const float z = sigmoid_l2((ur.t[mt][e] - um.t[mt][e]) + sgn * b4[e]);
       x.t[mt][e] = sm.t[mt][e] + z * (sr.t[mt][e] - sm.t[mt][e]);
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -262,7 +262,7 @@ __global__ __launch_bounds__(64 * T16_WAVES) void k_inc_score16(RowSet rs, Score
       for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const float wg = sigmoidf_(g.t[mt][e]);
+          const float wg = sigmoid_l2(g.t[mt][e]);
           x.t[mt][e] += wg * (xg.t[mt][e] - x.t[mt][e]);          // (1-w)*x + w*x_g
           if (e == 3) __builtin_amdgcn_sched_barrier(0);
         }
