@@ -211,6 +211,21 @@ def main():
                         "algorithmic_bytes_per_launch": models[name]["bytes"]}
             out["kernel_ms_per_step"] = {k: round(v[0] / args.steps, 3) for k, v in prof.items() if v[1]}
         out["roofline"] = roof
+        if world == 1:
+            # BASELINE configs[1] beside the batched figure: ONE 50 x 1024 alignment per rollout (latency bound)
+            one = codes[:1].contiguous()
+            g.profile_enable(False)
+            for _ in range(3):
+                g.rollout_argmax(one, None)["merges"].cpu()
+            torch.cuda.synchronize(dev)
+            t1 = time.perf_counter()
+            reps = 20
+            for _ in range(reps):
+                g.rollout_argmax(one, None)["merges"].cpu()
+            torch.cuda.synchronize(dev)
+            ms1 = 1e3 * (time.perf_counter() - t1) / reps
+            out["single_msa"] = {"workload": f"Batch=1, {T}x{L} (BASELINE configs[1])", "ms_per_tree": ms1,
+                                 "trees_per_sec": 1e3 / ms1}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfgs, packed, T, L)
         print(json.dumps(out), flush=True)

@@ -465,9 +465,16 @@ int launch_aggregate(nnj_handle* h, const RowSet& rs, const int* ij, float* base
   }
   {
     Scope sc(h, st, PK_AGG_FINISH);
+    if ((long)B * ((C + 127) / 128) < (long)h->num_cu) {     // small batches: one 32-site tile per workgroup, rows split over its waves
+      const size_t lds = (3 * 4096 + 64 + 8192) * sizeof(float);
+      if (int rc = set_lds(h, k_agg_finish<true>, lds)) return rc;
+      hipLaunchKernelGGL(k_agg_finish<true>, dim3((unsigned)((C + 31) / 32), (unsigned)B), dim3(256), lds, st, rs, sw, ij,
+                         base + w.agg_part, nch, S_out, U_out, Kp_out, beta_out, out_bstride, out_slots, in_place, n, C);
+      return NNJ_OK;
+    }
     const size_t lds = (3 * 4096 + 64) * sizeof(float);
-    if (int rc = set_lds(h, k_agg_finish, lds)) return rc;
-    hipLaunchKernelGGL(k_agg_finish, dim3((unsigned)((C + 127) / 128), (unsigned)B), dim3(256), lds, st, rs, sw, ij,
+    if (int rc = set_lds(h, k_agg_finish<false>, lds)) return rc;
+    hipLaunchKernelGGL(k_agg_finish<false>, dim3((unsigned)((C + 127) / 128), (unsigned)B), dim3(256), lds, st, rs, sw, ij,
                        base + w.agg_part, nch, S_out, U_out, Kp_out, beta_out, out_bstride, out_slots, in_place, n, C);
   }
   return NNJ_OK;

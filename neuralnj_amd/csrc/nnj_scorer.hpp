@@ -649,6 +649,10 @@ __global__ __launch_bounds__(256) void k_agg_alpha(RowSet rs, ScorerW w, const i
 // (and, when U_out != nullptr, its cached transforms).  Tokens = sites; grid (ceil(C/128), B).
 //   out_row(b) = out_base + b*out_bstride + out_slot(b)*C*64 where out_slot = live[pi]
 //   (in place, environment.py:764-768) or 0 for the dense one-row output of nnj_aggregate.
+//   SPLIT (small batches, where 128-site workgroups would not fill the chip): the workgroup owns ONE 32-site
+//   tile and its four waves split the rows of the x_g sum (every 4th row each, partial sums added in wave order
+//   through LDS); wave 0 finishes the tile.
+template <bool SPLIT>
 __global__ __launch_bounds__(256) void k_agg_finish(RowSet rs, ScorerW w, const int* __restrict__ ij,
                                                     const float* __restrict__ part, int nch, float* S_out,
                                                     float* U_out, float* Kp_out, float* beta_out,
@@ -691,12 +695,13 @@ __global__ __launch_bounds__(256) void k_agg_finish(RowSet rs, ScorerW w, const 
     al[lane] = (s > 0.f) ? e / s : 0.f;
   }
   __syncthreads();
-  const int tile = blockIdx.x * 4 + wave;
+  const int tile = SPLIT ? blockIdx.x : blockIdx.x * 4 + wave;
   if (tile * 32 >= C) return;
   const int c = tile * 32 + (lane & 31);
   const bool valid = c < C;
   const size_t bo = (size_t)b * rs.bstride;
   const int slot_i = slot_of(rs, b, pi), slot_j = slot_of(rs, b, pj);
+  if (SPLIT && !has_ctx && wave != 0) return;          // nothing to split
   f32x16 x[1][2], xg[1][2];
   {
     f32x16 si[2], sj[2], ui[2], uj[2];
@@ -722,12 +727,32 @@ __global__ __launch_bounds__(256) void k_agg_finish(RowSet rs, ScorerW w, const 
 #pragma unroll
       for (int r = 0; r < 16; ++r) xg[0][mt][r] = 0.f;
 #pragma unroll 4                                   // several rows' loads in flight (rows i, j have weight 0)
-    for (int r = 0; r < n; ++r) {
+    for (int r = SPLIT ? wave : 0; r < n; r += SPLIT ? 4 : 1) {
       const float a = al[r];
       f32x16 sr[2];
       load_token64(sr, rs.S + bo + ((size_t)slot_of(rs, b, r) * C + (valid ? c : 0)) * 64, valid, hh);
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt) xg[0][mt] += a * sr[mt];
+    }
+    if (SPLIT) {
+      float* red = al + 64;                            // [4 waves][64 lanes][32]
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          *reinterpret_cast<f32x4*>(red + ((wave * 64 + lane) * 32 + 16 * mt + 4 * g)) =
+              (f32x4){xg[0][mt][4 * g], xg[0][mt][4 * g + 1], xg[0][mt][4 * g + 2], xg[0][mt][4 * g + 3]};
+      __syncthreads();
+      if (wave != 0) return;
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          f32x4 v = *reinterpret_cast<const f32x4*>(red + (lane * 32 + 16 * mt + 4 * g));
+#pragma unroll
+          for (int w2 = 1; w2 < 4; ++w2) v += *reinterpret_cast<const f32x4*>(red + ((w2 * 64 + lane) * 32 + 16 * mt + 4 * g));
+          xg[0][mt][4 * g] = v[0]; xg[0][mt][4 * g + 1] = v[1]; xg[0][mt][4 * g + 2] = v[2]; xg[0][mt][4 * g + 3] = v[3];
+        }
     }
     f32x16 g[1][2];
     linear_T<2, 2, 1>(g, xg, Wg_l, w.bg, lane);
