@@ -128,8 +128,12 @@ def test_seeded_random_inputs_vs_oracle(ctx_cache):
     packed = weights.pack(cfgs, weights.seeded_state(cfgs, 21, "sharp"))
     g = ctx_cache(cfgs, packed)
     o = _oracle(cfgs, packed)
+    # shapes chosen to hit every kernel variant: row counts <= 16, 17..32, 33..48, 49..64 (the incremental scorer
+    # changes tile shape at those points), odd T (zero-padded k-step of the row attention), L = 4 (one 16-column
+    # block, mostly padding), L not a multiple of 16 / 256, L > 1024 (five 256-row operand blocks)
     for (B, T, L, seed) in ((3, 5, 36, 1), (1, 2, 64, 2), (2, 33, 100, 3), (1, 17, 260, 4), (1, 50, 128, 5),
-                            (1, 64, 64, 6), (2, 57, 96, 7)):      # 64 = the largest row count this build covers
+                            (1, 64, 64, 6), (2, 57, 96, 7), (2, 9, 4, 8), (1, 20, 12, 9), (1, 40, 268, 10),
+                            (1, 3, 1028, 11), (1, 48, 32, 12), (1, 49, 16, 13)):      # 64 = the largest row count this build covers
         codes = synth.synth_codes_tree(B, T, L, seed)
         mask = np.zeros((B, L), bool)
         if seed % 2:
