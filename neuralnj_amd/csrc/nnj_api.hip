@@ -303,7 +303,7 @@ int launch_encoder(nnj_handle* h, const uint8_t* codes, const float* onehot, con
       const unsigned grid = (unsigned)((nbh + 7) / 8 * 8 * (g6.Cp / 128));
 #define NNJ_PV_CASE(N)                                                                                   \
   case N: {                                                                                              \
-    const size_t stg = (N * 3072 + 4095) / 4096 * 4096, lds = (4 * stg <= 163840 ? 4 : 3) * stg;        \
+    const size_t stg = (N * NPL * 1024 + 4095) / 4096 * 4096, lds = (4 * stg <= 163840 ? 4 : 3) * stg;        \
     if (int rc = set_lds(h, k_row_pv<N>, lds)) return rc;                                                \
     hipLaunchKernelGGL(k_row_pv<N>, dim3(grid), dim3(256), lds, st, (const uint8_t*)V6, (const float*)Sbuf, \
                        (const float*)Mbuf, ctx, g6, nbh);                                                \
@@ -339,10 +339,9 @@ int launch_encoder(nnj_handle* h, const uint8_t* codes, const float* onehot, con
         const int groups_per_b = (T * C + 255) / 256;
         const long ngroups = (long)groups_per_b * B;
         const unsigned grid = (unsigned)std::min<long>(ngroups, h->num_cu);
-        const size_t lds_ffn = (size_t)4 * 6144 * sizeof(float);
-        // ctx (consumed by k_tok1 above, B*8*C*Epad >= B*T*C*64 floats) is the scratch of the two-pass FFN
+        const size_t lds_ffn = (size_t)8 * IMG64 * sizeof(float);   // W1 and W2 whole (8 images of 64x64)
         if (int rc = set_lds(h, k_ffn16, lds_ffn)) return rc;
-        hipLaunchKernelGGL(k_ffn16, dim3(grid), dim3(1024), lds_ffn, st, x, ctx, ffn_ptrs(h, h->lo[l]), B, T, C, groups_per_b);
+        hipLaunchKernelGGL(k_ffn16, dim3(grid), dim3(1024), lds_ffn, st, x, ffn_ptrs(h, h->lo[l]), B, T, C, groups_per_b);
       }
     }
   }
@@ -380,7 +379,7 @@ int launch_pair_scores(nnj_handle* h, const RowSet& rs, const int* ij_prev, cons
     if (has_ctx) {
       {
         Scope sc(h, st, PK_PAIR_ALPHA_INCR);
-        const size_t lds = (size_t)(6144 + 18432 + 16) * sizeof(float);
+        const size_t lds = (size_t)(IMG64 + T16_WAVES * 512 * NPL + 16) * sizeof(float);
 #define NNJ_IA(NG)                                                                                          \
   case NG:                                                                                                  \
     if (int rc = set_lds(h, k_inc_alpha16<NG>, lds)) return rc;                                             \
@@ -400,7 +399,7 @@ int launch_pair_scores(nnj_handle* h, const RowSet& rs, const int* ij_prev, cons
       if (n <= 16) {
         // 16-pair tiles: half the padding of the 32-pair kernels (measured 2x faster here); above 16 rows the
         // group barriers of the shared image cost more than the padding saves
-        const size_t lds = (size_t)(12288 + 18432 + 16) * sizeof(float);
+        const size_t lds = (size_t)(2 * IMG64 + T16_WAVES * 512 * NPL + 16) * sizeof(float);
         if (has_ctx) {
           if (int rc = set_lds(h, k_inc_score16<1, true>, lds)) return rc;
           hipLaunchKernelGGL((k_inc_score16<1, true>), grid, blk16, lds, st, rs, sw, ij_prev, base + w.alpha, mask,
@@ -411,7 +410,7 @@ int launch_pair_scores(nnj_handle* h, const RowSet& rs, const int* ij_prev, cons
                              base + w.score_part, n, C, g.cs);
         }
       } else if (n > 32 && n <= 48) {                      // three 16-row tiles: 48 instead of 64 padded pairs
-        const size_t lds = (size_t)(12288 + 4 * 6144 + 16) * sizeof(float);
+        const size_t lds = (size_t)(2 * IMG64 + 4 * IMG64 + 16) * sizeof(float);
         if (int rc = set_lds(h, k_inc_score16<3, true>, lds)) return rc;
         hipLaunchKernelGGL((k_inc_score16<3, true>), grid, blk16, lds, st, rs, sw, ij_prev, base + w.alpha, mask,
                            base + w.score_part, n, C, g.cs);
@@ -433,7 +432,7 @@ int launch_pair_scores(nnj_handle* h, const RowSet& rs, const int* ij_prev, cons
   if (has_ctx) {
     {
       Scope sc(h, st, PK_PAIR_ALPHA);
-      const size_t lds = 2 * 14336 * sizeof(float);
+      const size_t lds = 2 * (IMG64 + 8192) * sizeof(float);
       if (int rc = set_lds(h, k_pair_alpha<1, 8>, lds)) return rc;
       hipLaunchKernelGGL((k_pair_alpha<1, 8>), grid, dim3(512), lds, st, rs, sw, ij_prev, base + w.alpha_part, mode, n, C,
                          g.npairs, g.ppad, g.cs);
@@ -446,7 +445,7 @@ int launch_pair_scores(nnj_handle* h, const RowSet& rs, const int* ij_prev, cons
   }
   {
     Scope sc(h, st, PK_PAIR_SCORE);
-    const size_t lds = (size_t)(2 * b6_floats(64, 64) + 2 * 14336) * sizeof(float);
+    const size_t lds = (size_t)(2 * IMG64 + 2 * (IMG64 + 8192)) * sizeof(float);
     if (int rc = set_lds(h, k_pair_score<1, 8>, lds)) return rc;
     hipLaunchKernelGGL((k_pair_score<1, 8>), grid, dim3(512), lds, st, rs, sw, ij_prev, base + w.alpha, mask,
                        base + w.score_part, mode, n, C, g.npairs, g.ppad, g.cs, has_ctx);

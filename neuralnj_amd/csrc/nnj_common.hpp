@@ -213,24 +213,30 @@ __device__ __forceinline__ void linear_T_acc(f32x16 (&out)[NT][MT], const f32x16
   linear_core<MT, KT, NT, LDW, SWZ, true, false>(out, in, W, nullptr, lane);
 }
 
-// ---- fp32 linear layers on the bf16 matrix pipe ("bf16x6").
-// v_mfma_f32_32x32x16_bf16 moves 16x the k of v_mfma_f32_32x32x2_f32 per cycle.  Every fp32 operand is
-// split EXACTLY into three bf16 pieces, x = h + m + l (8 + 8 + 8 significand bits, round-to-nearest at
-// each cut, the residuals are exact fp32 subtractions), and a product is accumulated in fp32 from the six
-// piece products of weight >= 2^-16:  hh + hm + mh + hl + lh + mm.  The dropped ones (ml, lm, ll) are
-// below 2^-24 of the product, i.e. below the rounding of an fp32 multiply, so the result is an fp32
-// GEMM to fp32 accuracy at 6/16 of the fp32-MFMA cycles.  The C/D layout of the 32x32x16 instruction
+// ---- fp32 linear layers on the 16-bit matrix pipe ("f16x3").
+// v_mfma_f32_32x32x16_f16 moves 16x the k of v_mfma_f32_32x32x2_f32 per cycle.  Every fp32 operand is split
+// into two fp16 pieces, x = h + m: h = fp16(x) (round to nearest), m = fp16(x - h) (the subtraction is exact).
+// h + m carries 22 of the 24 significand bits (fp16 denormals are kept by the conversion and by the MFMA on
+// gfx950 -- tools/probe/f16_denorm.hip -- so small values degrade gracefully: absolute error <= 3e-8), and a
+// product is accumulated in fp32 from the three piece products hh + hm + mh (mm is below 2^-22 of the
+// product).  Measured on random GEMMs the result is within 1.3-1.7x of the error of a plain fp32 GEMM
+// (which has its own accumulation rounding) as long as the operands are not uniformly below ~1e-2 in
+// magnitude -- true of every operand here (weights, LayerNorm outputs, activations, softmax weights, q scaled
+// by 0.05) -- at 3/16 of the fp32-MFMA cycles and 4 bytes per stored operand element.  Operand magnitudes must
+// stay below 65504 (they do: the largest are the S rows, O(10)).  The C/D layout of the 32x32x16 instruction
 // is the feature-major tile above, and its B operand of k-step G of a 32-feature tile is registers
 // 8G..8G+7 of that tile: the layer chaining of linear_core carries over unchanged.
+// (Identifiers still say "b6"/"6": the scheme started as a 3-piece bf16 split with six products.)
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-struct Frag3 { u32x4 h, m, l; };                           // 8 bf16 per piece
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+constexpr int NPL = 2;                                     // pieces (= planes of a stored operand) per fp32 value
+struct Frag3 { u32x4 h, m; };                              // 8 fp16 per piece
 
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-// RNE, lo -> bits 15:0.  A plain cast (hipcc emits v_cvt_pk_bf16_f32): the compiler sees the instruction and
-// inserts the VALU -> MFMA hazard waits itself, which it cannot do for inline asm.
-__device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
-  const bf16x2 v = {(__bf16)lo, (__bf16)hi};
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+// round to nearest, lo -> bits 15:0.  A plain cast: the compiler sees the conversion and inserts the
+// VALU -> MFMA hazard waits itself, which it cannot do for inline asm.
+__device__ __forceinline__ unsigned cvt_pk_f16(float lo, float hi) {
+  const f16x2 v = {(_Float16)lo, (_Float16)hi};
   return __builtin_bit_cast(unsigned, v);
 }
 // hides a value's provenance from the optimiser (no instruction): without it the compiler re-converts each
@@ -240,35 +246,29 @@ __device__ __forceinline__ void opaque(unsigned& x) {
   asm("" : "+v"(x));
 #endif
 }
-// two fp32 -> three packed bf16 pairs
-__device__ __forceinline__ void split2(float a, float b, unsigned& h, unsigned& m, unsigned& l) {
-  h = cvt_pk_bf16(a, b);
+// two fp32 -> two packed fp16 pairs (h, m)
+__device__ __forceinline__ void split2(float a, float b, unsigned& h, unsigned& m) {
+  h = cvt_pk_f16(a, b);
   opaque(h);
-  const float ra = a - __uint_as_float(h << 16), rb = b - __uint_as_float(h & 0xffff0000u);
-  m = cvt_pk_bf16(ra, rb);
-  opaque(m);
-  const float la = ra - __uint_as_float(m << 16), lb = rb - __uint_as_float(m & 0xffff0000u);
-  l = cvt_pk_bf16(la, lb);
+  const f16x2 hv = __builtin_bit_cast(f16x2, h);
+  m = cvt_pk_f16(a - (float)hv[0], b - (float)hv[1]);
 }
 // registers base..base+7 of a feature-major tile -> the fragment of one k-step
 template <int BASE>
 __device__ __forceinline__ void split8(Frag3& o, const f32x16& x) {
 #pragma unroll
   for (int p = 0; p < 4; ++p) {
-    unsigned h, m, l;
-    split2(x[BASE + 2 * p], x[BASE + 2 * p + 1], h, m, l);
-    o.h[p] = h; o.m[p] = m; o.l[p] = l;
+    unsigned h, m;
+    split2(x[BASE + 2 * p], x[BASE + 2 * p + 1], h, m);
+    o.h[p] = h; o.m[p] = m;
   }
 }
 __device__ __forceinline__ f32x16 mfma_bf16(u32x4 a, u32x4 b, f32x16 c) {
-  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c,
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c,
                                                  0, 0, 0);
 }
 // c += A*B from the six leading piece products, smallest first
 __device__ __forceinline__ f32x16 mfma_b6(const Frag3& a, const Frag3& b, f32x16 c) {
-  c = mfma_bf16(a.l, b.h, c);
-  c = mfma_bf16(a.h, b.l, c);
-  c = mfma_bf16(a.m, b.m, c);
   c = mfma_bf16(a.m, b.h, c);
   c = mfma_bf16(a.h, b.m, c);
   c = mfma_bf16(a.h, b.h, c);
@@ -304,7 +304,7 @@ __device__ __forceinline__ void barrier_nofence() {
 #endif
 }
 __device__ __forceinline__ void pin_frag(Frag3& f) {
-  pin_after_wait(f.h); pin_after_wait(f.m); pin_after_wait(f.l);
+  pin_after_wait(f.h); pin_after_wait(f.m);
 }
 // LDS weight image for the bf16x6 layers: three planes (h, m, l) of [rows][IN] bf16.  Within a row the
 // in-features are permuted so that the eight a lane needs for one k-step are one 16-byte chunk:
@@ -332,14 +332,14 @@ __device__ __forceinline__ void stage_weight_b6(float* lds, const float* __restr
     const f32x4 v0 = *reinterpret_cast<const f32x4*>(g + (size_t)r * GLD + c0 + f0);
     const f32x4 v1 = *reinterpret_cast<const f32x4*>(g + (size_t)r * GLD + c0 + f0 + 8);
     Frag3 f;
-    unsigned h, m, l;
-    split2(v0[0], v0[1], h, m, l); f.h[0] = h; f.m[0] = m; f.l[0] = l;
-    split2(v0[2], v0[3], h, m, l); f.h[1] = h; f.m[1] = m; f.l[1] = l;
-    split2(v1[0], v1[1], h, m, l); f.h[2] = h; f.m[2] = m; f.l[2] = l;
-    split2(v1[2], v1[3], h, m, l); f.h[3] = h; f.m[3] = m; f.l[3] = l;
+    unsigned h, m;
+    split2(v0[0], v0[1], h, m); f.h[0] = h; f.m[0] = m;
+    split2(v0[2], v0[3], h, m); f.h[1] = h; f.m[1] = m;
+    split2(v1[0], v1[1], h, m); f.h[2] = h; f.m[2] = m;
+    split2(v1[2], v1[3], h, m); f.h[3] = h; f.m[3] = m;
     const int ir = row0 + r;
     const int o = ir * CH + wswz6<CH>(ir, q);
-    img[o] = f.h; img[plane + o] = f.m; img[2 * plane + o] = f.l;
+    img[o] = f.h; img[plane + o] = f.m;
   }
 }
 // the same image of the TRANSPOSE of a [IN][rows] fp32 matrix (image row r = column r of g)
@@ -356,18 +356,19 @@ __device__ __forceinline__ void stage_weight_b6_T(float* lds, const float* __res
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = g[(size_t)(f0 + (e & 3) + 8 * (e >> 2)) * rows + r];
     Frag3 f;
-    unsigned h, m, l;
+    unsigned h, m;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      split2(v[2 * e], v[2 * e + 1], h, m, l);
-      f.h[e] = h; f.m[e] = m; f.l[e] = l;
+      split2(v[2 * e], v[2 * e + 1], h, m);
+      f.h[e] = h; f.m[e] = m;
     }
     const int o = r * CH + wswz6<CH>(r, q);
-    img[o] = f.h; img[plane + o] = f.m; img[2 * plane + o] = f.l;
+    img[o] = f.h; img[plane + o] = f.m;
   }
 }
 // floats of LDS one staged matrix occupies
-__host__ __device__ constexpr int b6_floats(int rows, int in) { return rows * in * 3 / 2; }
+__host__ __device__ constexpr int b6_floats(int rows, int in) { return rows * in * NPL / 2; }
+constexpr int IMG64 = b6_floats(64, 64);                   // floats of a [64][64] operand image
 
 // out[nt][mt] = bias + W*in (or += W*in), W = a stage_weight_b6 image of [32*MT][32*KT].
 template <int MT, int KT, int NT, bool ACC, bool BIAS, bool LEAN = false>
@@ -396,7 +397,7 @@ __device__ __forceinline__ void linear_core_b6(f32x16 (&out)[NT][MT], const f32x
     const int ks = s / MT, mt = s % MT;
     const int wrow = 32 * mt + row;
     const int o = wrow * CH + wswz6<CH>(wrow, 2 * ks + hh);
-    a.h = img[o]; a.m = img[PLANE + o]; a.l = img[2 * PLANE + o];
+    a.h = img[o]; a.m = img[PLANE + o];
   };
   if constexpr (LEAN) {
     // register-lean form for kernels at two waves per SIMD (the partner wave fills the gaps): one A and
@@ -465,13 +466,10 @@ __device__ __forceinline__ void linear6_T_acc(f32x16 (&out)[NT][MT], const f32x1
 struct V64 { f32x4 t[4]; };
 
 __device__ __forceinline__ f32x4 mfma16_bf16(u32x4 a, u32x4 b, f32x4 c) {
-  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0,
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0,
                                                  0);
 }
 __device__ __forceinline__ f32x4 mfma16_b6(const Frag3& a, const Frag3& b, f32x4 c) {
-  c = mfma16_bf16(a.l, b.h, c);
-  c = mfma16_bf16(a.h, b.l, c);
-  c = mfma16_bf16(a.m, b.m, c);
   c = mfma16_bf16(a.m, b.h, c);
   c = mfma16_bf16(a.h, b.m, c);
   c = mfma16_bf16(a.h, b.h, c);
@@ -479,11 +477,11 @@ __device__ __forceinline__ f32x4 mfma16_b6(const Frag3& a, const Frag3& b, f32x4
 }
 // eight values -> one k-step fragment (k-slot order: a[0..3], b[0..3])
 __device__ __forceinline__ void split_8(Frag3& o, const f32x4& a, const f32x4& b) {
-  unsigned h, m, l;
-  split2(a[0], a[1], h, m, l); o.h[0] = h; o.m[0] = m; o.l[0] = l;
-  split2(a[2], a[3], h, m, l); o.h[1] = h; o.m[1] = m; o.l[1] = l;
-  split2(b[0], b[1], h, m, l); o.h[2] = h; o.m[2] = m; o.l[2] = l;
-  split2(b[2], b[3], h, m, l); o.h[3] = h; o.m[3] = m; o.l[3] = l;
+  unsigned h, m;
+  split2(a[0], a[1], h, m); o.h[0] = h; o.m[0] = m;
+  split2(a[2], a[3], h, m); o.h[1] = h; o.m[1] = m;
+  split2(b[0], b[1], h, m); o.h[2] = h; o.m[2] = m;
+  split2(b[2], b[3], h, m); o.h[3] = h; o.m[3] = m;
 }
 __device__ __forceinline__ void load_v64(V64& v, const float* p, int kq) {
 #pragma unroll
@@ -510,7 +508,7 @@ __device__ __forceinline__ void stage_weight_t16(float* lds, const float* __rest
     Frag3 f;
     split_8(f, v0, v1);
     const int o = r * 8 + wswz6<8>(r, q);
-    img[o] = f.h; img[plane + o] = f.m; img[2 * plane + o] = f.l;
+    img[o] = f.h; img[plane + o] = f.m;
   }
 }
 // out (MT tiles of 16 rows) = bias + W*in or += W*in; W = a [16*MT][64] image of the layout above
@@ -536,7 +534,7 @@ __device__ __forceinline__ void linear_t16(f32x4 (&out)[MT], const V64& in, cons
       const int row = 16 * mt + l15;
       const int o = row * 8 + wswz6<8>(row, 4 * ks + kq);
       Frag3 a;
-      a.h = img[o]; a.m = img[PLANE + o]; a.l = img[2 * PLANE + o];
+      a.h = img[o]; a.m = img[PLANE + o];
       out[mt] = mfma16_b6(a, b, out[mt]);
     }
     __builtin_amdgcn_sched_barrier(0);

@@ -276,6 +276,8 @@ __global__ __launch_bounds__(512) void k_tok1p(const float* __restrict__ ctx, co
                                                float* __restrict__ x, AttnW wr, AttnW wc, int B, int R, int C,
                                                int Epad, int skip_col) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int HALF = b6_floats(32, 64);
+  static_assert(IMG64 == 4096, "the LDS layout below assumes 16 KiB operand images");
   float* W0 = smem;               // Wo_row
   float* Wq_l = smem + 4096;
   float* Wk_l = smem + 8192;
@@ -287,11 +289,16 @@ __global__ __launch_bounds__(512) void k_tok1p(const float* __restrict__ ctx, co
   float* kimg = smem + 20480 + slot * (64 * 36 + 64 * 32);   // K image [64][36]
   float* vimg = kimg + 64 * 36;                              // V image [64][32]
   int* cnt = reinterpret_cast<int*>(smem + 20480 + 4 * (64 * 36 + 64 * 32)) + slot;
-  stage_weight<64>(W0, wr.Wo, 64, tid, 512);
-  stage_weight<64>(Wq_l, wc.Wq, 64, tid, 512);
-  stage_weight<64>(Wk_l, wc.Wk, 64, tid, 512);
-  stage_weight<64>(Wv_l, wc.Wv, 64, tid, 512);
-  stage_weight<64>(Wo_l, wc.Wo, 64, tid, 512);
+  // f16x3 operand images (4 B per element: the same 16 KiB per matrix as an fp32 image); q/k/v as two
+  // [32][64] images each, one per head half
+  stage_weight_b6<64>(W0, wr.Wo, 64, tid, 512);
+  stage_weight_b6<64>(Wo_l, wc.Wo, 64, tid, 512);
+#pragma unroll
+  for (int hf = 0; hf < 2; ++hf) {
+    stage_weight_b6<64>(Wq_l + hf * HALF, wc.Wq + hf * 32 * 64, 32, tid, 512);
+    stage_weight_b6<64>(Wk_l + hf * HALF, wc.Wk + hf * 32 * 64, 32, tid, 512);
+    stage_weight_b6<64>(Wv_l + hf * HALF, wc.Wv + hf * 32 * 64, 32, tid, 512);
+  }
   if (tid < 4) reinterpret_cast<int*>(smem + 20480 + 4 * (64 * 36 + 64 * 32))[tid] = 0;
   __syncthreads();
   int epoch = 0;
@@ -334,7 +341,7 @@ __global__ __launch_bounds__(512) void k_tok1p(const float* __restrict__ ctx, co
       f32x16 cx[1][2], o[1][2];
       xr[0][0] = xn[0]; xr[0][1] = xn[1];
       cx[0][0] = cn[0]; cx[0][1] = cn[1];
-      linear_T<2, 2, 1>(o, cx, W0, wr.bo, lane);
+      linear6_T<2, 2, 1, true>(o, cx, W0, wr.bo, lane);
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt) xr[0][mt] += o[0][mt];
     }
@@ -352,9 +359,9 @@ __global__ __launch_bounds__(512) void k_tok1p(const float* __restrict__ ctx, co
       {
         f32x16 y[1][2];
         layer_norm64(y[0], xr[0], wc.ln_w, wc.ln_b, hh);
-        linear_T<1, 2, 1>(qh, y, Wq_l + hf * 32 * 64, wc.bq + 32 * hf, lane);
-        linear_T<1, 2, 1>(kh, y, Wk_l + hf * 32 * 64, wc.bk + 32 * hf, lane);
-        linear_T<1, 2, 1>(vh, y, Wv_l + hf * 32 * 64, wc.bv + 32 * hf, lane);
+        linear6_T<1, 2, 1, true>(qh, y, Wq_l + hf * HALF, wc.bq + 32 * hf, lane);
+        linear6_T<1, 2, 1, true>(kh, y, Wk_l + hf * HALF, wc.bk + 32 * hf, lane);
+        linear6_T<1, 2, 1, true>(vh, y, Wv_l + hf * HALF, wc.bv + 32 * hf, lane);
       }
       pair_barrier(cnt, epoch);                         // the partner has finished reading the previous images
 #pragma unroll
@@ -421,7 +428,7 @@ __global__ __launch_bounds__(512) void k_tok1p(const float* __restrict__ ctx, co
     }
     load_col(col + cstride < ncols ? col + cstride : col, xn, cn);      // (last column: harmless reload; unconditional, so
     f32x16 o[1][2];                                                      //  the old values are dead across the iteration)
-    linear_T<2, 2, 1>(o, cx, Wo_l, wc.bo, lane);
+    linear6_T<2, 2, 1, true>(o, cx, Wo_l, wc.bo, lane);
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) xr[0][mt] += o[0][mt];
     store_token64(xr[0], xp, valid, hh);
@@ -440,73 +447,44 @@ __device__ __forceinline__ void flat_token(int t, int R, int C, int& c, int& r, 
 
 // FFN on 16-token tiles: 16 waves x 16 tokens = 256-token groups, 16 registers per tensor, four waves per SIMD
 // (<= 128 registers): the LayerNorm -> fc1 -> GELU -> fc2 chain of one wave is latency bound, the other three
-// fill its gaps (no register prefetch needed).  bf16x6 images of the two weight matrices take 192 KiB, more than
-// the LDS: the hidden layer is done in two halves, each one pass of this workgroup over ITS token groups with the
-// half's weights resident (W1 rows [128p,128p+128) | W2 columns [128p,128p+128): 96 KiB).  Pass 0 leaves
-// b2 + W2a gelu(..) in `tmp` (same token layout as x; every lane re-reads only what it wrote itself), pass 1
-// adds the other half and the residual.
-__global__ __launch_bounds__(1024) void k_ffn16(float* __restrict__ x, float* __restrict__ tmp, FfnW wf, int B, int R,
-                                                int C, int groups_per_b) {
+// fill its gaps (no register prefetch needed).  Both weight matrices are resident as eight [64][64] operand
+// images (128 KiB); the hidden layer is walked 64 units at a time and never leaves the registers.
+__global__ __launch_bounds__(1024) void k_ffn16(float* __restrict__ x, FfnW wf, int B, int R, int C, int groups_per_b) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* W1l = smem;                         // two [64][64] images (hidden units 64q..64q+63 of the half)
-  float* W2l = smem + 2 * 6144;              // two [64][64] images
+  float* W1l = smem;                         // four [64][64] images: hidden units 64q..64q+63
+  float* W2l = smem + 4 * IMG64;             // four [64][64] images: hidden columns 64q..64q+63
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, kq = lane >> 4;
   const int ngroups = groups_per_b * B;
   if ((int)blockIdx.x >= ngroups) return;
-  int c, r; bool valid;
-  auto addr = [&](int g_) {
-    const int b = g_ / groups_per_b;
-    flat_token(((g_ % groups_per_b) * 16 + wave) * 16 + l15, R, C, c, r, valid);
-    return (((size_t)b * R + r) * C + c) * 64;
-  };
-  static_for<0, 2>([&](auto pi) {
-    constexpr int pass = decltype(pi)::value;
-    if (pass) __syncthreads();               // everyone is done with the first half's images
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {              // four [64][64] images: W1 rows / W2 columns 128*pass + 64*q ..
-      stage_weight_t16(W1l + q * 6144, wf.W1 + (size_t)(pass * 128 + q * 64) * 64, 64, tid, 1024);
-      stage_weight_t16(W2l + q * 6144, wf.W2, 64, tid, 1024, false, 256, 128 * pass + 64 * q);
+  for (int q = 0; q < 4; ++q) {
+    stage_weight_t16(W1l + q * IMG64, wf.W1 + (size_t)(q * 64) * 64, 64, tid, 1024);
+    stage_weight_t16(W2l + q * IMG64, wf.W2, 64, tid, 1024, false, 256, 64 * q);
+  }
+  __syncthreads();
+  for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+    const int b = grp / groups_per_b;
+    int c, r; bool valid;
+    flat_token(((grp % groups_per_b) * 16 + wave) * 16 + l15, R, C, c, r, valid);
+    float* xp = x + (((size_t)b * R + r) * C + c) * 64;
+    asm volatile("" ::: "memory");          // keep the parameter loads inside the loop (hoisted, they would occupy ~200 VGPRs)
+    V64 xr, y, out;
+    load_v64(xr, xp, kq);
+    layer_norm_v64(y, xr, wf.ln_w, wf.ln_b, kq);
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) out.t[mt] = *reinterpret_cast<const f32x4*>(wf.b2 + 16 * mt + 4 * kq);
+#pragma unroll 1
+    for (int q = 0; q < 4; ++q) {              // 64 hidden units at a time
+      V64 hdn;
+      linear_t16<4, false>(hdn.t, y, W1l + q * IMG64, wf.b1 + q * 64, lane);
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) hdn.t[mt][e] = gelu_erf(hdn.t[mt][e]);
+      linear_t16<4, true>(out.t, hdn, W2l + q * IMG64, nullptr, lane);
     }
-    __syncthreads();
-    for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
-      const size_t xo = addr(grp);
-      const bool cur_valid = valid;
-      asm volatile("" ::: "memory");          // keep the parameter loads inside the loop (hoisted, they would occupy ~200 VGPRs)
-      V64 y, out;
-      {
-        V64 xr;
-        load_v64(xr, x + xo, kq);
-        layer_norm_v64(y, xr, wf.ln_w, wf.ln_b, kq);
-      }
+    if (!valid) continue;
 #pragma unroll
-      for (int mt = 0; mt < 4; ++mt) {
-        out.t[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (!pass) out.t[mt] = *reinterpret_cast<const f32x4*>(wf.b2 + 16 * mt + 4 * kq);
-      }
-#pragma unroll
-      for (int q = 0; q < 2; ++q) {              // 64 hidden units at a time
-        V64 hdn;
-        linear_t16<4, false>(hdn.t, y, W1l + q * 6144, wf.b1 + pass * 128 + q * 64, lane);
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) hdn.t[mt][e] = gelu_erf(hdn.t[mt][e]);
-        linear_t16<4, true>(out.t, hdn, W2l + q * 6144, nullptr, lane);
-      }
-      if (!cur_valid) continue;
-      if (pass) {
-        // x + (first half + second half): the token (L2) and the first half's sum are re-read here
-        V64 xo_, t0;
-        load_v64(xo_, x + xo, kq);
-        load_v64(t0, tmp + xo, kq);
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
-          *reinterpret_cast<f32x4*>(x + xo + 16 * mt + 4 * kq) = xo_.t[mt] + (t0.t[mt] + out.t[mt]);
-      } else {
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) *reinterpret_cast<f32x4*>(tmp + xo + 16 * mt + 4 * kq) = out.t[mt];
-      }
-    }
-  });
+    for (int mt = 0; mt < 4; ++mt) *reinterpret_cast<f32x4*>(xp + 16 * mt + 4 * kq) = xr.t[mt] + out.t[mt];
+  }
 }
-

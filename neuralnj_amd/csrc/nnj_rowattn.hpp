@@ -54,8 +54,8 @@ inline Ra6 ra6_geom(int T, int C, int Epad) {
   g.ET = 16;
   for (int k : buckets) if (need <= k) { g.ET = k; break; }
   g.nrb = g.Cp / 256; g.nt32 = g.Cp / 32; g.nk16 = g.Cp / 16;
-  g.qk_bh = (size_t)g.KS * g.nrb * 3 * 8192;
-  g.v_bh = (size_t)g.nk16 * 3 * g.ET * 32 * 32;
+  g.qk_bh = (size_t)g.KS * g.nrb * NPL * 8192;
+  g.v_bh = (size_t)g.nk16 * NPL * g.ET * 32 * 32;
   g.s_bh = (size_t)g.nt32 * g.nt32 * 1024;
   g.m_bh = (size_t)g.nt32 * g.nt32 * 32;
   return g;
@@ -145,12 +145,12 @@ __global__ __launch_bounds__(512) void k_qkv6(const float* __restrict__ x, const
           float v[4];
 #pragma unroll
           for (int t = 0; t < 4; ++t) v[t] = valid ? (b4[t] + o[0][2 * ten + mt][4 * gq + t]) * scale : 0.f;
-          unsigned p01[3], p23[3];
-          split2(v[0], v[1], p01[0], p01[1], p01[2]);
-          split2(v[2], v[3], p23[0], p23[1], p23[2]);
-          uint8_t* dst = (ten ? K6 : Q6) + bh * g.qk_bh + ((size_t)(rp * g.nrb + rb) * 3) * 8192 + qk_row;
+          unsigned p01[NPL], p23[NPL];
+          split2(v[0], v[1], p01[0], p01[1]);
+          split2(v[2], v[3], p23[0], p23[1]);
+          uint8_t* dst = (ten ? K6 : Q6) + bh * g.qk_bh + ((size_t)(rp * g.nrb + rb) * NPL) * 8192 + qk_row;
 #pragma unroll
-          for (int p = 0; p < 3; ++p) *reinterpret_cast<uint2*>(dst + (size_t)p * 8192) = make_uint2(p01[p], p23[p]);
+          for (int p = 0; p < NPL; ++p) *reinterpret_cast<uint2*>(dst + (size_t)p * 8192) = make_uint2(p01[p], p23[p]);
         }
         // ---- v: transposed.  The lane holds four rows e (t = 0..3) of ONE key; a 4x4 transpose over the
         // quad (four consecutive keys) gives it one row e = 8r + 4hh + (lane&3) of FOUR keys = 8 bytes.
@@ -159,12 +159,12 @@ __global__ __launch_bounds__(512) void k_qkv6(const float* __restrict__ x, const
           float v[4];
 #pragma unroll
           for (int t = 0; t < 4; ++t) v[t] = valid ? b4[t] + o[0][4 + mt][4 * gq + t] : 0.f;
-          unsigned p01[3], p23[3];
-          split2(v[0], v[1], p01[0], p01[1], p01[2]);
-          split2(v[2], v[3], p23[0], p23[1], p23[2]);
-          uint8_t* dst = V6 + bh * g.v_bh + ((size_t)cb * 3 * (g.ET * 32) + e_row) * 32 + v_col;
+          unsigned p01[NPL], p23[NPL];
+          split2(v[0], v[1], p01[0], p01[1]);
+          split2(v[2], v[3], p23[0], p23[1]);
+          uint8_t* dst = V6 + bh * g.v_bh + ((size_t)cb * NPL * (g.ET * 32) + e_row) * 32 + v_col;
 #pragma unroll
-          for (int p = 0; p < 3; ++p) {
+          for (int p = 0; p < NPL; ++p) {
             // step 1 (lane ^ 1): even lanes collect element t=0 (and 2) of the key pair, odd lanes t=1 (and 3)
             const unsigned x01 = dpp_quad_xor1(p01[p]), x23 = dpp_quad_xor1(p23[p]);
             const unsigned q_lo = __builtin_amdgcn_perm(x01, p01[p], sel);
@@ -196,8 +196,10 @@ struct RsShape {
   static constexpr int NJ = QW / 64;                                 // query tiles per wave
   static constexpr int NST = QW == 256 ? 3 : 2;
   static constexpr unsigned QPL = QW * 32u;                          // bytes of one plane of the Q tile
-  static constexpr unsigned STAGE = 24576u + 3u * QPL;
-  static constexpr int NP = (24 + 3 * QW / 32) / 4;                  // DMA pieces per wave and k-step
+  static constexpr unsigned KTB = NPL * 8192u;                       // bytes of a K tile (256 rows x 16 k, NPL planes)
+  static constexpr unsigned STAGE = KTB + NPL * QPL;
+  static constexpr int NPK = NPL * 8;                                // 1-KiB pieces of the K tile
+  static constexpr int NP = (NPK + NPL * QW / 32) / 4;               // DMA pieces per wave and k-step
 };
 template <int QW>
 __global__ __launch_bounds__(256, QW == 128 ? 2 : 1) void k_row_s(const uint8_t* __restrict__ Q6, const uint8_t* __restrict__ K6,
@@ -205,7 +207,8 @@ __global__ __launch_bounds__(256, QW == 128 ? 2 : 1) void k_row_s(const uint8_t*
                                                              float* __restrict__ M, Ra6 g, int nbh, float fill) {
   using SH = RsShape<QW>;
   constexpr int NJ = SH::NJ, NP = SH::NP, NST = SH::NST;
-  constexpr unsigned QPL = SH::QPL, STAGE = SH::STAGE;
+  constexpr unsigned QPL = SH::QPL, STAGE = SH::STAGE, KTB = SH::KTB;
+  constexpr int NPK = SH::NPK;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, HH = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -218,9 +221,9 @@ __global__ __launch_bounds__(256, QW == 128 ? 2 : 1) void k_row_s(const uint8_t*
   const int kh = wave >> 1, qh = wave & 1;                           // key half, query half
   const int KS = g.KS;
   const int q0 = qb * QW;                                            // first query of the block
-  const uint8_t* Kt = K6 + (size_t)bh * g.qk_bh + (size_t)kb * 3 * 8192;
-  const uint8_t* Qt = Q6 + (size_t)bh * g.qk_bh + (size_t)(q0 >> 8) * 3 * 8192 + (size_t)(q0 & 255) * 32;
-  const size_t ks_stride = (size_t)g.nrb * 3 * 8192;
+  const uint8_t* Kt = K6 + (size_t)bh * g.qk_bh + (size_t)kb * NPL * 8192;
+  const uint8_t* Qt = Q6 + (size_t)bh * g.qk_bh + (size_t)(q0 >> 8) * NPL * 8192 + (size_t)(q0 & 255) * 32;
+  const size_t ks_stride = (size_t)g.nrb * NPL * 8192;
   // DMA piece i (of NP per wave and tile pair): 1 KiB of the K tile (pieces 0..23 of the workgroup) or of one
   // plane of the Q tile.  An LDS-DMA instruction costs 60-185 issue cycles: the pieces of the next tile are
   // spread over the MFMA groups of a k-step instead of being issued in one burst.
@@ -229,10 +232,10 @@ __global__ __launch_bounds__(256, QW == 128 ? 2 : 1) void k_row_s(const uint8_t*
     const int kk = ks < KS ? ks : KS - 1;                            // past the end: harmless reload into a free stage
     const int I = wave * NP + i;                                     // wave-uniform
     const uint8_t* src;
-    if (I < 24) {
+    if (I < NPK) {
       src = Kt + I * 1024;
     } else {
-      const int J = I - 24, pl = J / (QW / 32), pc = J % (QW / 32);  // plane, 1-KiB piece of the plane
+      const int J = I - NPK, pl = J / (QW / 32), pc = J % (QW / 32); // plane, 1-KiB piece of the plane
       src = Qt + (size_t)pl * 8192 + pc * 1024;
     }
     uint8_t* dst = reinterpret_cast<uint8_t*>(smem) + stage * STAGE + I * 1024;
@@ -243,7 +246,7 @@ __global__ __launch_bounds__(256, QW == 128 ? 2 : 1) void k_row_s(const uint8_t*
   };
   const unsigned half = 16u * (unsigned)(HH ^ ((l31 >> 3) & 1));
   const unsigned aA = lds_addr(smem) + (unsigned)(kh * 128 + l31) * 32u + half;
-  const unsigned aB = lds_addr(smem) + 24576u + (unsigned)(qh * 32 * NJ + l31) * 32u + half;
+  const unsigned aB = lds_addr(smem) + KTB + (unsigned)(qh * 32 * NJ + l31) * 32u + half;
   f32x16 acc[4][NJ];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
@@ -257,14 +260,12 @@ __global__ __launch_bounds__(256, QW == 128 ? 2 : 1) void k_row_s(const uint8_t*
       constexpr int i = decltype(ii)::value;
       lds_read_frag<i * 1024>(A[i].h, base);
       lds_read_frag<i * 1024 + 8192>(A[i].m, base);
-      lds_read_frag<i * 1024 + 16384>(A[i].l, base);
     });
   };
   auto readB = [&](Frag3& bfr, unsigned base, auto jj) {
     constexpr int j = decltype(jj)::value;
     lds_read_frag<j * 1024>(bfr.h, base);
     lds_read_frag<j * 1024 + QPL>(bfr.m, base);
-    lds_read_frag<j * 1024 + 2 * QPL>(bfr.l, base);
   };
   issue(0, 0);
   if constexpr (NST == 3) issue(1, 1);
@@ -350,7 +351,7 @@ template <int ET>
 __global__ __launch_bounds__(256) void k_row_pv(const uint8_t* __restrict__ V6, const float* __restrict__ S,
                                                 const float* __restrict__ M, float* __restrict__ ctx, Ra6 g,
                                                 int nbh) {
-  constexpr unsigned TILE = ET * 3072u;                               // bytes of one V6 tile
+  constexpr unsigned TILE = ET * NPL * 1024u;                         // bytes of one V6 tile
   constexpr unsigned STG = (TILE + 4095u) / 4096u * 4096u;            // stage size: whole KiB per wave
   constexpr int NIW = STG / 4096;                                     // DMA instructions per wave and tile
   constexpr int NST = 4 * STG <= 163840 ? 4 : 3;                      // ring stages (160 KiB of LDS)
@@ -439,13 +440,12 @@ __global__ __launch_bounds__(256) void k_row_pv(const uint8_t* __restrict__ V6, 
       constexpr int t = decltype(ti)::value;
       lds_read_frag<t * 1024>(a[t % 3].h, so);
       lds_read_frag<t * 1024 + ET * 1024>(a[t % 3].m, so);
-      lds_read_frag<t * 1024 + 2 * ET * 1024>(a[t % 3].l, so);
     };
     rd(std::integral_constant<int, 0>{});
     if constexpr (ET > 1) rd(std::integral_constant<int, 1>{});
     static_for<0, ET>([&](auto ti) {
       constexpr int t = decltype(ti)::value;
-      if constexpr (t + 1 < ET) lds_wait_le<3>(); else lds_wait_all();      // fragment t is in (t+1 may be landing)
+      if constexpr (t + 1 < ET) lds_wait_le<NPL>(); else lds_wait_all();    // fragment t is in (t+1 may be landing)
       pin_frag(a[t % 3]);
       if constexpr (t + 2 < ET) rd(std::integral_constant<int, t + 2>{});
       acc[t] = mfma_b6(a[t % 3], bf, acc[t]);

@@ -94,13 +94,12 @@ __device__ __forceinline__ void site_store(const SiteRegs<NTHR>& R, float* img_a
       // K' as a bf16x6 A image [3 planes][64 rows r][64 d] (the layout of stage_weight_b6): this thread's four
       // features d = 4ch..4ch+3 are one half of chunk q = 4*kt + 2*G + hh  (d = 32kt + 16G + 8j + 4hh + t)
       const int q = 4 * (ch >> 3) + 2 * ((ch >> 2) & 1) + (ch & 1), j = (ch >> 1) & 1;
-      unsigned h01, m01, l01, h23, m23, l23;
-      split2(R.a[k][0], R.a[k][1], h01, m01, l01);
-      split2(R.a[k][2], R.a[k][3], h23, m23, l23);
+      unsigned h01, m01, h23, m23;
+      split2(R.a[k][0], R.a[k][1], h01, m01);
+      split2(R.a[k][2], R.a[k][3], h23, m23);
       uint2* img = reinterpret_cast<uint2*>(img_a) + (r * 8 + wswz6<8>(r, q)) * 2 + j;   // 8-byte units
       img[0] = make_uint2(h01, h23);
       img[64 * 8 * 2] = make_uint2(m01, m23);
-      img[2 * 64 * 8 * 2] = make_uint2(l01, l23);
     }
     if (WITH_T) {
       // S^T as a bf16x6 A image: [3 planes][64 d][64 r'] bf16, row d = the r' order of stage_weight_b6
@@ -108,13 +107,12 @@ __device__ __forceinline__ void site_store(const SiteRegs<NTHR>& R, float* img_a
       const int q = 4 * (r >> 5) + 2 * ((r >> 4) & 1) + ((r >> 2) & 1), e = 4 * ((r >> 3) & 1) + (r & 3);
 #pragma unroll
       for (int pr = 0; pr < 2; ++pr) {
-        unsigned h, m, l;
-        split2(R.s[k][2 * pr], R.s[k][2 * pr + 1], h, m, l);
+        unsigned h, m;
+        split2(R.s[k][2 * pr], R.s[k][2 * pr + 1], h, m);
         const int d0 = 4 * ch + 2 * pr, d1 = d0 + 1;
         const int o0 = d0 * 64 + 8 * wswz6<8>(d0, q) + e, o1 = d1 * 64 + 8 * wswz6<8>(d1, q) + e;
         t16[o0] = (unsigned short)h; t16[o1] = (unsigned short)(h >> 16);
         t16[4096 + o0] = (unsigned short)m; t16[4096 + o1] = (unsigned short)(m >> 16);
-        t16[8192 + o0] = (unsigned short)l; t16[8192 + o1] = (unsigned short)(l >> 16);
         __builtin_amdgcn_sched_barrier(0);
       }
     }
@@ -172,23 +170,23 @@ __global__ __launch_bounds__(64 * NW) void k_pair_alpha(RowSet rs, ScorerW w, co
   SiteRegs<64 * NW> R;
   if (c0 < c1) {
     site_load<true, 64 * NW>(R, rs, b, n, C, c0, rs.Kp, tid);
-    site_store<true, false, 64 * NW>(R, smem, smem + 6144, smem + 10240, nullptr, tid);
+    site_store<true, false, 64 * NW>(R, smem, smem + IMG64, smem + IMG64 + 4096, nullptr, tid);
   }
   __syncthreads();
   for (int c = c0; c < c1; ++c) {
-    float* cur = smem + ((c - c0) & 1) * 14336;
-    float* nxt = smem + (((c - c0) & 1) ^ 1) * 14336;
+    float* cur = smem + ((c - c0) & 1) * (IMG64 + 8192);
+    float* nxt = smem + (((c - c0) & 1) ^ 1) * (IMG64 + 8192);
     const bool more = c + 1 < c1;
     if (more) site_load<true, 64 * NW>(R, rs, b, n, C, c + 1, rs.Kp, tid);     // in flight behind the MFMAs
     if (any) {
 #pragma unroll
       for (int tt = 0; tt < TPW; ++tt) {
         f32x16 x[1][2];
-        gate_tile(x[0], cur + 6144, cur + 10240, w.bh, pi[tt], pj[tt], hh);
+        gate_tile(x[0], cur + IMG64, cur + IMG64 + 4096, w.bh, pi[tt], pj[tt], hh);
         linear6_T_acc<2, 2, 1, true>(acc[tt], x, cur, lane);
       }
     }
-    if (more) site_store<true, false, 64 * NW>(R, nxt, nxt + 6144, nxt + 10240, nullptr, tid);
+    if (more) site_store<true, false, 64 * NW>(R, nxt, nxt + IMG64, nxt + IMG64 + 4096, nullptr, tid);
     __syncthreads();
   }
 #pragma unroll
@@ -279,15 +277,15 @@ __global__ __launch_bounds__(64 * NW) void k_pair_score(RowSet rs, ScorerW w, co
   SiteRegs<64 * NW> R;
   if (c0 < c1) {
     site_load<false, 64 * NW>(R, rs, b, n, C, c0, nullptr, tid);
-    site_store<false, true, 64 * NW>(R, nullptr, ring + 6144, ring + 10240, ring, tid);
+    site_store<false, true, 64 * NW>(R, nullptr, ring + IMG64, ring + IMG64 + 4096, ring, tid);
   }
   __syncthreads();
   for (int c = c0; c < c1; ++c) {
-    float* cur = ring + ((c - c0) & 1) * 14336;
-    float* nxt = ring + (((c - c0) & 1) ^ 1) * 14336;
-    const float* img_t = cur;                          // bf16x6 image: 6144 floats
-    const float* img_s = cur + 6144;
-    const float* img_u = cur + 10240;
+    float* cur = ring + ((c - c0) & 1) * (IMG64 + 8192);
+    float* nxt = ring + (((c - c0) & 1) ^ 1) * (IMG64 + 8192);
+    const float* img_t = cur;                          // operand image (IMG64 floats)
+    const float* img_s = cur + IMG64;
+    const float* img_u = cur + IMG64 + 4096;
     const bool more = c + 1 < c1;
     if (more) site_load<false, 64 * NW>(R, rs, b, n, C, c + 1, nullptr, tid);   // in flight behind the MFMAs
     const float mc = (mask && mask[(size_t)b * C + c]) ? 0.f : 1.f;   // seq_mask (model.py:96)
@@ -323,7 +321,7 @@ __global__ __launch_bounds__(64 * NW) void k_pair_score(RowSet rs, ScorerW w, co
         score[tt] += (s + w.s2b) * mc;
       }
     }
-    if (more) site_store<false, true, 64 * NW>(R, nullptr, nxt + 6144, nxt + 10240, nxt, tid);
+    if (more) site_store<false, true, 64 * NW>(R, nullptr, nxt + IMG64, nxt + IMG64 + 4096, nxt, tid);
     __syncthreads();
   }
   if (hh == 0) {
@@ -494,13 +492,12 @@ __global__ __launch_bounds__(512) void k_inc_score(RowSet rs, ScorerW w, const i
         for (int g = 0; g < 4; ++g)
 #pragma unroll
           for (int pr = 0; pr < 2; ++pr) {
-            unsigned h, m, l;
-            split2(raw.sr[0][mt][4 * g + 2 * pr], raw.sr[0][mt][4 * g + 2 * pr + 1], h, m, l);
+            unsigned h, m;
+            split2(raw.sr[0][mt][4 * g + 2 * pr], raw.sr[0][mt][4 * g + 2 * pr + 1], h, m);
             const int d0 = 32 * mt + 8 * g + 4 * hh + 2 * pr, d1 = d0 + 1;
             const int o0 = d0 * (32 * KT) + 8 * wswz6<TCH>(d0, q) + e, o1 = d1 * (32 * KT) + 8 * wswz6<TCH>(d1, q) + e;
             t16[o0] = (unsigned short)h; t16[o1] = (unsigned short)(h >> 16);
             t16[PL + o0] = (unsigned short)m; t16[PL + o1] = (unsigned short)(m >> 16);
-            t16[2 * PL + o0] = (unsigned short)l; t16[2 * PL + o1] = (unsigned short)(l >> 16);
           }
       if constexpr (KT == 2) pair_barrier_lds(cnt, epoch);   // all 64 columns are in the image
     }

@@ -66,13 +66,13 @@ __global__ __launch_bounds__(64 * T16_WAVES) void k_inc_alpha16(RowSet rs, Score
                                                                 float* __restrict__ alpha_part, int n, int C, int cs) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int NSLOT = T16_WAVES / NG;
-  constexpr int IMG = 16 * NG * 64 * 3 / 2;                // floats of an image
-  float* At_l = smem;                                      // A^T, 6144 floats
+  constexpr int IMG = 16 * NG * 64 * NPL / 2;              // floats of an image
+  float* At_l = smem;                                      // A^T, IMG64 floats
   const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, kq = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int slot = wave % NSLOT, tl = wave / NSLOT;
-  float* img = smem + 6144 + slot * IMG;
-  int* cnt0 = reinterpret_cast<int*>(smem + 6144 + NSLOT * IMG);
+  float* img = smem + IMG64 + slot * IMG;
+  int* cnt0 = reinterpret_cast<int*>(smem + IMG64 + NSLOT * IMG);
   const int sc = blockIdx.x, b = blockIdx.y;
   const int c0 = sc * cs, c1 = min(C, c0 + cs);
   stage_weight_t16(At_l, w.A, 64, tid, 64 * T16_WAVES, true);
@@ -110,7 +110,7 @@ __global__ __launch_bounds__(64 * T16_WAVES) void k_inc_alpha16(RowSet rs, Score
       Frag3 f;
       split_8(f, sr.t[2 * ks], sr.t[2 * ks + 1]);
       const int o = L.r * 8 + wswz6<8>(L.r, 4 * ks + kq);
-      im4[o] = f.h; im4[PL + o] = f.m; im4[2 * PL + o] = f.l;
+      im4[o] = f.h; im4[PL + o] = f.m;
     }
     if constexpr (NG > 1) group_barrier_lds<NG>(cnt, epoch);     // all rows are in the image
     const int cn = c + NSLOT < c1 ? c + NSLOT : c;               // prefetch behind the MFMAs (last: harmless reload)
@@ -123,7 +123,7 @@ __global__ __launch_bounds__(64 * T16_WAVES) void k_inc_alpha16(RowSet rs, Score
   // one partial set per WORKGROUP: the slots add their tiles into one LDS tile [64 pairs][64 r'] in slot order
   // (fixed order: bitwise reproducible), the images are dead by then
   __syncthreads();
-  float* red = smem + 6144;                                // 4096 floats
+  float* red = smem + IMG64;                               // 4096 floats (NSLOT * IMG >= 12288)
   for (int i = tid; i < 4096; i += 64 * T16_WAVES) red[i] = 0.f;
   __syncthreads();
   for (int s_ = 0; s_ < NSLOT; ++s_) {
@@ -159,19 +159,19 @@ __global__ __launch_bounds__(64 * T16_WAVES) void k_inc_score16(RowSet rs, Score
   constexpr int NC = NG == 3 ? 4 : NG;                     // image geometry: 16*NC columns (3 waves use the 64-column one)
   constexpr int CH = 2 * NC;                               // 16-byte chunks per image row (8 r' each)
   constexpr int KSX = NC == 4 ? 2 : 1;                     // k-steps of the x_g GEMM (32 r' each)
-  constexpr int IMG = 64 * 16 * NC * 3 / 2;                // floats of an image
+  constexpr int IMG = 64 * 16 * NC * NPL / 2;              // floats of an image
   float* Wg_l = smem;
-  float* S0_l = smem + 6144;
+  float* S0_l = smem + IMG64;
   const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, kq = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int slot = wave % NSLOT, tl = wave / NSLOT;
-  float* img = smem + 12288 + slot * IMG;
+  float* img = smem + 2 * IMG64 + slot * IMG;
   const int sc = blockIdx.x, b = blockIdx.y;
   const int c0 = sc * cs, c1 = min(C, c0 + cs);
   stage_weight_t16(Wg_l, w.Wg, 64, tid, 64 * T16_WAVES);
   stage_weight_t16(S0_l, w.S0, 64, tid, 64 * T16_WAVES);
   if constexpr (NG == 3) {                                 // columns 48..63 are never written: they meet alpha = 0 but must be finite
-    for (int i = tid; i < NSLOT * IMG; i += 64 * T16_WAVES) smem[12288 + i] = 0.f;
+    for (int i = tid; i < NSLOT * IMG; i += 64 * T16_WAVES) smem[2 * IMG64 + i] = 0.f;
   }
   __syncthreads();
   const Inc16 L = inc16(rs, ij_prev, b, n, 16 * tl + l15);
@@ -224,13 +224,12 @@ __global__ __launch_bounds__(64 * T16_WAVES) void k_inc_score16(RowSet rs, Score
       for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
         for (int pr = 0; pr < 2; ++pr) {
-          unsigned h, m, l;
-          split2(sr.t[mt][2 * pr], sr.t[mt][2 * pr + 1], h, m, l);
+          unsigned h, m;
+          split2(sr.t[mt][2 * pr], sr.t[mt][2 * pr + 1], h, m);
           const int d0 = 16 * mt + 4 * kq + 2 * pr, d1 = d0 + 1;
           const int o0 = d0 * RL + 8 * tswz<NC>(d0, wchunk) + we, o1 = d1 * RL + 8 * tswz<NC>(d1, wchunk) + we;
           t16[o0] = (unsigned short)h; t16[o1] = (unsigned short)(h >> 16);
           t16[PLH + o0] = (unsigned short)m; t16[PLH + o1] = (unsigned short)(m >> 16);
-          t16[2 * PLH + o0] = (unsigned short)l; t16[2 * PLH + o1] = (unsigned short)(l >> 16);
           __builtin_amdgcn_sched_barrier(0);                     // bounded live ranges (three waves per SIMD: 168 registers)
         }
       if constexpr (NG > 1) __syncthreads();                     // all columns are in the image
@@ -252,7 +251,7 @@ __global__ __launch_bounds__(64 * T16_WAVES) void k_inc_score16(RowSet rs, Score
           const int d = 16 * mt + l15;
           const int o = d * CH + tswz<NC>(d, lc);
           Frag3 a;
-          a.h = im4[o]; a.m = im4[PL4 + o]; a.l = im4[2 * PL4 + o];
+          a.h = im4[o]; a.m = im4[PL4 + o];
           xg.t[mt] = mfma16_b6(a, bfr, xg.t[mt]);
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -283,7 +282,7 @@ __global__ __launch_bounds__(64 * T16_WAVES) void k_inc_score16(RowSet rs, Score
   }
   // one partial set per WORKGROUP: the slots' sums meet in LDS (the images are dead) and are added in slot order
   __syncthreads();
-  float* red = smem + 12288;                               // [NSLOT][64]
+  float* red = smem + 2 * IMG64;                           // [NSLOT][64]
   if (16 * NG < 64 && tl == 0) red[slot * 64 + lane] = 0.f;                 // pair rows without a wave
   __syncthreads();
   if (kq == 0) red[slot * 64 + L.r] = score;
