@@ -30,10 +30,11 @@ from neuralnj_amd import synth, utils, weights  # noqa: E402
 from neuralnj_amd._lib import Nnj  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 / 16x16x4_f32
-PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 (v_mfma_f32_32x32x16_bf16, 32 cycles)
-# fp32 GEMMs run as "bf16x6": every fp32 product is 6 bf16 MFMA products (exact 3-way operand split, fp32
-# accumulate, fp32 accuracy), so the matrix-pipe ceiling for ALGORITHMIC fp32 flops is the bf16 peak / 6.
-PEAK_F32_VIA_BF16X6_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6.0
+PEAK_F16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense fp16 / bf16 (v_mfma_f32_32x32x16_f16, 32 cycles)
+# fp32 GEMMs run as "f16x3": every fp32 operand is split into two fp16 pieces and a product is three fp16 MFMA
+# products with fp32 accumulation, so the matrix-pipe ceiling for ALGORITHMIC fp32 flops is the
+# fp16 peak / 3.
+PEAK_F32_VIA_F16X3_TFLOPS = PEAK_F16_MFMA_TFLOPS / 3.0
 PEAK_HBM_GBS = 8000.0
 
 
@@ -48,14 +49,14 @@ def kernel_models(B, T, L, layers):
     P = T * (T - 1) // 2
     row = C * D * 4
     m = {}
-    X6, F32 = PEAK_F32_VIA_BF16X6_TFLOPS, PEAK_F32_MFMA_TFLOPS
+    X6, F32 = PEAK_F32_VIA_F16X3_TFLOPS, PEAK_F32_MFMA_TFLOPS
     heads = 8
-    planes = heads * C * E * 6.0              # bytes of one of Q6/K6/V6 per tree (3 bf16 planes)
+    planes = heads * C * E * 4.0              # bytes of one of Q6/K6/V6 per tree (2 fp16 planes)
     sbytes = heads * C * C * 4.0              # the score images of one tree
     m["k_qkv6"] = dict(flops=B * N * 6.0 * D * D, bytes=B * (N * D * 4 + 3.0 * planes), peak=X6)
     m["k_row_s"] = dict(flops=B * 2.0 * C * C * T * D, bytes=B * (2.0 * planes + sbytes), peak=X6)
     m["k_row_pv"] = dict(flops=B * 2.0 * C * C * T * D, bytes=B * (planes + sbytes + heads * C * E * 4.0), peak=X6)
-    m["k_tok1"] = dict(flops=B * (N * 10.0 * D * D + 4.0 * T * T * C * D), bytes=B * 3.0 * N * D * 4, peak=F32)
+    m["k_tok1"] = dict(flops=B * (N * 10.0 * D * D + 4.0 * T * T * C * D), bytes=B * 3.0 * N * D * 4, peak=X6)
     m["k_ffn"] = dict(flops=B * N * 4.0 * D * F, bytes=B * 6.0 * N * D * 4, peak=X6)
     m["k_embed"] = dict(flops=B * N * 8.0 * D, bytes=B * (N + N * D * 4.0), peak=F32)
     # reference per (pair, site): W_h 2D^2, W_q 2D^2, alpha 2nD | x_g 2nD, W_g 2D^2, s_out 2D^2+2D
@@ -179,8 +180,9 @@ def main():
         "value": trees / elapsed, "unit": "trees/sec", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "precision": "fp32 results (GEMMs as exact 3-way bf16 operand splits on the bf16 matrix pipe, six piece "
-                     "products per fp32 product, fp32 accumulation; parity tests at the fp32 tolerances)",
+        "precision": "fp32 results (GEMM operands split into two fp16 pieces on the fp16 matrix pipe, three piece "
+                     "products per fp32 product, fp32 accumulation; score tables as close to an fp64 evaluation as "
+                     "the reference's own fp32 tables, profiles/r01/parity_margin_f16x3.json)",
         "config": {"workload": f"Batch={B} synthetic {T}x{L} MSAs per GPU, Argmax rollout (BASELINE configs[2]; "
                                f"configs[3] when sharded over 8 GPUs)",
                    "batch_per_gpu": B, "taxa": T, "sites": L, "gap_frac": 0.2, "model": "dim64 heads8 layers6 patch1",
@@ -203,13 +205,29 @@ def main():
                 peak = models[name]["peak"]
                 roof = {"kernel": name, "bound": "mfma", "achieved": ach, "peak": peak,
                         "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic,
-                        "peak_basis": ("dense bf16 MFMA peak / 6 (fp32 GEMM as six bf16 piece products, fp32 accumulate)"
-                                       if peak == PEAK_F32_VIA_BF16X6_TFLOPS else "dense fp32 MFMA peak"),
+                        "peak_basis": ("dense fp16 MFMA peak / 3 (fp32 GEMM as three fp16 piece products, fp32 accumulate)"
+                                       if peak == PEAK_F32_VIA_F16X3_TFLOPS else "dense fp32 MFMA peak"),
+                        # the same kernel against the HBM roofline, by its algorithmic bytes
+                        "hbm": {"achieved": models[name]["bytes"] / avg_s / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                "frac": models[name]["bytes"] / avg_s / 1e9 / PEAK_HBM_GBS},
                         "avg_launch_ms": ms / cnt, "launches": cnt,
                         "share_of_kernel_time": ms / total_ms if total_ms else None,
                         "algorithmic_flops_per_launch": models[name]["flops"],
                         "algorithmic_bytes_per_launch": models[name]["bytes"]}
             out["kernel_ms_per_step"] = {k: round(v[0] / args.steps, 3) for k, v in prof.items() if v[1]}
+            if roof is not None:
+                # the BASELINE "NJ Q-matrix kernel" quantity: all per-step kernels of the NJ loop against
+                # the HBM roofline, bytes = sum over steps of (n+1) rows + the score tables = 0.334 GB per 50x1024 tree
+                step_kinds = ("k_pair_alpha_incr", "k_pair_score_incr", "k_assemble_argmax", "k_agg_alpha", "k_agg_finish")
+                step_ms = sum(prof[k][0] for k in step_kinds if k in prof) / args.steps
+                C, D = L, 64
+                P = lambda n: n * (n - 1) // 2  # noqa: E731
+                step_bytes = B * sum((n + 1) * C * D * 4 + 4 * (P(n + 1) + n + P(n)) for n in range(T - 1, 1, -1))
+                if step_ms > 0:
+                    gbs = step_bytes / (step_ms / 1e3) / 1e9
+                    roof["nj_loop_hbm"] = {"kernels": list(step_kinds), "ms_per_rollout": step_ms,
+                                           "algorithmic_bytes_per_rollout": step_bytes, "achieved": gbs,
+                                           "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS}
         out["roofline"] = roof
         if world == 1:
             # BASELINE configs[1] beside the batched figure: ONE 50 x 1024 alignment per rollout (latency bound)

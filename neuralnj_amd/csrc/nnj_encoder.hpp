@@ -285,7 +285,10 @@ __global__ __launch_bounds__(512) void k_tok1p(const float* __restrict__ ctx, co
   float* Wo_l = smem + 16384;     // Wo_col
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int slot = wave & 3, rt = wave >> 2;            // column slot of the workgroup, row tile of the column
+  // column slot of the workgroup, row tile of the column.  Consecutive waves land on different SIMDs: the two
+  // waves of a column (which run in lockstep) sit on two SIMDs, and each SIMD hosts waves of two different,
+  // unsynchronised columns -- one's VALU phases overlap the other's MFMA phases
+  const int slot = wave >> 1, rt = wave & 1;
   float* kimg = smem + 20480 + slot * (64 * 36 + 64 * 32);   // K image [64][36]
   float* vimg = kimg + 64 * 36;                              // V image [64][32]
   int* cnt = reinterpret_cast<int*>(smem + 20480 + 4 * (64 * 36 + 64 * 32)) + slot;

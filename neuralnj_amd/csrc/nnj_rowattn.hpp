@@ -194,7 +194,7 @@ __global__ __launch_bounds__(512) void k_qkv6(const float* __restrict__ x, const
 template <int QW>
 struct RsShape {
   static constexpr int NJ = QW / 64;                                 // query tiles per wave
-  static constexpr int NST = QW == 256 ? 3 : 2;
+  static constexpr int NST = 3;                                      // 3 x 24 KiB stages: two workgroups per CU still fit
   static constexpr unsigned QPL = QW * 32u;                          // bytes of one plane of the Q tile
   static constexpr unsigned KTB = NPL * 8192u;                       // bytes of a K tile (256 rows x 16 k, NPL planes)
   static constexpr unsigned STAGE = KTB + NPL * QPL;
