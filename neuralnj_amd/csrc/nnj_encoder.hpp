@@ -276,12 +276,10 @@ __global__ __launch_bounds__(512) void k_tok1p(const float* __restrict__ ctx, co
                                                float* __restrict__ x, AttnW wr, AttnW wc, int B, int R, int C,
                                                int Epad, int skip_col) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  constexpr int HALF = b6_floats(32, 64);
-  static_assert(IMG64 == 4096, "the LDS layout below assumes 16 KiB operand images");
+  constexpr int QKV = b6_floats(96, 64);                // q | k | v rows of one head half: one operand image
+  static_assert(IMG64 == 4096 && QKV == 6144, "the LDS layout below assumes 4-byte operand elements");
   float* W0 = smem;               // Wo_row
-  float* Wq_l = smem + 4096;
-  float* Wk_l = smem + 8192;
-  float* Wv_l = smem + 12288;
+  float* Wqkv_l = smem + 4096;    // two [96][64] images
   float* Wo_l = smem + 16384;     // Wo_col
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -290,17 +288,17 @@ __global__ __launch_bounds__(512) void k_tok1p(const float* __restrict__ ctx, co
   // unsynchronised columns -- one's VALU phases overlap the other's MFMA phases
   const int slot = wave >> 1, rt = wave & 1;
   float* kimg = smem + 20480 + slot * (64 * 36 + 64 * 32);   // K image [64][36]
-  float* vimg = kimg + 64 * 36;                              // V image [64][32]
+  // V^T image: two fp16 planes of [32 (head, d)][64 keys], keys in fragment order (see the P.V loop), 8 KiB
+  uint8_t* vimg = reinterpret_cast<uint8_t*>(kimg + 64 * 36);
   int* cnt = reinterpret_cast<int*>(smem + 20480 + 4 * (64 * 36 + 64 * 32)) + slot;
-  // f16x3 operand images (4 B per element: the same 16 KiB per matrix as an fp32 image); q/k/v as two
-  // [32][64] images each, one per head half
+  // f16x3 operand images (4 B per element: the same 16 KiB per matrix as an fp32 image)
   stage_weight_b6<64>(W0, wr.Wo, 64, tid, 512);
   stage_weight_b6<64>(Wo_l, wc.Wo, 64, tid, 512);
 #pragma unroll
   for (int hf = 0; hf < 2; ++hf) {
-    stage_weight_b6<64>(Wq_l + hf * HALF, wc.Wq + hf * 32 * 64, 32, tid, 512);
-    stage_weight_b6<64>(Wk_l + hf * HALF, wc.Wk + hf * 32 * 64, 32, tid, 512);
-    stage_weight_b6<64>(Wv_l + hf * HALF, wc.Wv + hf * 32 * 64, 32, tid, 512);
+    stage_weight_b6<64>(Wqkv_l + hf * QKV, wc.Wq + hf * 32 * 64, 32, tid, 512, 0, 96);
+    stage_weight_b6<64>(Wqkv_l + hf * QKV, wc.Wk + hf * 32 * 64, 32, tid, 512, 32, 96);
+    stage_weight_b6<64>(Wqkv_l + hf * QKV, wc.Wv + hf * 32 * 64, 32, tid, 512, 64, 96);
   }
   if (tid < 4) reinterpret_cast<int*>(smem + 20480 + 4 * (64 * 36 + 64 * 32))[tid] = 0;
   __syncthreads();
@@ -358,21 +356,53 @@ __global__ __launch_bounds__(512) void k_tok1p(const float* __restrict__ ctx, co
     f32x16 cx[1][2];
 #pragma unroll
     for (int hf = 0; hf < 2; ++hf) {                    // heads 4*hf .. 4*hf+3
-      f32x16 qh[1][1], kh[1][1], vh[1][1];
+      // q, k feature-major (lane = row); v TOKEN-major (operands swapped: lane = (head, d), registers = rows) so
+      // that its columns go to the V^T image as 8-byte stores.  One pass over y: its fp16 split is shared.
+      f32x16 qh, kh, vT;
       {
-        f32x16 y[1][2];
-        layer_norm64(y[0], xr[0], wc.ln_w, wc.ln_b, hh);
-        linear6_T<1, 2, 1, true>(qh, y, Wq_l + hf * HALF, wc.bq + 32 * hf, lane);
-        linear6_T<1, 2, 1, true>(kh, y, Wk_l + hf * HALF, wc.bk + 32 * hf, lane);
-        linear6_T<1, 2, 1, true>(vh, y, Wv_l + hf * HALF, wc.bv + 32 * hf, lane);
+        f32x16 y[2];
+        layer_norm64(y, xr[0], wc.ln_w, wc.ln_b, hh);
+        const float bvl = wc.bv[32 * hf + tok];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f32x4 q4 = *reinterpret_cast<const f32x4*>(wc.bq + 32 * hf + 8 * g + 4 * hh);
+          const f32x4 k4 = *reinterpret_cast<const f32x4*>(wc.bk + 32 * hf + 8 * g + 4 * hh);
+#pragma unroll
+          for (int t = 0; t < 4; ++t) { qh[4 * g + t] = q4[t]; kh[4 * g + t] = k4[t]; vT[4 * g + t] = bvl; }
+        }
+        const u32x4* img = reinterpret_cast<const u32x4*>(Wqkv_l + hf * QKV);
+        static_for<0, 4>([&](auto ki) {
+          constexpr int ks = decltype(ki)::value;
+          Frag3 bfr;
+          split8<8 * (ks & 1)>(bfr, y[ks >> 1]);
+          static_for<0, 3>([&](auto mi) {
+            constexpr int mt = decltype(mi)::value;
+            const int wrow = 32 * mt + tok;
+            const int o = wrow * 8 + wswz6<8>(wrow, 2 * ks + hh);
+            Frag3 afr;
+            afr.h = img[o]; afr.m = img[96 * 8 + o];
+            if constexpr (mt == 0) qh = mfma_b6(afr, bfr, qh);
+            else if constexpr (mt == 1) kh = mfma_b6(afr, bfr, kh);
+            else vT = mfma_b6(bfr, afr, vT);
+          });
+          __builtin_amdgcn_sched_barrier(0);
+        });
       }
       pair_barrier(cnt, epoch);                         // the partner has finished reading the previous images
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const f32x4 k4 = {kh[0][0][4 * g], kh[0][0][4 * g + 1], kh[0][0][4 * g + 2], kh[0][0][4 * g + 3]};
-        const f32x4 v4 = {vh[0][0][4 * g], vh[0][0][4 * g + 1], vh[0][0][4 * g + 2], vh[0][0][4 * g + 3]};
+        const f32x4 k4 = {kh[4 * g], kh[4 * g + 1], kh[4 * g + 2], kh[4 * g + 3]};
         *reinterpret_cast<f32x4*>(kimg + r * 36 + 8 * g + 4 * hh) = k4;
-        *reinterpret_cast<f32x4*>(vimg + r * 32 + 8 * g + 4 * hh) = v4;
+        // vT registers 4g..4g+3: rows 32rt + 8g + 4hh + 0..3 of feature `tok`.  Key 32jt + 16u + 8v + 4hh + w sits at
+        // position 32jt + 16u + 8hh + 4v + w of the image row: the 8 keys a lane multiplies in one k-step (16 keys)
+        // are one 16-byte chunk, chunk index 4jt + 2u + hh, in the order the probability registers have
+        unsigned h01, m01, h23, m23;
+        split2(vT[4 * g], vT[4 * g + 1], h01, m01);
+        split2(vT[4 * g + 2], vT[4 * g + 3], h23, m23);
+        const int chunk = 4 * rt + 2 * (g >> 1) + hh;
+        uint8_t* dst = vimg + tok * 128 + 16 * wswz6<8>(tok, chunk) + 8 * (g & 1);
+        *reinterpret_cast<uint2*>(dst) = make_uint2(h01, h23);
+        *reinterpret_cast<uint2*>(dst + 4096) = make_uint2(m01, m23);
       }
       pair_barrier(cnt, epoch);                         // both row tiles' K and V are in the images
 #pragma unroll
@@ -385,7 +415,7 @@ __global__ __launch_bounds__(512) void k_tok1p(const float* __restrict__ ctx, co
 #pragma unroll
           for (int k = 0; k < 16; ++k) sc_[jt][k] = 0.f;
 #pragma unroll
-          for (int t = 0; t < 4; ++t) sc_[jt] = mfma32(ka[t], qh[0][0][4 * g + t] * qscale, sc_[jt]);
+          for (int t = 0; t < 4; ++t) sc_[jt] = mfma32(ka[t], qh[4 * g + t] * qscale, sc_[jt]);
         }
         // element k of tile jt is key j = 32*jt + (k&3) + 8*(k>>2) + 4*hh.  A padded column gets the same score
         // for every key (axial_attention.py:220-224: -10000 everywhere): its q is scaled by 0 instead, the
@@ -402,30 +432,37 @@ __global__ __launch_bounds__(512) void k_tok1p(const float* __restrict__ ctx, co
           }
         m = fmaxf(m, __shfl_xor(m, 32));
         float l = 0.f;
-        f32x2 o2[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};       // packed FMAs: two d per instruction
 #pragma unroll
         for (int jt = 0; jt < 2; ++jt)
 #pragma unroll
           for (int k = 0; k < 16; ++k) {
             const float p = nnj_exp(sc_[jt][k] - m);
+            sc_[jt][k] = p;
             l += p;
-            const float* vp = vimg + (32 * jt + (k & 3) + 8 * (k >> 2) + 4 * hh) * 32 + 8 * g;
-            const f32x4 v0 = *reinterpret_cast<const f32x4*>(vp);
-            const f32x4 v1 = *reinterpret_cast<const f32x4*>(vp + 4);
-            const f32x2 pp = {p, p};
-            o2[0] += pp * (f32x2){v0[0], v0[1]};
-            o2[1] += pp * (f32x2){v0[2], v0[3]};
-            o2[2] += pp * (f32x2){v1[0], v1[1]};
-            o2[3] += pp * (f32x2){v1[2], v1[3]};
           }
-        const float o8[8] = {o2[0][0], o2[0][1], o2[1][0], o2[1][1], o2[2][0], o2[2][1], o2[3][0], o2[3][1]};
         l += __shfl_xor(l, 32);
+        // O^T[(head, d) x query] = V^T P^T on the fp16 pipe: the probability registers 8u..8u+7 of tile jt are the B
+        // operand of k-step 2jt + u as they stand; A = the whole V^T image (all four heads of the half: only the
+        // rows of head g mean anything against P_g, i.e. registers 4g..4g+3 of the product -- d = 4hh + t)
+        f32x16 o;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) o[k] = 0.f;
+        static_for<0, 4>([&](auto si) {
+          constexpr int ks = decltype(si)::value;
+          Frag3 pf, vf;
+          split8<8 * (ks & 1)>(pf, sc_[ks >> 1]);
+          const uint8_t* src = vimg + tok * 128 + 16 * wswz6<8>(tok, 2 * ks + hh);
+          vf.h = *reinterpret_cast<const u32x4*>(src);
+          vf.m = *reinterpret_cast<const u32x4*>(src + 4096);
+          o = mfma_b6(vf, pf, o);
+        });
         const float inv = nnj_rcp(l);
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {                   // this lane keeps d = 4hh+t of the head
-          const float send = hh ? o8[t] : o8[4 + t];
-          const float recv = __shfl_xor(send, 32);
-          cx[0][hf][4 * g + t] = ((hh ? o8[4 + t] : o8[t]) + recv) * inv;
+        for (int t = 0; t < 4; ++t) {
+          float ov = o[0];                              // register 4g + t, g a compile-time constant after unrolling
+#pragma unroll
+          for (int k = 1; k < 16; ++k) ov = (k == 4 * g + t) ? o[k] : ov;
+          cx[0][hf][4 * g + t] = ov * inv;
         }
       }
     }
