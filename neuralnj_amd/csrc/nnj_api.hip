@@ -379,7 +379,7 @@ int launch_pair_scores(nnj_handle* h, const RowSet& rs, const int* ij_prev, cons
     if (has_ctx) {
       {
         Scope sc(h, st, PK_PAIR_ALPHA_INCR);
-        const size_t lds = (size_t)(IMG64 + T16_WAVES * 512 * NPL + 16) * sizeof(float);
+        const size_t lds = (size_t)(2 * IMG64 + T16_WAVES * 512 * NPL + 16) * sizeof(float);
 #define NNJ_IA(NG)                                                                                          \
   case NG:                                                                                                  \
     if (int rc = set_lds(h, k_inc_alpha16<NG>, lds)) return rc;                                             \
@@ -399,7 +399,7 @@ int launch_pair_scores(nnj_handle* h, const RowSet& rs, const int* ij_prev, cons
       if (n <= 16) {
         // 16-pair tiles: half the padding of the 32-pair kernels (measured 2x faster here); above 16 rows the
         // group barriers of the shared image cost more than the padding saves
-        const size_t lds = (size_t)(2 * IMG64 + T16_WAVES * 512 * NPL + 16) * sizeof(float);
+        const size_t lds = (size_t)(3 * IMG64 + T16_WAVES * 512 * NPL + 16) * sizeof(float);
         if (has_ctx) {
           if (int rc = set_lds(h, k_inc_score16<1, true>, lds)) return rc;
           hipLaunchKernelGGL((k_inc_score16<1, true>), grid, blk16, lds, st, rs, sw, ij_prev, base + w.alpha, mask,
@@ -410,17 +410,17 @@ int launch_pair_scores(nnj_handle* h, const RowSet& rs, const int* ij_prev, cons
                              base + w.score_part, n, C, g.cs);
         }
       } else if (n > 32 && n <= 48) {                      // three 16-row tiles: 48 instead of 64 padded pairs
-        const size_t lds = (size_t)(2 * IMG64 + 4 * IMG64 + 16) * sizeof(float);
+        const size_t lds = (size_t)(3 * IMG64 + 4 * IMG64 + 16) * sizeof(float);
         if (int rc = set_lds(h, k_inc_score16<3, true>, lds)) return rc;
         hipLaunchKernelGGL((k_inc_score16<3, true>), grid, blk16, lds, st, rs, sw, ij_prev, base + w.alpha, mask,
                            base + w.score_part, n, C, g.cs);
       } else if (n > 32) {
-        const size_t lds = (size_t)(2 * b6_floats(64, 64) + 4 * b6_floats(64, 64) + 16) * sizeof(float);
+        const size_t lds = (size_t)(3 * IMG64 + 4 * b6_floats(64, 64) + 16) * sizeof(float);
         if (int rc = set_lds(h, k_inc_score<2, true>, lds)) return rc;
         hipLaunchKernelGGL((k_inc_score<2, true>), grid, dim3(512), lds, st, rs, sw, ij_prev, base + w.alpha, mask,
                            base + w.score_part, n, C, g.cs);
       } else {
-        const size_t lds = (size_t)(2 * b6_floats(64, 64) + 8 * b6_floats(64, 32) + 16) * sizeof(float);
+        const size_t lds = (size_t)(3 * IMG64 + 8 * b6_floats(64, 32) + 16) * sizeof(float);
         if (int rc = set_lds(h, k_inc_score<1, true>, lds)) return rc;
         hipLaunchKernelGGL((k_inc_score<1, true>), grid, dim3(512), lds, st, rs, sw, ij_prev, base + w.alpha, mask,
                            base + w.score_part, n, C, g.cs);

@@ -361,7 +361,7 @@ __device__ __forceinline__ IncLane inc_lane(const RowSet& rs, const int* ij_prev
   return L;
 }
 template <int NT>
-struct IncRaw { f32x16 sr[NT][2], ur[NT][2]; };      // this lane's rows (prefetched one site ahead)
+struct IncRaw { f32x16 sr[NT][2], ur[NT][2]; };      // this lane's row (sr prefetched one site ahead; ur = W_h sr recomputed)
 struct IncShared { f32x16 sm[2], um[2]; };            // the merged row m (same for all lanes; loaded just in time)
 
 __device__ __forceinline__ void inc_load_shared(IncShared& sh, const RowSet& rs, const IncLane& L, size_t bo, int C,
@@ -379,7 +379,6 @@ __device__ __forceinline__ void inc_load(IncRaw<NT>& raw, const RowSet& rs, cons
     // lanes beyond the live rows read row 0 (slot_r is clamped) and are NOT zeroed: their pairs are never
     // used, and as image rows/columns they only ever meet attention weights that are exactly 0
     load_token64(raw.sr[nt], rs.S + o, true, hh);
-    load_token64(raw.ur[nt], rs.U + o, true, hh);
   }
 }
 // x = z*x_i + (1-z)*x_j with (i,j) = sort(m, r), z = sigmoid(U_i - U_j + b)  (model.py:105-108, 186-197).
@@ -435,21 +434,23 @@ __global__ __launch_bounds__(512) void k_inc_score(RowSet rs, ScorerW w, const i
                                                    const uint8_t* __restrict__ mask,
                                                    float* __restrict__ score_part, int n, int C, int cs) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* Wg_l = smem;                                      // bf16x6 images
-  float* S0_l = smem + b6_floats(64, 64);
+  float* Wg_l = smem;                                      // operand images
+  float* S0_l = smem + IMG64;
+  float* Wh_l = smem + 2 * IMG64;
   const int tid = threadIdx.x, lane = tid & 63, hh = lane >> 5, tok = lane & 31;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   constexpr int NSLOT = 8 / KT;                            // sites in flight per workgroup
   const int slot = wave % NSLOT, tl = wave / NSLOT;        // tl: which 32 rows of the image this wave holds
   constexpr int TCH = 4 * KT;                              // 16-byte chunks per image row
   constexpr int IMG = b6_floats(64, 32 * KT);
-  float* img_t = smem + 2 * b6_floats(64, 64) + slot * IMG;
-  int* cnt = reinterpret_cast<int*>(smem + 2 * b6_floats(64, 64) + NSLOT * IMG) + slot;
+  float* img_t = smem + 3 * IMG64 + slot * IMG;
+  int* cnt = reinterpret_cast<int*>(smem + 3 * IMG64 + NSLOT * IMG) + slot;
   const int sc = blockIdx.x, b = blockIdx.y;
   const int c0 = sc * cs, c1 = min(C, c0 + cs);
   stage_weight_b6<64>(Wg_l, w.Wg, 64, tid, 512);
   stage_weight_b6<64>(S0_l, w.S0, 64, tid, 512);
-  if (tid < NSLOT) reinterpret_cast<int*>(smem + 2 * b6_floats(64, 64) + NSLOT * IMG)[tid] = 0;
+  stage_weight_b6<64>(Wh_l, w.Wh, 64, tid, 512);
+  if (tid < NSLOT) reinterpret_cast<int*>(smem + 3 * IMG64 + NSLOT * IMG)[tid] = 0;
   __syncthreads();
   int epoch = 0;
   const IncLane L = inc_lane<1>(rs, ij_prev, b, n, lane, 32 * tl);
@@ -478,29 +479,56 @@ __global__ __launch_bounds__(512) void k_inc_score(RowSet rs, ScorerW w, const i
     }
     f32x16 x[1][2];
     {
+      // fp16 pieces of S_r: the B operand of U_r = W_h S_r (recomputed on the idle matrix pipe: the cached U rows
+      // were half of the kernel's HBM reads) and, transposed, the columns of the image -- written before the gate
+      // so that the pieces are dead by then
+      Frag3 sf[4];
+      static_for<0, 4>([&](auto ki) {
+        constexpr int ks = decltype(ki)::value;
+        split8<8 * (ks & 1)>(sf[ks], raw.sr[0][ks >> 1]);
+      });
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int k = 0; k < 16; ++k) raw.ur[0][mt][k] = 0.f;
+      const u32x4* wh4 = reinterpret_cast<const u32x4*>(Wh_l);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+          const int wrow = 32 * mt + tok;
+          const int o = wrow * 8 + wswz6<8>(wrow, 2 * ks + hh);
+          Frag3 a;
+          a.h = wh4[o]; a.m = wh4[64 * 8 + o];
+          raw.ur[0][mt] = mfma_b6(a, sf[ks], raw.ur[0][mt]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if constexpr (CTX) {
+        if constexpr (KT == 2) pair_barrier_lds(cnt, epoch);   // the partner is done with the previous site's image
+        unsigned short* t16 = reinterpret_cast<unsigned short*>(img_t);
+        constexpr int PL = 64 * 32 * KT;                       // plane stride in fp16 elements
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+          for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int pr = 0; pr < 2; ++pr) {
+              const unsigned h = sf[2 * mt + (g >> 1)].h[2 * (g & 1) + pr], m = sf[2 * mt + (g >> 1)].m[2 * (g & 1) + pr];
+              const int d0 = 32 * mt + 8 * g + 4 * hh + 2 * pr, d1 = d0 + 1;
+              const int o0 = d0 * (32 * KT) + 8 * wswz6<TCH>(d0, q) + e, o1 = d1 * (32 * KT) + 8 * wswz6<TCH>(d1, q) + e;
+              t16[o0] = (unsigned short)h; t16[o1] = (unsigned short)(h >> 16);
+              t16[PL + o0] = (unsigned short)m; t16[PL + o1] = (unsigned short)(m >> 16);
+            }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    {
       IncShared sh;
       inc_load_shared(sh, rs, L, bo, C, c, hh);
       inc_gate<1>(x, raw, sh, L, w.bh, hh);
     }
-    if constexpr (CTX) {
-      if constexpr (KT == 2) pair_barrier_lds(cnt, epoch);   // the partner is done with the previous site's image
-      unsigned short* t16 = reinterpret_cast<unsigned short*>(img_t);
-      constexpr int PL = 64 * 32 * KT;                       // plane stride in bf16 elements
-#pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-#pragma unroll
-          for (int pr = 0; pr < 2; ++pr) {
-            unsigned h, m;
-            split2(raw.sr[0][mt][4 * g + 2 * pr], raw.sr[0][mt][4 * g + 2 * pr + 1], h, m);
-            const int d0 = 32 * mt + 8 * g + 4 * hh + 2 * pr, d1 = d0 + 1;
-            const int o0 = d0 * (32 * KT) + 8 * wswz6<TCH>(d0, q) + e, o1 = d1 * (32 * KT) + 8 * wswz6<TCH>(d1, q) + e;
-            t16[o0] = (unsigned short)h; t16[o1] = (unsigned short)(h >> 16);
-            t16[PL + o0] = (unsigned short)m; t16[PL + o1] = (unsigned short)(m >> 16);
-          }
-      if constexpr (KT == 2) pair_barrier_lds(cnt, epoch);   // all 64 columns are in the image
-    }
+    if constexpr (CTX && KT == 2) pair_barrier_lds(cnt, epoch);   // all 64 columns are in the image
     const float mc = (mask && mask[(size_t)b * C + c]) ? 0.f : 1.f;     // seq_mask (model.py:96)
     const int cn = c + NSLOT;
     inc_load<1>(raw, rs, L, bo, n, C, cn < c1 ? cn : c, hh);           // prefetch behind the MFMAs (last: harmless reload)
@@ -532,7 +560,7 @@ __global__ __launch_bounds__(512) void k_inc_score(RowSet rs, ScorerW w, const i
   }
   // one partial set per WORKGROUP: the slots' sums meet in LDS (the images are dead) and are added in slot order
   __syncthreads();
-  float* red = smem + 2 * b6_floats(64, 64);              // [NSLOT][64]
+  float* red = smem + 3 * IMG64;                           // [NSLOT][64]
   if (hh == 0) red[slot * 64 + r] = score;
   if (KT == 1 && lane >= 32) red[slot * 64 + lane] = 0.f;  // pair rows 32..63 have no wave
   __syncthreads();

@@ -68,14 +68,16 @@ __global__ __launch_bounds__(64 * T16_WAVES) void k_inc_alpha16(RowSet rs, Score
   constexpr int NSLOT = T16_WAVES / NG;
   constexpr int IMG = 16 * NG * 64 * NPL / 2;              // floats of an image
   float* At_l = smem;                                      // A^T, IMG64 floats
+  float* Wh_l = smem + IMG64;                              // W_h
   const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, kq = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int slot = wave % NSLOT, tl = wave / NSLOT;
-  float* img = smem + IMG64 + slot * IMG;
-  int* cnt0 = reinterpret_cast<int*>(smem + IMG64 + NSLOT * IMG);
+  float* img = smem + 2 * IMG64 + slot * IMG;
+  int* cnt0 = reinterpret_cast<int*>(smem + 2 * IMG64 + NSLOT * IMG);
   const int sc = blockIdx.x, b = blockIdx.y;
   const int c0 = sc * cs, c1 = min(C, c0 + cs);
   stage_weight_t16(At_l, w.A, 64, tid, 64 * T16_WAVES, true);
+  stage_weight_t16(Wh_l, w.Wh, 64, tid, 64 * T16_WAVES);
   if (tid < NSLOT) cnt0[tid] = 0;
   __syncthreads();
   int* cnt = cnt0 + slot;
@@ -83,7 +85,6 @@ __global__ __launch_bounds__(64 * T16_WAVES) void k_inc_alpha16(RowSet rs, Score
   const Inc16 L = inc16(rs, ij_prev, b, n, 16 * tl + l15);
   const size_t bo = (size_t)b * rs.bstride;
   const float* Sr = rs.S + bo + (size_t)L.slot_r * C * 64;
-  const float* Ur = rs.U + bo + (size_t)L.slot_r * C * 64;
   const float* Sm = rs.S + bo + (size_t)L.slot_m * C * 64;
   const float* Um = rs.U + bo + (size_t)L.slot_m * C * 64;
   f32x4 acc[NG];
@@ -91,31 +92,49 @@ __global__ __launch_bounds__(64 * T16_WAVES) void k_inc_alpha16(RowSet rs, Score
   for (int mt = 0; mt < NG; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
   u32x4* im4 = reinterpret_cast<u32x4*>(img);
   constexpr int PL = 16 * NG * 8;
-  V64 sr, ur;
+  V64 sr;
   int c = c0 + slot;
-  if (c < c1) { load_v64(sr, Sr + (size_t)c * 64, kq); load_v64(ur, Ur + (size_t)c * 64, kq); }
+  if (c < c1) load_v64(sr, Sr + (size_t)c * 64, kq);
   for (; c < c1; c += NSLOT) {
     asm volatile("" ::: "memory");
     V64 x;
+    // The fp16 pieces of S_r serve twice: as this row of the image and as the B operand of U_r = W_h S_r, which
+    // is recomputed here (24 MFMAs on an idle pipe) instead of being read: the kernel is HBM bound and the
+    // cached U rows were half of its traffic.  (U_m, one row per site, is still read.)
+    Frag3 sf[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) split_8(sf[ks], sr.t[2 * ks], sr.t[2 * ks + 1]);
     {
-      V64 sm, um;
+      V64 sm, um, ur;
       load_v64(sm, Sm + (size_t)c * 64, kq);
       load_v64(um, Um + (size_t)c * 64, kq);
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) ur.t[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      const u32x4* wh4 = reinterpret_cast<const u32x4*>(Wh_l);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+          const int row = 16 * mt + l15;
+          const int o = row * 8 + wswz6<8>(row, 4 * ks + kq);
+          Frag3 a;
+          a.h = wh4[o]; a.m = wh4[64 * 8 + o];
+          ur.t[mt] = mfma16_b6(a, sf[ks], ur.t[mt]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
       gate16(x, sr, ur, sm, um, w.bh, L.sgn, kq);
     }
     if constexpr (NG > 1) group_barrier_lds<NG>(cnt, epoch);     // everyone is done with the previous image
     // row r of the image: chunk 4*ks + kq = this lane's tiles 2ks, 2ks+1
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      Frag3 f;
-      split_8(f, sr.t[2 * ks], sr.t[2 * ks + 1]);
       const int o = L.r * 8 + wswz6<8>(L.r, 4 * ks + kq);
-      im4[o] = f.h; im4[PL + o] = f.m;
+      im4[o] = sf[ks].h; im4[PL + o] = sf[ks].m;
     }
     if constexpr (NG > 1) group_barrier_lds<NG>(cnt, epoch);     // all rows are in the image
     const int cn = c + NSLOT < c1 ? c + NSLOT : c;               // prefetch behind the MFMAs (last: harmless reload)
     load_v64(sr, Sr + (size_t)cn * 64, kq);
-    load_v64(ur, Ur + (size_t)cn * 64, kq);
     V64 xp;
     linear_t16<4, false>(xp.t, x, At_l, nullptr, lane);          // x' = A^T x
     linear_t16<NG, true>(acc, xp, img, nullptr, lane);           // acc[r'][pair] += S_r' . x'
@@ -123,7 +142,7 @@ __global__ __launch_bounds__(64 * T16_WAVES) void k_inc_alpha16(RowSet rs, Score
   // one partial set per WORKGROUP: the slots add their tiles into one LDS tile [64 pairs][64 r'] in slot order
   // (fixed order: bitwise reproducible), the images are dead by then
   __syncthreads();
-  float* red = smem + IMG64;                               // 4096 floats (NSLOT * IMG >= 12288)
+  float* red = smem + 2 * IMG64;                           // 4096 floats (NSLOT * IMG >= 12288)
   for (int i = tid; i < 4096; i += 64 * T16_WAVES) red[i] = 0.f;
   __syncthreads();
   for (int s_ = 0; s_ < NSLOT; ++s_) {
@@ -162,22 +181,23 @@ __global__ __launch_bounds__(64 * T16_WAVES) void k_inc_score16(RowSet rs, Score
   constexpr int IMG = 64 * 16 * NC * NPL / 2;              // floats of an image
   float* Wg_l = smem;
   float* S0_l = smem + IMG64;
+  float* Wh_l = smem + 2 * IMG64;
   const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, kq = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int slot = wave % NSLOT, tl = wave / NSLOT;
-  float* img = smem + 2 * IMG64 + slot * IMG;
+  float* img = smem + 3 * IMG64 + slot * IMG;
   const int sc = blockIdx.x, b = blockIdx.y;
   const int c0 = sc * cs, c1 = min(C, c0 + cs);
   stage_weight_t16(Wg_l, w.Wg, 64, tid, 64 * T16_WAVES);
   stage_weight_t16(S0_l, w.S0, 64, tid, 64 * T16_WAVES);
+  stage_weight_t16(Wh_l, w.Wh, 64, tid, 64 * T16_WAVES);
   if constexpr (NG == 3) {                                 // columns 48..63 are never written: they meet alpha = 0 but must be finite
-    for (int i = tid; i < NSLOT * IMG; i += 64 * T16_WAVES) smem[2 * IMG64 + i] = 0.f;
+    for (int i = tid; i < NSLOT * IMG; i += 64 * T16_WAVES) smem[3 * IMG64 + i] = 0.f;
   }
   __syncthreads();
   const Inc16 L = inc16(rs, ij_prev, b, n, 16 * tl + l15);
   const size_t bo = (size_t)b * rs.bstride;
   const float* Sr = rs.S + bo + (size_t)L.slot_r * C * 64;
-  const float* Ur = rs.U + bo + (size_t)L.slot_r * C * 64;
   const float* Sm = rs.S + bo + (size_t)L.slot_m * C * 64;
   const float* Um = rs.U + bo + (size_t)L.slot_m * C * 64;
   const float* ap = alpha + ((size_t)b * 64 + L.r) * 64 + 8 * kq;
@@ -198,9 +218,8 @@ __global__ __launch_bounds__(64 * T16_WAVES) void k_inc_score16(RowSet rs, Score
     const int c = act ? c_ : c1 - 1;
     // no register prefetch of the next site: three waves per SIMD hide the row loads, and the 32 registers
     // would push the kernel over the 168 of that occupancy
-    V64 sr, ur;
+    V64 sr;
     load_v64(sr, Sr + (size_t)c * 64, kq);
-    load_v64(ur, Ur + (size_t)c * 64, kq);
     // alpha[pair][r'] of this lane's pair, k-slot 8kq + j of k-step ks = r' = 32ks + 8kq + j (exactly 0 beyond
     // the live rows): issued first, it lands behind the gate and the image
     f32x4 al[KSX][2];
@@ -212,10 +231,30 @@ __global__ __launch_bounds__(64 * T16_WAVES) void k_inc_score16(RowSet rs, Score
       }
     }
     V64 x;
+    // fp16 pieces of S_r: B operand of U_r = W_h S_r (recomputed: the cached U rows were half of the kernel's HBM
+    // reads) and, transposed, the columns of the image
+    Frag3 sf[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) split_8(sf[ks], sr.t[2 * ks], sr.t[2 * ks + 1]);
     {
-      V64 sm, um;
+      V64 sm, um, ur;
       load_v64(sm, Sm + (size_t)c * 64, kq);
       load_v64(um, Um + (size_t)c * 64, kq);
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) ur.t[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      const u32x4* wh4 = reinterpret_cast<const u32x4*>(Wh_l);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+          const int row = 16 * mt + l15;
+          const int o = row * 8 + wswz6<8>(row, 4 * ks + kq);
+          Frag3 a;
+          a.h = wh4[o]; a.m = wh4[64 * 8 + o];
+          ur.t[mt] = mfma16_b6(a, sf[ks], ur.t[mt]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
       gate16(x, sr, ur, sm, um, w.bh, L.sgn, kq);
     }
     if constexpr (CTX) {
@@ -224,8 +263,7 @@ __global__ __launch_bounds__(64 * T16_WAVES) void k_inc_score16(RowSet rs, Score
       for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
         for (int pr = 0; pr < 2; ++pr) {
-          unsigned h, m;
-          split2(sr.t[mt][2 * pr], sr.t[mt][2 * pr + 1], h, m);
+          const unsigned h = sf[mt >> 1].h[2 * (mt & 1) + pr], m = sf[mt >> 1].m[2 * (mt & 1) + pr];
           const int d0 = 16 * mt + 4 * kq + 2 * pr, d1 = d0 + 1;
           const int o0 = d0 * RL + 8 * tswz<NC>(d0, wchunk) + we, o1 = d1 * RL + 8 * tswz<NC>(d1, wchunk) + we;
           t16[o0] = (unsigned short)h; t16[o1] = (unsigned short)(h >> 16);
@@ -282,7 +320,7 @@ __global__ __launch_bounds__(64 * T16_WAVES) void k_inc_score16(RowSet rs, Score
   }
   // one partial set per WORKGROUP: the slots' sums meet in LDS (the images are dead) and are added in slot order
   __syncthreads();
-  float* red = smem + 2 * IMG64;                           // [NSLOT][64]
+  float* red = smem + 3 * IMG64;                           // [NSLOT][64]
   if (16 * NG < 64 && tl == 0) red[slot * 64 + lane] = 0.f;                 // pair rows without a wave
   __syncthreads();
   if (kq == 0) red[slot * 64 + L.r] = score;
