@@ -64,9 +64,9 @@ def kernel_models(B, T, L, layers):
     m["k_pair_score"] = dict(flops=B * P * C * (2.0 * T * D + 4.0 * D * D + 2.0 * D), bytes=B * 2.0 * T * row, peak=X6)
     ns = list(range(T - 1, 1, -1))
     m["k_pair_alpha_incr"] = dict(flops=B * sum(n * C * (4.0 * D * D + 2.0 * n * D) for n in ns if n > 2) / max(1, len([n for n in ns if n > 2])),
-                                  bytes=B * sum(2.0 * n * row for n in ns) / len(ns), peak=X6)
+                                  bytes=B * sum((n + 1.0) * row for n in ns) / len(ns), peak=X6)
     m["k_pair_score_incr"] = dict(flops=B * sum(n * C * (2.0 * n * D + 4.0 * D * D + 2.0 * D) for n in ns) / len(ns),
-                                  bytes=B * sum(2.0 * n * row for n in ns) / len(ns), peak=X6)
+                                  bytes=B * sum((n + 1.0) * row for n in ns) / len(ns), peak=X6)
     return m
 
 
@@ -103,6 +103,8 @@ def main():
     ap.add_argument("--taxa", type=int, default=50)
     ap.add_argument("--sites", type=int, default=1024)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-single-msa", action="store_true",
+                    help="skip the Batch=1 latency figure (keeps a rocprofv3 summary of this command to the timed workload)")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel HIP events")
     args = ap.parse_args()
 
@@ -229,7 +231,7 @@ def main():
                                            "algorithmic_bytes_per_rollout": step_bytes, "achieved": gbs,
                                            "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS}
         out["roofline"] = roof
-        if world == 1:
+        if world == 1 and not args.no_single_msa:
             # BASELINE configs[1] beside the batched figure: ONE 50 x 1024 alignment per rollout (latency bound)
             one = codes[:1].contiguous()
             g.profile_enable(False)

@@ -23,8 +23,8 @@ def build_hip(force: bool = False, verbose: bool = False) -> str:
     if not force and not _stale():
         return LIB
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    # No -ffast-math (nor -fassociative-math): the bf16x6 operand split relies on exact IEEE subtractions
-    # (x - bf16(x) ...); with reassociation the pieces no longer add up and the parity tests fail at 4e-4.
+    # No -ffast-math (nor -fassociative-math): the f16x3 operand split relies on exact IEEE subtractions
+    # (x - fp16(x)); with reassociation the pieces no longer add up and the parity tests fail at 4e-4.
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
            "-Wno-unused-value", "-o", LIB] + SOURCES
     if verbose:

@@ -306,7 +306,7 @@ __device__ __forceinline__ void barrier_nofence() {
 __device__ __forceinline__ void pin_frag(Frag3& f) {
   pin_after_wait(f.h); pin_after_wait(f.m);
 }
-// LDS weight image for the bf16x6 layers: three planes (h, m, l) of [rows][IN] bf16.  Within a row the
+// LDS weight image for the f16x3 layers: two planes (h, m) of [rows][IN] fp16.  Within a row the
 // in-features are permuted so that the eight a lane needs for one k-step are one 16-byte chunk:
 // chunk q = 4*kt + 2*G + hh holds features 32kt + 16G + 8j + 4hh + t (j = 0,1; t = 0..3) in order
 // (j, t); chunks are XOR-swizzled by row & 7 (ds_read_b128 of 32 rows x 2 chunks: conflict free).
@@ -459,7 +459,7 @@ __device__ __forceinline__ void linear6_T_acc(f32x16 (&out)[NT][MT], const f32x1
 }
 
 // ---- 16-token tiles.  lane = (token l&15, feature quarter kq = l>>4); a 64-feature vector is four f32x4 tiles,
-// element r of tile mt = feature 16*mt + 4*kq + r -- the C/D layout of v_mfma_f32_16x16x32_bf16 -- so a tensor
+// element r of tile mt = feature 16*mt + 4*kq + r -- the C/D layout of v_mfma_f32_16x16x32_f16 -- so a tensor
 // costs 16 registers per lane (32 with the 32-token tiles): kernels whose dependency chains are latency bound
 // run three or four waves per SIMD on it.  The B operand of k-step ks (32 features) is tiles 2ks, 2ks+1:
 // k-slot 8*kq + 4*u + r = feature 32*ks + 16*u + 4*kq + r; weight images store their columns in that order.
@@ -487,7 +487,7 @@ __device__ __forceinline__ void load_v64(V64& v, const float* p, int kq) {
 #pragma unroll
   for (int mt = 0; mt < 4; ++mt) v.t[mt] = *reinterpret_cast<const f32x4*>(p + 16 * mt + 4 * kq);
 }
-// LDS image of a [rows][64] fp32 matrix for the 16-token linears: three planes of [rows][8 chunks of 16 B],
+// LDS image of a [rows][64] fp32 matrix for the 16-token linears: two planes of [rows][8 chunks of 16 B],
 // chunk q = 4*ks + kg holds in-features 32ks + 16u + 4kg + r in (u, r) order, XOR-swizzled like the 32-token
 // images (a ds_read_b128 of 16 rows x 4 chunks is conflict free).
 __device__ __forceinline__ void stage_weight_t16(float* lds, const float* __restrict__ g, int rows, int tid,

@@ -7,7 +7,7 @@
 //
 //   k_embed     : embed (6-entry LUT of the site codes, or the embed MLP on float input) -> x
 //   k_tok1/1p   : ctx -> out_proj -> +x ; LN -> q,k,v -> column attention -> out_proj -> +x
-//   k_ffn16     : LN -> fc1 -> GELU -> fc2 -> +x   (persistent, flat token tiling, 16-token tiles, bf16x6)
+//   k_ffn16     : LN -> fc1 -> GELU -> fc2 -> +x   (persistent, flat token tiling, 16-token tiles, f16x3)
 // The tied row attention (q,k,v projections, scores, context) lives in nnj_rowattn.hpp.
 //
 // HBM layouts: x [B,R,C,64]; ctx head-major [B,8,C,Epad] with e = r*8 + d, Epad = roundup(R*8,16).

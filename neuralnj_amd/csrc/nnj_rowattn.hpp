@@ -1,14 +1,13 @@
-// nnj_rowattn.hpp -- tied row attention of the MSA encoder on the bf16 matrix pipe
+// nnj_rowattn.hpp -- tied row attention of the MSA encoder on the fp16 matrix pipe
 // (restates reference axial_attention.py:6-138: q,k,v projections, q scaling and padding,
 //  attention over the C alignment columns with head dimension E = R*8, softmax over keys).
 //
 // The attention of one (batch element, head) is two fp32-accurate GEMMs with contraction lengths
-// E = 8R (scores) and C (context).  Both run as "bf16x6" (nnj_common.hpp): operands stored as three
-// bf16 planes, six piece products per fp32 product, fp32 accumulation.  A flash-style single kernel
-// would have to keep a query block stationary at 6 bytes per element (77 KiB per 32 queries at R = 50),
-// which neither the register file nor the LDS holds at a useful block size; the scores therefore make
-// one round trip through HBM (288 GB; 8.6 GB per layer at B = 256, C = 1024), which costs ~2 ms of
-// bandwidth per layer next to ~10 ms of matrix work:
+// E = 8R (scores) and C (context).  Both run as "f16x3" (nnj_common.hpp): operands stored as two
+// fp16 planes, three piece products per fp32 product, fp32 accumulation.  A flash-style single kernel
+// would have to keep a query block stationary at 4 bytes per element (51 KiB per 32 queries at R = 50)
+// next to its 208 context accumulators, or re-stream K and V per small query block; the scores therefore
+// make one round trip through HBM (288 GB; 8.6 GB per layer at B = 256, C = 1024):
 //
 //   k_qkv6    LN -> q,k,v projections -> Q6, K6 (row-major operand tiles) and V6 (transposed operand tiles),
 //             already split into planes and already in the LDS image order of the consumers
@@ -16,11 +15,11 @@
 //             written as 32x32 C-layout register images + per-tile row maxima
 //   k_row_pv  per 128 queries: P = exp(S - max) (split in registers), O^T = V^T P^T, ctx = O / sum(P)
 //
-// Operand tile ("A tile"): [3 planes][rows][16 k] bf16 = 32 bytes per row and plane; the two 16-byte
+// Operand tile ("A tile"): [2 planes][rows][16 k] fp16 = 32 bytes per row and plane; the two 16-byte
 // halves of a row (k-slots 0-7, 8-15) are stored swapped when bit 3 of the row index is set, which makes
 // the ds_read_b128 of 32 rows x one half conflict free (16 lanes of a read group hit 16 different
 // 16-byte slots).  One MFMA k-step consumes one tile row per lane: lane (row r, half HH) reads its 8
-// bf16 with one ds_read_b128 per plane.
+// fp16 with one ds_read_b128 per plane.
 //   Q6/K6: [bh][ks][row block of 256][plane][256 rows c][32 B]   k-slot 8*(r&1) + d, e = 8r + d, ks = r>>1
 //   V6   : [bh][k16][plane][ET*32 rows e][32 B]                  k-slot 8*HH + 4*jj + t for key
 //                                                                 16*k16 + 8*jj + 4*HH + t
@@ -85,7 +84,7 @@ __global__ __launch_bounds__(512) void k_qkv6(const float* __restrict__ x, const
                                               uint8_t* __restrict__ Q6, uint8_t* __restrict__ K6,
                                               uint8_t* __restrict__ V6, Ra6 g, int B) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* Wl = smem;                          // one bf16x6 image [Wq | Wk | Wv] of 192 rows: y is split once
+  float* Wl = smem;                          // one f16x3 image [Wq | Wk | Wv] of 192 rows: y is split once
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5;
   stage_weight_b6<64>(Wl, wn.Wq, 64, tid, 512, 0, 192);
   stage_weight_b6<64>(Wl, wn.Wk, 64, tid, 512, 64, 192);
@@ -181,16 +180,14 @@ __global__ __launch_bounds__(512) void k_qkv6(const float* __restrict__ x, const
 }
 
 // ------------------------------------------------------------------ k_row_s
-// S^T block [256 keys x 256 queries] of one (b, h): 4 waves, wave = 128 keys x 128 queries = 4x4 MFMA tiles
-// (256 accumulator registers), contraction over the KS operand tiles of 16.  Operand tiles stream
-// HBM/L2 -> LDS by LDS-DMA into a three-stage ring (stage = K tile 24 KiB | Q tile 24 KiB); fragments are
-// read with hand-issued ds_read_b128 (the compiler would drain the in-flight DMA before reads of its own);
-// the B fragment of query tile j+1 is in flight behind the 24 MFMAs of group j.  One workgroup barrier per
-// k-step (96 MFMAs per wave).
-// QW = queries per workgroup: 256 (wave = 128 keys x 128 queries, 256 accumulator registers, one
-// workgroup per CU, three-stage ring) or 128 (wave = 128 x 64, 128 accumulator registers, two-stage ring
-// of 36 KiB stages: TWO workgroups per CU, which are not synchronised with each other -- one computes while
-// the other issues DMA pieces, waits at its barrier or stores its tiles).
+// S^T block [256 keys x QW queries] of one (b, h): 4 waves, wave = 128 keys x QW/2 queries = 4 x QW/64 MFMA
+// tiles, contraction over the KS operand tiles of 16.  Operand tiles stream HBM/L2 -> LDS by LDS-DMA into a
+// three-stage ring (stage = K tile 16 KiB | Q tile QW/16 KiB); fragments are read with hand-issued ds_read_b128
+// (the compiler would drain the in-flight DMA before reads of its own); the B fragment of query tile j+1 is in
+// flight behind the 12 MFMAs of group j.  One workgroup barrier per k-step.
+// QW = 128 is the instantiation used (wave = 128 x 64, 128 accumulator registers, three 24-KiB stages): TWO
+// workgroups per CU, which are not synchronised with each other -- one computes while the other issues DMA
+// pieces, waits at its barrier or stores its tiles.
 template <int QW>
 struct RsShape {
   static constexpr int NJ = QW / 64;                                 // query tiles per wave

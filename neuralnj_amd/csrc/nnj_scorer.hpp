@@ -91,7 +91,7 @@ __device__ __forceinline__ void site_store(const SiteRegs<NTHR>& R, float* img_a
     *reinterpret_cast<f32x4*>(img_s + r * 64 + sw) = R.s[k];
     *reinterpret_cast<f32x4*>(img_u + r * 64 + sw) = R.u[k];
     if (WITH_A) {
-      // K' as a bf16x6 A image [3 planes][64 rows r][64 d] (the layout of stage_weight_b6): this thread's four
+      // K' as an f16x3 A image [2 planes][64 rows r][64 d] (the layout of stage_weight_b6): this thread's four
       // features d = 4ch..4ch+3 are one half of chunk q = 4*kt + 2*G + hh  (d = 32kt + 16G + 8j + 4hh + t)
       const int q = 4 * (ch >> 3) + 2 * ((ch >> 2) & 1) + (ch & 1), j = (ch >> 1) & 1;
       unsigned h01, m01, h23, m23;
@@ -102,7 +102,7 @@ __device__ __forceinline__ void site_store(const SiteRegs<NTHR>& R, float* img_a
       img[64 * 8 * 2] = make_uint2(m01, m23);
     }
     if (WITH_T) {
-      // S^T as a bf16x6 A image: [3 planes][64 d][64 r'] bf16, row d = the r' order of stage_weight_b6
+      // S^T as an f16x3 A image: [2 planes][64 d][64 r'] fp16, row d = the r' order of stage_weight_b6
       unsigned short* t16 = reinterpret_cast<unsigned short*>(img_t);
       const int q = 4 * (r >> 5) + 2 * ((r >> 4) & 1) + ((r >> 2) & 1), e = 4 * ((r >> 3) & 1) + (r & 3);
 #pragma unroll
@@ -148,7 +148,7 @@ template <int TPW, int NW>
 __global__ __launch_bounds__(64 * NW) void k_pair_alpha(RowSet rs, ScorerW w, const int* __restrict__ ij_prev,
                                                     float* __restrict__ alpha_part, int mode, int n, int C,
                                                     int npairs, int ppad, int cs) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];   // 2 x [img_k (bf16x6) | img_s | img_u]
+  extern __shared__ __attribute__((aligned(16))) float smem[];   // 2 x [img_k (f16x3) | img_s | img_u]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5;
   const int sc = blockIdx.x, pg = blockIdx.y, b = blockIdx.z;
   const int c0 = sc * cs, c1 = min(C, c0 + cs);
@@ -251,7 +251,7 @@ __global__ __launch_bounds__(64 * NW) void k_pair_score(RowSet rs, ScorerW w, co
                                                     const uint8_t* __restrict__ mask,
                                                     float* __restrict__ score_part, int mode, int n, int C,
                                                     int npairs, int ppad, int cs, int has_ctx) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];   // Wg | S0 (bf16x6 images) | 2 x [img_t | img_s | img_u]
+  extern __shared__ __attribute__((aligned(16))) float smem[];   // Wg | S0 (f16x3 images) | 2 x [img_t | img_s | img_u]
   float* Wg_l = smem;
   float* S0_l = smem + b6_floats(64, 64);
   float* ring = smem + 2 * b6_floats(64, 64);
@@ -423,7 +423,7 @@ __device__ __forceinline__ void pair_barrier_lds(int* cnt, int& epoch) {
 
 // Phase B: scores of the new pairs.  Eight waves, one 32-pair tile each (two waves per SIMD: the partner
 // wave's MFMAs run beside this wave's VALU work).  The transposed site image S_c^T -- A operand of
-// x_g^T = S_c^T alpha^T, a bf16x6 image [64 d][32*KT r'] -- is written from the rows the lanes hold.
+// x_g^T = S_c^T alpha^T, an f16x3 image [64 d][32*KT r'] -- is written from the rows the lanes hold.
 // KT = 1 (n <= 32): every wave owns whole sites (c = c0 + wave, +8, ...), image private to the wave.
 // KT = 2 (n > 32): waves w and w+4 share site slot w&3 and build the 64-column image together, each the
 // columns of its 32 rows, between two pair barriers on an LDS counter (see k_tok1p).

@@ -7,11 +7,11 @@
 // latency bound at two waves per SIMD, and the 32-token feature-major tile (32 registers per 64-feature
 // vector) leaves no room for a third.  Here a wave owns 16 pairs: lane = (pair l&15, feature quarter
 // kq = l>>4), a 64-feature vector is four f32x4 tiles, element r of tile mt = feature 16*mt + 4*kq + r -- the
-// C/D layout of v_mfma_f32_16x16x32_bf16 -- so every tensor costs 16 registers, twelve waves fit a CU
+// C/D layout of v_mfma_f32_16x16x32_f16 -- so every tensor costs 16 registers, twelve waves fit a CU
 // (three per SIMD) and a step pads its n-1 pairs to a multiple of 16 instead of 32.
 // The B operand of k-step ks (32 features) is tiles 2ks, 2ks+1: k-slot 8*kq + 4*u + r = feature
 // 32*ks + 16*u + 4*kq + r; weight images store their columns in that order (stage_weight_t16).
-// Everything is bf16x6 (nnj_common.hpp).
+// Everything is f16x3 (nnj_common.hpp).
 #pragma once
 #include "nnj_scorer.hpp"
 
@@ -58,7 +58,7 @@ constexpr int T16_WAVES = 12;
 
 // ------------------------------------------------------------------ k_inc_alpha16
 // alpha partials of the new pairs (see k_inc_alpha: (A^T x).S_r, K' never read).  NG waves (16 pairs each)
-// share a site: together they write its 16*NG S rows as a weight-like image [3 planes][16*NG r][64 d] (each
+// share a site: together they write its 16*NG S rows as a weight-like image [2 planes][16*NG r][64 d] (each
 // lane one 16-byte chunk per k-step and plane) and each multiplies its x' with all rows.
 // part[b][sc*NSLOT+slot][pair r][r'].
 template <int NG>
@@ -161,7 +161,7 @@ __global__ __launch_bounds__(64 * T16_WAVES) void k_inc_alpha16(RowSet rs, Score
 }
 
 // ------------------------------------------------------------------ k_inc_score16
-// scores of the new pairs.  The NG waves of a site build its transposed image S^T [3 planes][64 d][16*NG r']
+// scores of the new pairs.  The NG waves of a site build its transposed image S^T [2 planes][64 d][16*NG r']
 // (natural r' order; A operand of x_g^T = S^T alpha^T) together, each the columns of its 16 rows.
 // part[b][sc*NSLOT+slot][pair r].
 template <int NC>                                           // NC = 16-column groups of an image row (1, 2 or 4)
@@ -203,8 +203,8 @@ __global__ __launch_bounds__(64 * T16_WAVES) void k_inc_score16(RowSet rs, Score
   const float* ap = alpha + ((size_t)b * 64 + L.r) * 64 + 8 * kq;
   // column r of the image: chunk r>>3, element r&7
   unsigned short* t16 = reinterpret_cast<unsigned short*>(img);
-  constexpr int RL = 16 * NC;                              // bf16 per image row
-  constexpr int PLH = 64 * RL;                             // plane stride in bf16
+  constexpr int RL = 16 * NC;                              // fp16 per image row
+  constexpr int PLH = 64 * RL;                             // plane stride in fp16
   const int wchunk = 2 * tl + (l15 >> 3), we = l15 & 7;
   const u32x4* im4 = reinterpret_cast<const u32x4*>(img);
   constexpr int PL4 = 64 * CH;                             // plane stride in 16-byte units
