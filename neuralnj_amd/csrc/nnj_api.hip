@@ -409,17 +409,17 @@ int launch_pair_scores(nnj_handle* h, const RowSet& rs, const int* ij_prev, cons
           hipLaunchKernelGGL((k_inc_score16<1, false>), grid, blk16, lds, st, rs, sw, ij_prev, base + w.alpha, mask,
                              base + w.score_part, n, C, g.cs);
         }
-      } else if (n > 32 && n <= 48) {                      // three 16-row tiles: 48 instead of 64 padded pairs
-        const size_t lds = (size_t)(3 * IMG64 + 4 * IMG64 + 16) * sizeof(float);
-        if (int rc = set_lds(h, k_inc_score16<3, true>, lds)) return rc;
-        hipLaunchKernelGGL((k_inc_score16<3, true>), grid, blk16, lds, st, rs, sw, ij_prev, base + w.alpha, mask,
+      } else if (n > 32 && n <= 48) {                      // three 16-row tiles: 48 instead of 64 padded pairs,
+        const size_t lds = (size_t)(3 * IMG64 + 8 * (64 * 48 * NPL / 2)) * sizeof(float);   // one wave per site
+        if (int rc = set_lds(h, k_inc_score_w<3, true>, lds)) return rc;
+        hipLaunchKernelGGL((k_inc_score_w<3, true>), grid, dim3(512), lds, st, rs, sw, ij_prev, base + w.alpha, mask,
                            base + w.score_part, n, C, g.cs);
       } else if (n > 32) {
         const size_t lds = (size_t)(3 * IMG64 + 4 * b6_floats(64, 64) + 16) * sizeof(float);
         if (int rc = set_lds(h, k_inc_score<2, true>, lds)) return rc;
         hipLaunchKernelGGL((k_inc_score<2, true>), grid, dim3(512), lds, st, rs, sw, ij_prev, base + w.alpha, mask,
                            base + w.score_part, n, C, g.cs);
-      } else {
+      } else {                                             // 17..32: the 32-pair kernel (k_inc_score_w<2> measured equal)
         const size_t lds = (size_t)(3 * IMG64 + 8 * b6_floats(64, 32) + 16) * sizeof(float);
         if (int rc = set_lds(h, k_inc_score<1, true>, lds)) return rc;
         hipLaunchKernelGGL((k_inc_score<1, true>), grid, dim3(512), lds, st, rs, sw, ij_prev, base + w.alpha, mask,

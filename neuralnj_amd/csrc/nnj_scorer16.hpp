@@ -1,7 +1,7 @@
-// nnj_scorer16.hpp -- the incremental NJ-step scorer on 16-token tiles: alpha for every n; scores for n <= 16
-// and for 33..48 rows (three tiles = 48 instead of 64 padded pairs).  Measured: with 17..32 and 49..64 rows the
-// group barriers of the shared score image cost more than the padding saves; there the 32-pair kernels of
-// nnj_scorer.hpp are used.
+// nnj_scorer16.hpp -- the incremental NJ-step scorer on 16-token tiles: alpha for every n (k_inc_alpha16); scores
+// for n <= 16 (k_inc_score16<1>: twelve one-tile waves) and for 33..48 rows (k_inc_score_w<3>: one wave per site
+// walks three tiles = 48 instead of 64 padded pairs).  Measured: with 17..32 and 49..64 rows the 32-pair kernels
+// of nnj_scorer.hpp are as fast or faster; there they are used.
 //
 // The per-site dependency chain of the pair scorer (gate -> image -> x_g -> W_g -> mix -> s_out -> GELU) is
 // latency bound at two waves per SIMD, and the 32-token feature-major tile (32 registers per 64-feature
@@ -329,6 +329,181 @@ __global__ __launch_bounds__(64 * T16_WAVES) void k_inc_score16(RowSet rs, Score
     float v = 0.f;
 #pragma unroll
     for (int s_ = 0; s_ < NSLOT; ++s_) v += red[s_ * 64 + tid];
+    score_part[((size_t)b * gridDim.x + sc) * 64 + tid] = v;
+  }
+}
+
+// ------------------------------------------------------------------ k_inc_score_w
+// scores of the new pairs with ONE WAVE PER SITE: the wave walks the NT 16-pair tiles of its site itself, so the
+// site image S^T [2 planes][64 d][16*NT r'] is private to the wave and nothing in the loop synchronises with
+// another wave (k_inc_score16<3> pays two twelve-wave barriers per site).  Eight waves per workgroup (two per
+// SIMD, <= 256 registers): the latency of one tile's chain is covered by the other tiles of the same wave --
+// the phases below are loops over the tiles, i.e. NT independent chains -- and by the second wave.
+// Used for 33..48 rows (NT = 3: 48 instead of 64 padded pairs).  part[b][sc][pair r].
+template <int NT, bool CTX>
+__global__ __launch_bounds__(512) void k_inc_score_w(RowSet rs, ScorerW w, const int* __restrict__ ij_prev,
+                                                     const float* __restrict__ alpha,
+                                                     const uint8_t* __restrict__ mask,
+                                                     float* __restrict__ score_part, int n, int C, int cs) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int NW = 8;
+  constexpr int RL = 16 * NT;                              // fp16 per image row
+  constexpr int CH = 2 * NT;                               // 16-byte chunks per image row (8 r' each)
+  constexpr int KSX = (NT + 1) / 2;                        // k-steps of the x_g GEMM (32 r' each)
+  constexpr int IMG = 64 * RL * NPL / 2;                   // floats of an image
+  constexpr int PLH = 64 * RL;                             // plane stride in fp16
+  constexpr int PL4 = 64 * CH;                             // plane stride in 16-byte units
+  float* Wg_l = smem;
+  float* S0_l = smem + IMG64;
+  float* Wh_l = smem + 2 * IMG64;
+  const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, kq = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  float* img = smem + 3 * IMG64 + wave * IMG;
+  const int sc = blockIdx.x, b = blockIdx.y;
+  const int c0 = sc * cs, c1 = min(C, c0 + cs);
+  stage_weight_t16(Wg_l, w.Wg, 64, tid, 64 * NW);
+  stage_weight_t16(S0_l, w.S0, 64, tid, 64 * NW);
+  stage_weight_t16(Wh_l, w.Wh, 64, tid, 64 * NW);
+  __syncthreads();
+  const size_t bo = (size_t)b * rs.bstride;
+  const float* Sr[NT];
+  const float* ap[NT];
+  float sgn[NT], score[NT];
+  int rr[NT];
+  const float *Sm, *Um;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const Inc16 L = inc16(rs, ij_prev, b, n, 16 * t + l15);
+    Sr[t] = rs.S + bo + (size_t)L.slot_r * C * 64;
+    ap[t] = alpha + ((size_t)b * 64 + L.r) * 64 + 8 * kq;
+    sgn[t] = L.sgn;
+    rr[t] = L.r;
+    score[t] = 0.f;
+    if (t == 0) {
+      Sm = rs.S + bo + (size_t)L.slot_m * C * 64;
+      Um = rs.U + bo + (size_t)L.slot_m * C * 64;
+    }
+  }
+  // chunk swizzle of the image rows: none needed for 96-byte rows (see below), tswz for 32/64/128-byte rows
+  auto wsw = [](int d, int chunk) { if constexpr (NT == 3) return chunk; else return tswz<NT>(d, chunk); };
+  unsigned short* t16 = reinterpret_cast<unsigned short*>(img);
+  const u32x4* im4 = reinterpret_cast<const u32x4*>(img);
+  const u32x4* wh4 = reinterpret_cast<const u32x4*>(Wh_l);
+  for (int c = c0 + wave; c < c1; c += NW) {
+    asm volatile("" ::: "memory");
+    V64 x[NT];
+    {
+      V64 sr[NT], sm, um;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) load_v64(sr[t], Sr[t] + (size_t)c * 64, kq);
+      load_v64(sm, Sm + (size_t)c * 64, kq);
+      load_v64(um, Um + (size_t)c * 64, kq);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        // fp16 pieces of S_r: B operand of U_r = W_h S_r (recomputed, see k_inc_alpha16) and, transposed, the
+        // columns 16t + l15 of the image
+        Frag3 sf[2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) split_8(sf[ks], sr[t].t[2 * ks], sr[t].t[2 * ks + 1]);
+        V64 ur;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) ur.t[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt) {
+            const int row = 16 * mt + l15;
+            const int o = row * 8 + wswz6<8>(row, 4 * ks + kq);
+            Frag3 a;
+            a.h = wh4[o]; a.m = wh4[64 * 8 + o];
+            ur.t[mt] = mfma16_b6(a, sf[ks], ur.t[mt]);
+          }
+        gate16(x[t], sr[t], ur, sm, um, w.bh, sgn[t], kq);
+        if constexpr (CTX) {
+          const int wchunk = 2 * t + (l15 >> 3), we = l15 & 7;
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int pr = 0; pr < 2; ++pr) {
+              const unsigned h = sf[mt >> 1].h[2 * (mt & 1) + pr], m = sf[mt >> 1].m[2 * (mt & 1) + pr];
+              const int d0 = 16 * mt + 4 * kq + 2 * pr, d1 = d0 + 1;
+              const int o0 = d0 * RL + 8 * wsw(d0, wchunk) + we, o1 = d1 * RL + 8 * wsw(d1, wchunk) + we;
+              t16[o0] = (unsigned short)h; t16[o1] = (unsigned short)(h >> 16);
+              t16[PLH + o0] = (unsigned short)m; t16[PLH + o1] = (unsigned short)(m >> 16);
+            }
+        }
+        // bounded live ranges: one tile's pieces at a time, and the weight fragments are re-read per tile (kept
+        // across the tiles they would take 64 registers per matrix)
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    const float mc = (mask && mask[(size_t)b * C + c]) ? 0.f : 1.f;      // seq_mask (model.py:96)
+    // x_g^T = S^T alpha^T, W_g, mix, s_out per tile.  Image rows are 16*NT fp16 (96 bytes at NT = 3: rows d and
+    // d+8 share banks, the 16 lanes of a read group hold 8 distinct d per chunk parity -- conflict free without
+    // a swizzle).  Lanes whose chunk lies beyond a short row read the row's last chunk: finite data against
+    // alpha = 0.
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      if constexpr (CTX) {
+        V64 xg, g;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) xg.t[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KSX; ++ks) {
+          const f32x4 a0 = *reinterpret_cast<const f32x4*>(ap[t] + 32 * ks);
+          const f32x4 a1 = *reinterpret_cast<const f32x4*>(ap[t] + 32 * ks + 4);
+          Frag3 bfr;
+          split_8(bfr, a0, a1);
+          const int lc = min(4 * ks + kq, CH - 1);
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt) {
+            const int d = 16 * mt + l15;
+            const int o = d * CH + wsw(d, lc);
+            Frag3 a;
+            a.h = im4[o]; a.m = im4[PL4 + o];
+            xg.t[mt] = mfma16_b6(a, bfr, xg.t[mt]);
+          }
+        }
+        linear_t16<4, false>(g.t, xg, Wg_l, w.bg, lane);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float wg = sigmoid_l2(g.t[mt][e]);
+            x[t].t[mt][e] += wg * (xg.t[mt][e] - x[t].t[mt][e]);        // (1-w)*x + w*x_g
+          }
+      }
+      V64 s1;
+      linear_t16<4, false>(s1.t, x[t], S0_l, w.s0, lane);
+      float s = 0.f;
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) {
+        const f32x4 w4 = *reinterpret_cast<const f32x4*>(w.s2w + 16 * mt + 4 * kq);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s += gelu_erf(s1.t[mt][e]) * w4[e];
+      }
+      s += __shfl_xor(s, 16);
+      s += __shfl_xor(s, 32);
+      score[t] += (s + w.s2b) * mc;
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  // one partial set per WORKGROUP: the waves' sums meet in LDS (the images are dead) and are added in wave order
+  __syncthreads();
+  float* red = smem + 3 * IMG64;                           // [NW][64]
+  red[wave * 64 + lane] = 0.f;                             // pair rows without a tile
+  __syncthreads();
+  if (kq == 0) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) red[wave * 64 + rr[t]] = score[t];
+  }
+  __syncthreads();
+  if (tid < 64) {
+    float v = 0.f;
+#pragma unroll
+    for (int s_ = 0; s_ < NW; ++s_) v += red[s_ * 64 + tid];
     score_part[((size_t)b * gridDim.x + sc) * 64 + tid] = v;
   }
 }
