@@ -168,6 +168,7 @@ def main():
     prof = {} if args.no_profile else g.profile_read()
     if not args.no_profile:
         g.profile_enable(False)
+    g.check_numeric()                       # outside the timed region: no score table of the run was non-finite
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -159,6 +159,14 @@ int nnj_rollout_sample(nnj_handle* h, const uint8_t* codes_dev, const uint8_t* m
                        int32_t* merges_out_dev, float* logits_trace_dev,
                        void* ws_dev, size_t ws_bytes, void* stream);
 
+/* Numeric guard.  The GEMMs of this library split fp32 operands into two fp16 pieces: operand
+ * magnitudes beyond 65504 overflow to infinity instead of being rounded as fp32 would.  Every pair-score table
+ * the library writes is scanned by the kernel that writes it; a non-finite entry sets a sticky per-handle flag.
+ * nnj_numeric_status synchronises `stream`, returns the flag in *nonfinite_out (1 = some table since the last
+ * call held a non-finite score: results must be discarded) and clears it.  The reference has no counterpart
+ * (it computes in plain fp32); callers that fetch results to the host should call this once per batch. */
+int nnj_numeric_status(nnj_handle* h, int32_t* nonfinite_out, void* stream);
+
 /* Kernel timing for bench.py's roofline object: when enabled, every kernel launch of
  * the entry points is bracketed by a HIP event pair on the launch stream, tagged with
  * its kernel kind.  After the caller has synchronised the stream, nnj_profile_read

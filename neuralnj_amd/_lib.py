@@ -46,6 +46,7 @@ _SIGS = {
     "nnj_profile_kind_name": ([C.c_int32], C.c_char_p),
     "nnj_profile_read": ([_vp, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int32], C.c_int),
     "nnj_debug_encoder_stop": ([_vp, C.c_int32], C.c_int),
+    "nnj_numeric_status": ([_vp, C.POINTER(C.c_int32), _vp], C.c_int),
 }
 
 _lib = None
@@ -255,6 +256,17 @@ class Nnj:
         if want_state:
             out["state"] = st
         return out
+
+    def check_numeric(self):
+        """Synchronises the stream and raises if any pair-score table written since the last call held a
+        non-finite score (an operand left the range of the fp16 pieces, include/nnj.h): call once per batch
+        before trusting merge lists fetched to the host."""
+        flag = C.c_int32(0)
+        self._chk(self.lib.nnj_numeric_status(self.h, C.byref(flag), self._stream()))
+        if flag.value:
+            raise FloatingPointError(
+                "non-finite pair scores: an operand magnitude exceeded the fp16 piece range (65504) of the "
+                "f16x3 GEMMs; the results of this batch are invalid")
 
     def rollout_sample(self, codes, mask, uniforms, temperature=1.0, replicas=None, want_trace=False):
         """Sampled rollouts (NeuralNJ-MC device part).  `uniforms` float [B,T-1] in [0,1).

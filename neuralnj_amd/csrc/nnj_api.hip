@@ -52,6 +52,7 @@ struct nnj_handle {
   float t0 = 0.f, s2b = 0.f;
   int debug_stop = 0;            // encoder debug tap (nnj_debug_encoder_stop)
   int num_cu = 256;              // compute units of the device (persistent-kernel grid size)
+  int* d_flag = nullptr;         // sticky "a pair score was not finite" flag (nnj_numeric_status)
   char err[512] = "";
   // profiling
   bool prof = false;
@@ -535,6 +536,11 @@ int nnj_create(const nnj_config* cfg, nnj_handle** out) {
   nnj_handle* h = new nnj_handle();
   h->cfg = *cfg;
   h->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  if (hipSetDevice(cfg->device) != hipSuccess || hipMalloc(&h->d_flag, sizeof(int)) != hipSuccess ||
+      hipMemset(h->d_flag, 0, sizeof(int)) != hipSuccess) {
+    delete h;
+    return fail(nullptr, NNJ_ERR_HIP, "nnj_create: device allocation failed");
+  }
   *out = h;
   return NNJ_OK;
 }
@@ -543,6 +549,7 @@ int nnj_destroy(nnj_handle* h) {
   if (!h) return NNJ_OK;
   hipSetDevice(h->cfg.device);
   if (h->d_w) hipFree(h->d_w);
+  if (h->d_flag) hipFree(h->d_flag);
   for (hipEvent_t e : h->ev) hipEventDestroy(e);
   delete h;
   return NNJ_OK;
@@ -668,7 +675,8 @@ int nnj_pair_scores_full(nnj_handle* h, const float* state, const uint8_t* mask,
     Scope sc(h, st, PK_ASSEMBLE);
     hipLaunchKernelGGL(k_assemble_argmax, dim3((unsigned)B), dim3(256), 0, st, base + w.score_part, g.nsc, g.ppad,
                        (const float*)nullptr, (const int*)nullptr, logits_out, (float*)nullptr, 0L, (const int*)nullptr,
-                       0L, (int*)nullptr, 0L, (float*)nullptr, 0L, ij, (int)PAIRS_FULL, n, (const float*)nullptr, 0L, 1.0f);
+                       0L, (int*)nullptr, 0L, (float*)nullptr, 0L, ij, (int)PAIRS_FULL, n, (const float*)nullptr, 0L, 1.0f,
+                       h->d_flag);
   }
   HIPCHK(h, hipGetLastError());
   return NNJ_OK;
@@ -692,7 +700,7 @@ int nnj_pair_scores_incr(nnj_handle* h, const float* state, const uint8_t* mask,
     Scope sc(h, st, PK_ASSEMBLE);
     hipLaunchKernelGGL(k_assemble_argmax, dim3((unsigned)B), dim3(256), 0, st, base + w.score_part, g.nsc, g.ppad,
                        logits_prev, ij_prev, logits_out, (float*)nullptr, 0L, (const int*)nullptr, 0L, (int*)nullptr, 0L,
-                       (float*)nullptr, 0L, ij, (int)PAIRS_INCR, n, (const float*)nullptr, 0L, 1.0f);
+                       (float*)nullptr, 0L, ij, (int)PAIRS_INCR, n, (const float*)nullptr, 0L, 1.0f, h->d_flag);
   }
   HIPCHK(h, hipGetLastError());
   return NNJ_OK;
@@ -809,7 +817,7 @@ static int rollout_impl(nnj_handle* h, const uint8_t* codes, const uint8_t* mask
                          (const float*)lg[(step + 1) & 1], (const int*)ij, lg[step & 1], trace ? trace + off : nullptr,
                          (long)total, forced ? forced + 2 * step : nullptr, (long)(T - 1) * 2, merges_out + 2 * step,
                          (long)(T - 1) * 2, gap ? gap + step : nullptr, (long)(T - 1), ij, mode, n,
-                         uniforms ? uniforms + step : nullptr, (long)(T - 1), inv_temp);
+                         uniforms ? uniforms + step : nullptr, (long)(T - 1), inv_temp, h->d_flag);
     }
     off += (size_t)n * (n - 1) / 2;
     if (n > 2) {                                                                                    // env.step :164
@@ -855,6 +863,18 @@ int nnj_profile_enable(nnj_handle* h, int32_t on) {
   }
   h->ev_used = 0;
   for (int k = 0; k < PK_COUNT; ++k) { h->prof_ms[k] = 0; h->prof_n[k] = 0; }
+  return NNJ_OK;
+}
+
+int nnj_numeric_status(nnj_handle* h, int32_t* nonfinite_out, void* stream) {
+  if (!h || !nonfinite_out) return fail(h, NNJ_ERR_ARG, "nnj_numeric_status: null argument");
+  HIPCHK(h, hipSetDevice(h->cfg.device));
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  int v = 0;
+  HIPCHK(h, hipMemcpyAsync(&v, h->d_flag, sizeof(int), hipMemcpyDeviceToHost, st));
+  HIPCHK(h, hipMemsetAsync(h->d_flag, 0, sizeof(int), st));
+  HIPCHK(h, hipStreamSynchronize(st));
+  *nonfinite_out = v;
   return NNJ_OK;
 }
 

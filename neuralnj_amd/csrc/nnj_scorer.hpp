@@ -812,7 +812,7 @@ __global__ __launch_bounds__(256) void k_assemble_argmax(const float* __restrict
                                                          float* __restrict__ gap_out, long gap_bstride,
                                                          int* ij_cur, int mode, int n,
                                                          const float* __restrict__ uniforms, long u_bstride,
-                                                         float inv_temp) {
+                                                         float inv_temp, int* __restrict__ nonfinite) {
   __shared__ float newsc[64];
   __shared__ float red_v[256];
   __shared__ int red_i[256];
@@ -847,6 +847,9 @@ __global__ __launch_bounds__(256) void k_assemble_argmax(const float* __restrict
     logits_out[(size_t)b * np + p] = v;
     if (trace_out) trace_out[(size_t)b * trace_bstride + p] = v;
     if (v > best || (v == best && p < besti)) { best = v; besti = p; }
+    // a score that is not finite means an operand left the range of the fp16 pieces (nnj_common.hpp): sticky flag,
+    // read back by nnj_numeric_status -- the library must not return a wrong tree silently
+    if (!(fabsf(v) <= 3.402823466e38f) && nonfinite) *nonfinite = 1;
   }
   red_v[tid] = best; red_i[tid] = besti;
   __syncthreads();

@@ -50,6 +50,7 @@ def argmax_rollout(batch, agent, env, device=None):
     env.init_states(batch["seqs"], batch["seq_keys"], batch.get("data"))
     r = agent.rollout_argmax(codes.to(device), mask)
     merges = r["merges"].cpu().numpy()
+    agent._context().check_numeric()          # raises if a score table was not finite (include/nnj.h)
     env.apply_merges(merges)
     scores, _, _, best = env.evaluate_loglikelihood()
     return scores, best, merges
@@ -68,6 +69,7 @@ def sample_rollouts(batch, agent, env, n_rollouts, seed=0, temperature=1.0, devi
     r = agent._context().rollout_sample(codes[:1].to(device), mask[:1], u, temperature=temperature,
                                         replicas=n_rollouts)
     merges = r["merges"].cpu().numpy()
+    agent._context().check_numeric()
     env.init_states([batch["seqs"][0]] * n_rollouts, [batch["seq_keys"][0]] * n_rollouts, None)
     env.apply_merges(merges)
     trees = {}

@@ -191,6 +191,23 @@ def test_mask_none_equals_all_false(ctx_cache):
     assert torch.equal(a["logits"], b["logits"]) and torch.equal(a["merges"], b["merges"])
 
 
+def test_operands_beyond_the_fp16_piece_range_are_reported(ctx_cache):
+    """The f16x3 GEMMs overflow where fp32 would not (|x| > 65504): the table kernel flags non-finite
+    scores and check_numeric raises instead of a wrong tree being returned silently; the flag clears."""
+    z, cfgs, packed = load_golden("synth_b2_t8_l128_s0")
+    g = ctx_cache(cfgs, packed)
+    o = _oracle(cfgs, packed)
+    state = o.encode(onehot_f32(z["codes"]), z["mask"])
+    mask = torch.from_numpy(z["mask"])
+    g.pair_scores_full(torch.from_numpy(state), mask)
+    g.check_numeric()                                          # ordinary magnitudes: fine
+    g.pair_scores_full(torch.from_numpy(state * 1e6), mask)
+    with pytest.raises(FloatingPointError):
+        g.check_numeric()
+    g.pair_scores_full(torch.from_numpy(state), mask)
+    g.check_numeric()                                          # the flag was cleared by the read
+
+
 def test_unsupported_shapes_fail_loudly(ctx_cache):
     cfgs = utils.shipped_config()
     packed = weights.pack(cfgs, weights.seeded_state(cfgs, 0, "sharp"))
