@@ -472,7 +472,7 @@ int launch_aggregate(nnj_handle* h, const RowSet& rs, const int* ij, float* base
                          base + w.agg_part, nch, S_out, U_out, Kp_out, beta_out, out_bstride, out_slots, in_place, n, C);
       return NNJ_OK;
     }
-    const size_t lds = (3 * 4096 + 64) * sizeof(float);
+    const size_t lds = (3 * 4096 + 64 + 256) * sizeof(float);
     if (int rc = set_lds(h, k_agg_finish<false>, lds)) return rc;
     hipLaunchKernelGGL(k_agg_finish<false>, dim3((unsigned)((C + 127) / 128), (unsigned)B), dim3(256), lds, st, rs, sw, ij,
                        base + w.agg_part, nch, S_out, U_out, Kp_out, beta_out, out_bstride, out_slots, in_place, n, C);

@@ -696,28 +696,39 @@ __global__ __launch_bounds__(256) void k_agg_finish(RowSet rs, ScorerW w, const 
     stage_weight<64>(A_l, w.A, 64, tid, 256);
   }
   const bool has_ctx = n > 2;                       // model.py:111
-  if (wave == 0) {
-    float a = -INFINITY;
+  {
+    // alpha logits of the merged pair: the chunk partials of k_agg_alpha and the rows' beta partials are summed by
+    // all four waves (every 4th term each, all loads of a wave in flight at once; the serial loop of one wave was
+    // most of this kernel's latency at small batch), the four sums meet in LDS in wave order
     const bool in = has_ctx && lane < n && lane != pi && lane != pj;
+    float s = 0.f;
     if (in) {
-      float s = 0.f;
-#pragma unroll 8
-      for (int ch = 0; ch < nch; ++ch) s += part[((size_t)b * nch + ch) * 64 + lane];
+#pragma unroll 16
+      for (int ch = wave; ch < nch; ch += 4) s += part[((size_t)b * nch + ch) * 64 + lane];
       const float* bp = rs.beta_part + ((size_t)b * (rs.bstride / ((long)C * 64)) + slot_of(rs, b, lane)) * rs.ntile32;
       float beta = 0.f;
-  #pragma unroll 8
-    for (int t = 0; t < rs.ntile32; ++t) beta += bp[t];
-      beta += (float)C * w.t0;
-      a = (s + beta) * (1.0f / sqrtf(64.0f * (float)C));
+#pragma unroll 8
+      for (int t = wave; t < rs.ntile32; t += 4) beta += bp[t];
+      s += beta;
     }
-    float mx = a;
+    float* red4 = al + 64;                          // [4][64]
+    red4[wave * 64 + lane] = s;
+    __syncthreads();
+    if (wave == 0) {
+      float a = -INFINITY;
+      if (in) {
+        const float tot = ((red4[lane] + red4[64 + lane]) + red4[128 + lane]) + red4[192 + lane] + (float)C * w.t0;
+        a = tot * (1.0f / sqrtf(64.0f * (float)C));
+      }
+      float mx = a;
 #pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
-    float e = in ? expf(a - mx) : 0.f;
-    float s = e;
+      for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+      float e = in ? expf(a - mx) : 0.f;
+      float se = e;
 #pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o);
-    al[lane] = (s > 0.f) ? e / s : 0.f;
+      for (int o = 32; o >= 1; o >>= 1) se += __shfl_xor(se, o);
+      al[lane] = (se > 0.f) ? e / se : 0.f;
+    }
   }
   __syncthreads();
   const int tile = SPLIT ? blockIdx.x : blockIdx.x * 4 + wave;
