@@ -580,9 +580,9 @@ __device__ __forceinline__ void row_transforms(const f32x16 (&s)[1][2], const fl
                                                int c, bool valid, int lane) {
   const int hh = lane >> 5;
   f32x16 o[1][2];
-  linear_T_nb<2, 2, 1>(o, s, Wh_l, lane);
+  linear6_T_nb<2, 2, 1>(o, s, Wh_l, lane);
   store_token64(o[0], U_row + (size_t)c * 64, valid, hh);
-  linear_T<2, 2, 1>(o, s, A_l, w.a0, lane);
+  linear6_T<2, 2, 1>(o, s, A_l, w.a0, lane);
   store_token64(o[0], Kp_row + (size_t)c * 64, valid, hh);
   float d = 0.f;
 #pragma unroll
@@ -607,8 +607,8 @@ __global__ __launch_bounds__(256) void k_row_xf(const float* __restrict__ S, flo
   float* Wh_l = smem;
   float* A_l = smem + 4096;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  stage_weight<64>(Wh_l, w.Wh, 64, tid, 256);
-  stage_weight<64>(A_l, w.A, 64, tid, 256);
+  stage_weight_b6<64>(Wh_l, w.Wh, 64, tid, 256);
+  stage_weight_b6<64>(A_l, w.A, 64, tid, 256);
   __syncthreads();
   const int tile = blockIdx.x * 4 + wave, row = blockIdx.y, b = blockIdx.z;
   if (tile >= ntile32) return;
@@ -690,10 +690,10 @@ __global__ __launch_bounds__(256) void k_agg_finish(RowSet rs, ScorerW w, const 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5;
   const int b = blockIdx.y;
   const int pi = min(max(ij[2 * b], 0), n - 1), pj = min(max(ij[2 * b + 1], 0), n - 1);
-  stage_weight<64>(Wg_l, w.Wg, 64, tid, 256);
+  stage_weight_b6<64>(Wg_l, w.Wg, 64, tid, 256);
   if (U_out) {
-    stage_weight<64>(Wh_l, w.Wh, 64, tid, 256);
-    stage_weight<64>(A_l, w.A, 64, tid, 256);
+    stage_weight_b6<64>(Wh_l, w.Wh, 64, tid, 256);
+    stage_weight_b6<64>(A_l, w.A, 64, tid, 256);
   }
   const bool has_ctx = n > 2;                       // model.py:111
   {
@@ -791,7 +791,7 @@ __global__ __launch_bounds__(256) void k_agg_finish(RowSet rs, ScorerW w, const 
         }
     }
     f32x16 g[1][2];
-    linear_T<2, 2, 1>(g, xg, Wg_l, w.bg, lane);
+    linear6_T<2, 2, 1>(g, xg, Wg_l, w.bg, lane);
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
