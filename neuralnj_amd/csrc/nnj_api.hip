@@ -429,14 +429,14 @@ int launch_pair_scores(nnj_handle* h, const RowSet& rs, const int* ij_prev, cons
     }
     return NNJ_OK;
   }
-  const dim3 grid((unsigned)g.nsc, (unsigned)g.pg, (unsigned)B);
+  const dim3 grid(pair_grid(g.nsc, g.pg, B));       // XCD-aware 1-D mapping (nnj_scorer.hpp pair_block)
   if (has_ctx) {
     {
       Scope sc(h, st, PK_PAIR_ALPHA);
       const size_t lds = 2 * (IMG64 + 8192) * sizeof(float);
       if (int rc = set_lds(h, k_pair_alpha<1, 8>, lds)) return rc;
       hipLaunchKernelGGL((k_pair_alpha<1, 8>), grid, dim3(512), lds, st, rs, sw, ij_prev, base + w.alpha_part, mode, n, C,
-                         g.npairs, g.ppad, g.cs);
+                         g.npairs, g.ppad, g.cs, g.nsc, g.pg, B);
     }
     {
       Scope sc(h, st, PK_ALPHA_SOFTMAX);
@@ -449,7 +449,7 @@ int launch_pair_scores(nnj_handle* h, const RowSet& rs, const int* ij_prev, cons
     const size_t lds = (size_t)(2 * IMG64 + 2 * (IMG64 + 8192)) * sizeof(float);
     if (int rc = set_lds(h, k_pair_score<1, 8>, lds)) return rc;
     hipLaunchKernelGGL((k_pair_score<1, 8>), grid, dim3(512), lds, st, rs, sw, ij_prev, base + w.alpha, mask,
-                       base + w.score_part, mode, n, C, g.npairs, g.ppad, g.cs, has_ctx);
+                       base + w.score_part, mode, n, C, g.npairs, g.ppad, g.cs, has_ctx, g.nsc, g.pg, B);
   }
   return NNJ_OK;
 }

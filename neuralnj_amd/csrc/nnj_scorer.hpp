@@ -142,15 +142,30 @@ __device__ __forceinline__ void gate_tile(f32x16 (&x)[2], const float* img_s, co
 }
 
 // ------------------------------------------------------------------ k_pair_alpha
+// Workgroup -> (site chunk, pair group, batch element) of the all-pairs kernels.  The pair groups of one
+// (site chunk, b) read the same rows: they get consecutive slots of ONE XCD (blockIdx % 8 = the XCD of the
+// round-robin dispatch), so they run together and the rows they share are served by that XCD's L2 instead of
+// being fetched once per pair group.  false: padding workgroup, nothing to do.
+__device__ __forceinline__ bool pair_block(int nsc, int npg, int B, int& sc, int& pg, int& b) {
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int grp = (slot / npg) * 8 + xcd;
+  pg = slot % npg;
+  sc = grp % nsc;
+  b = grp / nsc;
+  return grp < nsc * B;
+}
+__host__ inline unsigned pair_grid(int nsc, int npg, int B) { return (unsigned)(((nsc * B + 7) / 8) * 8 * npg); }
+
 // Phase A: alpha_part[b][sc][pair][r] = sum_{c in chunk sc} x_pair[c,:] . K'_r[c,:]
 // grid (nsc, pair groups, B); 4 waves x TPW tiles of 32 pairs.
 template <int TPW, int NW>
 __global__ __launch_bounds__(64 * NW) void k_pair_alpha(RowSet rs, ScorerW w, const int* __restrict__ ij_prev,
                                                     float* __restrict__ alpha_part, int mode, int n, int C,
-                                                    int npairs, int ppad, int cs) {
+                                                    int npairs, int ppad, int cs, int nsc, int npg, int B) {
   extern __shared__ __attribute__((aligned(16))) float smem[];   // 2 x [img_k (f16x3) | img_s | img_u]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5;
-  const int sc = blockIdx.x, pg = blockIdx.y, b = blockIdx.z;
+  int sc, pg, b;
+  if (!pair_block(nsc, npg, B, sc, pg, b)) return;
   const int c0 = sc * cs, c1 = min(C, c0 + cs);
   int pi[TPW], pj[TPW];
   bool any = false;
@@ -193,7 +208,7 @@ __global__ __launch_bounds__(64 * NW) void k_pair_alpha(RowSet rs, ScorerW w, co
   for (int tt = 0; tt < TPW; ++tt) {
     const int p = ((pg * NW + wave) * TPW + tt) * 32 + (lane & 31);
     if (p < ppad) {
-      float* dst = alpha_part + (((size_t)b * gridDim.x + sc) * ppad + p) * 64;
+      float* dst = alpha_part + (((size_t)b * nsc + sc) * ppad + p) * 64;
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -250,13 +265,14 @@ __global__ __launch_bounds__(64 * NW) void k_pair_score(RowSet rs, ScorerW w, co
                                                     const float* __restrict__ alpha,
                                                     const uint8_t* __restrict__ mask,
                                                     float* __restrict__ score_part, int mode, int n, int C,
-                                                    int npairs, int ppad, int cs, int has_ctx) {
+                                                    int npairs, int ppad, int cs, int has_ctx, int nsc, int npg, int B) {
   extern __shared__ __attribute__((aligned(16))) float smem[];   // Wg | S0 (f16x3 images) | 2 x [img_t | img_s | img_u]
   float* Wg_l = smem;
   float* S0_l = smem + b6_floats(64, 64);
   float* ring = smem + 2 * b6_floats(64, 64);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5;
-  const int sc = blockIdx.x, pg = blockIdx.y, b = blockIdx.z;
+  int sc, pg, b;
+  if (!pair_block(nsc, npg, B, sc, pg, b)) return;
   const int c0 = sc * cs, c1 = min(C, c0 + cs);
   stage_weight_b6<64>(Wg_l, w.Wg, 64, tid, 64 * NW);
   stage_weight_b6<64>(S0_l, w.S0, 64, tid, 64 * NW);
@@ -328,7 +344,7 @@ __global__ __launch_bounds__(64 * NW) void k_pair_score(RowSet rs, ScorerW w, co
 #pragma unroll
     for (int tt = 0; tt < TPW; ++tt) {
       const int p = ((pg * NW + wave) * TPW + tt) * 32 + (lane & 31);
-      if (p < ppad) score_part[((size_t)b * gridDim.x + sc) * ppad + p] = score[tt];
+      if (p < ppad) score_part[((size_t)b * nsc + sc) * ppad + p] = score[tt];
     }
   }
 }
