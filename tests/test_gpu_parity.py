@@ -191,6 +191,30 @@ def test_mask_none_equals_all_false(ctx_cache):
     assert torch.equal(a["logits"], b["logits"]) and torch.equal(a["merges"], b["merges"])
 
 
+def test_batch_shards_reproduce_the_whole_batch(ctx_cache):
+    """Multi-GPU sharding is a contiguous split of the batch: a shard must give what the same
+    alignments give inside the whole batch.  Launch geometry (site chunks per workgroup, small-batch kernels)
+    depends on B, so partial sums may be added in another order: tables within tolerance, merges identical on
+    decisive steps -- and bit-identical when the geometry is the same (two shards of equal size)."""
+    cfgs = utils.shipped_config()
+    packed = weights.pack(cfgs, weights.seeded_state(cfgs, 33, "sharp"))
+    g = ctx_cache(cfgs, packed)
+    codes = synth.synth_codes_tree(6, 21, 200, 77)
+    full = g.rollout_argmax(torch.from_numpy(codes), None, want_trace=True)
+    fl, fm, fg = full["logits"].cpu().numpy(), full["merges"].cpu().numpy(), full["top2_gap"].cpu().numpy()
+    halves = []
+    for lo in (0, 3):
+        r = g.rollout_argmax(torch.from_numpy(codes[lo:lo + 3]), None, want_trace=True)
+        halves.append((r["logits"].cpu().numpy(), r["merges"].cpu().numpy()))
+        scale = np.abs(fl[lo:lo + 3]).max()
+        assert_logits_close(halves[-1][0], fl[lo:lo + 3], RTOL, f"shard {lo}")
+        decisive = fg[lo:lo + 3] > 4 * RTOL * scale
+        assert (halves[-1][1][decisive] == fm[lo:lo + 3][decisive]).all()
+    again = g.rollout_argmax(torch.from_numpy(codes[0:3]), None, want_trace=True)
+    assert np.array_equal(again["logits"].cpu().numpy(), halves[0][0])          # same geometry: same bits
+    assert np.array_equal(again["merges"].cpu().numpy(), halves[0][1])
+
+
 def test_operands_beyond_the_fp16_piece_range_are_reported(ctx_cache):
     """The f16x3 GEMMs overflow where fp32 would not (|x| > 65504): the table kernel flags non-finite
     scores and check_numeric raises instead of a wrong tree being returned silently; the flag clears."""
