@@ -319,16 +319,17 @@ int launch_encoder(nnj_handle* h, const uint8_t* codes, const float* onehot, con
     {
       Scope sc(h, st, PK_TOK1);
       const int dbg = ((l == 0 && h->debug_stop == 1) ? 1 : 0) | (h->debug_stop >= 16 ? (h->debug_stop >> 4) << 1 : 0);
-      const unsigned grid1 = (unsigned)std::min<long>((long)colblocks, (long)h->num_cu);   // persistent
-      if (NT == 2) {      // 32 < R <= 64: two waves per column
+      if (NT == 2) {      // 32 < R <= 64: two waves per column, four columns in flight per workgroup
+        const unsigned grid1 = (unsigned)std::min<long>((long)(((size_t)B * C + 3) / 4), (long)h->num_cu);   // persistent
         const size_t lds = (size_t)(5 * 4096 + 4 * (64 * 36 + 64 * 32) + 16) * sizeof(float);
-        if (int rc = set_lds(h, k_tok1p, lds)) return rc;
-        hipLaunchKernelGGL(k_tok1p, dim3(grid1), dim3(512), lds, st, ctx, mask, x, attn_ptrs(h, h->lo[l].row),
+        if (int rc = set_lds(h, k_tok1p<2>, lds)) return rc;
+        hipLaunchKernelGGL(k_tok1p<2>, dim3(grid1), dim3(512), lds, st, ctx, mask, x, attn_ptrs(h, h->lo[l].row),
                            attn_ptrs(h, h->lo[l].col), B, T, C, d.Epad, dbg);
-      } else {
-        const size_t lds = (size_t)(5 * 4096 + 4 * 2048) * sizeof(float);
-        if (int rc = set_lds(h, k_tok1<1>, lds)) return rc;
-        hipLaunchKernelGGL(k_tok1<1>, dim3(grid1), dim3(256), lds, st, ctx, mask, x, attn_ptrs(h, h->lo[l].row),
+      } else {            // R <= 32: one wave per column, eight columns in flight
+        const unsigned grid1 = (unsigned)std::min<long>((long)(((size_t)B * C + 7) / 8), (long)h->num_cu);
+        const size_t lds = (size_t)(5 * 4096 + 8 * (32 * 36 + 32 * 32) + 16) * sizeof(float);
+        if (int rc = set_lds(h, k_tok1p<1>, lds)) return rc;
+        hipLaunchKernelGGL(k_tok1p<1>, dim3(grid1), dim3(512), lds, st, ctx, mask, x, attn_ptrs(h, h->lo[l].row),
                            attn_ptrs(h, h->lo[l].col), B, T, C, d.Epad, dbg);
       }
     }

@@ -6,7 +6,8 @@
 // of a flat (column, row) order.  Token-local stages chain in registers (nnj_common.hpp); weights sit in LDS.
 //
 //   k_embed     : embed (6-entry LUT of the site codes, or the embed MLP on float input) -> x
-//   k_tok1/1p   : ctx -> out_proj -> +x ; LN -> q,k,v -> column attention -> out_proj -> +x
+//   k_tok1p     : ctx -> out_proj -> +x ; LN -> q,k,v -> column attention -> out_proj -> +x  (f16x3; one wave per
+//                 column for R <= 32, two for R <= 64)
 //   k_ffn16     : LN -> fc1 -> GELU -> fc2 -> +x   (persistent, flat token tiling, 16-token tiles, f16x3)
 // The tied row attention (q,k,v projections, scores, context) lives in nnj_rowattn.hpp.
 //
@@ -83,184 +84,14 @@ __global__ __launch_bounds__(256) void k_embed(const uint8_t* __restrict__ codes
   }
 }
 
-// ------------------------------------------------------------------ k_tok1
+// ------------------------------------------------------------------ k_tok1p
 // Row-attention output projection + residual, then the whole column-attention block
 // (reference msa_modules.py:109-125 around axial_attention.py:119-138 and 141-255).
-//   LDS: W[0..3] four 64x64 weight images (Wo_row -> later Wo_col, Wq, Wk, Wv) 64 KiB
-//        + per wave K,V of one head-half [64][32] x 2 = 16 KiB  (x4 waves)
-template <int NT>
-__global__ __launch_bounds__(256) void k_tok1(const float* __restrict__ ctx, const uint8_t* __restrict__ mask,
-                                              float* __restrict__ x, AttnW wr, AttnW wc, int B, int R, int C,
-                                              int Epad, int skip_col) {
-  // persistent: one workgroup per CU, the five 64x64 weight images staged ONCE (80 KiB), then a loop
-  // over groups of 4 columns (one column per wave) with no workgroup barrier inside
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* W0 = smem;               // Wo_row
-  float* Wq_l = smem + 4096;
-  float* Wk_l = smem + 8192;
-  float* Wv_l = smem + 12288;
-  float* Wo_l = smem + 16384;     // Wo_col
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  float* kvl = smem + 20480 + wave * 2048;   // V image of one head-half [64][32], wave private
-  stage_weight<64>(W0, wr.Wo, 64, tid, 256);
-  stage_weight<64>(Wq_l, wc.Wq, 64, tid, 256);
-  stage_weight<64>(Wk_l, wc.Wk, 64, tid, 256);
-  stage_weight<64>(Wv_l, wc.Wv, 64, tid, 256);
-  stage_weight<64>(Wo_l, wc.Wo, 64, tid, 256);
-  __syncthreads();
-  const int tok = lane & 31, hh = lane >> 5;
-  const long ncols = (long)B * C;
-  for (long col = (long)blockIdx.x * 4 + wave; col < ncols; col += (long)gridDim.x * 4) {
-  asm volatile("" ::: "memory");            // keep bias / LayerNorm parameter loads inside the loop (hoisted, they would occupy ~200 VGPRs)
-  const int b = (int)(col / C), c = (int)(col % C);
-  const bool padded = mask && mask[(size_t)b * C + c];
-
-  f32x16 xr[NT][2];
-  {
-    // ---- row attention: out_proj(context) + residual
-    f32x16 cx[NT][2];
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      const int r = 32 * nt + tok;
-      const bool valid = r < R;
-      load_token64(xr[nt], x + (((size_t)b * R + (valid ? r : 0)) * C + c) * 64, valid, hh);
-#pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int h = 4 * mt + g;
-          const f32x4 v = *reinterpret_cast<const f32x4*>(ctx + (((size_t)b * NNJ_NHEAD + h) * C + c) * Epad +
-                                                          (valid ? r : 0) * 8 + 4 * hh);
-          cx[nt][mt][4 * g + 0] = valid ? v[0] : 0.f; cx[nt][mt][4 * g + 1] = valid ? v[1] : 0.f;
-          cx[nt][mt][4 * g + 2] = valid ? v[2] : 0.f; cx[nt][mt][4 * g + 3] = valid ? v[3] : 0.f;
-        }
-    }
-    f32x16 o[NT][2];
-    linear_T<2, 2, NT>(o, cx, W0, wr.bo, lane);
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-      for (int mt = 0; mt < 2; ++mt) xr[nt][mt] += o[nt][mt];
-  }
-  if (skip_col & 3) {                        // 1: debug tap (state after the row-attention block); 2: timing ablation
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      const int r = 32 * nt + tok;
-      store_token64(xr[nt], x + (((size_t)b * R + r) * C + c) * 64, r < R, hh);
-    }
-    continue;
-  }
-
-  // ---- column attention
-  f32x16 cx[NT][2];
-  if (R == 1) {
-    // single position: output = out_proj(v_proj(x)) (axial_attention.py:198-209)
-    f32x16 y[NT][2];
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) layer_norm64(y[nt], xr[nt], wc.ln_w, wc.ln_b, hh);
-    linear_T<2, 2, NT>(cx, y, Wv_l, wc.bv, lane);
-  } else {
-    const float scaling = rsqrtf((float)NNJ_DH);      // axial_attention.py:214
-#pragma unroll
-    for (int hf = 0; hf < 2; ++hf) {                  // heads 4*hf .. 4*hf+3
-      f32x16 qh[NT][1], kh[NT][1], vh[NT][1];
-      {
-        f32x16 y[NT][2];                              // LayerNorm recomputed per head-half: cheaper than 64 live VGPRs
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) layer_norm64(y[nt], xr[nt], wc.ln_w, wc.ln_b, hh);
-      linear_T<1, 2, NT>(qh, y, Wq_l + hf * 32 * 64, wc.bq + 32 * hf, lane);
-      linear_T<1, 2, NT>(kh, y, Wk_l + hf * 32 * 64, wc.bk + 32 * hf, lane);
-      linear_T<1, 2, NT>(vh, y, Wv_l + hf * 32 * 64, wc.bv + 32 * hf, lane);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      // publish v of this head-half for all rows of the column (wave-private LDS image [row][32])
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-        const int r = 32 * nt + tok;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          f32x4 v4 = {vh[nt][0][4 * g], vh[nt][0][4 * g + 1], vh[nt][0][4 * g + 2], vh[nt][0][4 * g + 3]};
-          *reinterpret_cast<f32x4*>(kvl + r * 32 + 8 * g + 4 * hh) = v4;
-        }
-      }
-      // per head: S^T[key j x query i] = K_h Q_h^T straight from the projection registers (the q/k
-      // accumulators ARE the B/A operands: lane-half hh carries d = 4hh+t), softmax over j inside the
-      // lane (+ one exchange with the other half), P.V on the VALU with V broadcast from LDS
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        f32x16 sc_[NT][NT];                       // [query tile][key tile]
-#pragma unroll
-        for (int it = 0; it < NT; ++it)
-#pragma unroll
-          for (int jt = 0; jt < NT; ++jt) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) sc_[it][jt][r] = 0.f;
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-              sc_[it][jt] = mfma32(kh[jt][0][4 * g + t], qh[it][0][4 * g + t] * scaling, sc_[it][jt]);
-          }
-#pragma unroll
-        for (int it = 0; it < NT; ++it) {
-          // element reg of tile jt is key j = 32*jt + (reg&3) + 8*(reg>>2) + 4*hh
-          float m = -INFINITY;
-#pragma unroll
-          for (int jt = 0; jt < NT; ++jt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              const int j = 32 * jt + (r & 3) + 8 * (r >> 2) + 4 * hh;
-              float v = sc_[it][jt][r];
-              if (padded) v = -10000.0f;           // every key of a padded column (axial_attention.py:220-224)
-              if (j >= R) v = -INFINITY;
-              sc_[it][jt][r] = v;
-              m = fmaxf(m, v);
-            }
-          m = fmaxf(m, __shfl_xor(m, 32));
-          float l = 0.f, o8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-          for (int jt = 0; jt < NT; ++jt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              const float p = nnj_exp(sc_[it][jt][r] - m);
-              l += p;
-              const float* vp = kvl + (32 * jt + (r & 3) + 8 * (r >> 2) + 4 * hh) * 32 + 8 * g;
-              const f32x4 v0 = *reinterpret_cast<const f32x4*>(vp);
-              const f32x4 v1 = *reinterpret_cast<const f32x4*>(vp + 4);
-#pragma unroll
-              for (int t = 0; t < 4; ++t) { o8[t] += p * v0[t]; o8[4 + t] += p * v1[t]; }
-            }
-          l += __shfl_xor(l, 32);
-          const float inv = nnj_rcp(l);
-          // this lane keeps d = 4hh+t: add the partner half's partial sums for those d
-#pragma unroll
-          for (int t = 0; t < 4; ++t) {
-            const float send = hh ? o8[t] : o8[4 + t];
-            const float recv = __shfl_xor(send, 32);
-            cx[it][hf][4 * g + t] = ((hh ? o8[4 + t] : o8[t]) + recv) * inv;
-          }
-          __builtin_amdgcn_sched_barrier(0);        // keep the heads' live ranges apart
-        }
-      }
-    }
-  }
-  f32x16 o[NT][2];
-  linear_T<2, 2, NT>(o, cx, Wo_l, wc.bo, lane);
-#pragma unroll
-  for (int nt = 0; nt < NT; ++nt) {
-    const int r = 32 * nt + tok;
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt) xr[nt][mt] += o[nt][mt];
-    store_token64(xr[nt], x + (((size_t)b * R + r) * C + c) * 64, r < R, hh);
-  }
-  }   // persistent column loop
-}
-
-// ------------------------------------------------------------------ k_tok1p
-// k_tok1 for 32 < R <= 64 with TWO waves per column (one 32-row tile each), 8 waves per workgroup:
-// two waves per SIMD, so the VALU stream (softmax, P.V) issues at the full rate and one wave's VALU
-// overlaps the other's MFMAs.  The K and V projections of a head-half are exchanged through a
-// per-column LDS image; the two waves of a column meet at a pair barrier built on an LDS counter
-// (never a workgroup barrier: the four column pairs run unsynchronised).  Persistent: the five
-// weight images are staged once (80 KiB) + 4 x (K image [64][36] + V image [64][32]) = 149 KiB.
+// A column (b, c) is owned by NWC waves, one 32-row tile each (NWC = 1 for R <= 32, 2 for R <= 64), 8 waves per
+// workgroup: two waves per SIMD, so one wave's VALU (softmax) overlaps the other's MFMAs.  The K and V
+// projections of a head-half go through per-column LDS images; with NWC = 2 the two waves of a column meet at a
+// pair barrier built on an LDS counter (never a workgroup barrier: the column slots run unsynchronised).
+// Persistent: the five weight images are staged once (80 KiB) + 8/NWC x (K image + V^T image) = 149 KiB.
 __device__ __forceinline__ void pair_barrier(int* cnt, int& epoch) {
   // both waves of the pair arrive (LDS executes a wave's operations in order: its image writes are
   // in place before its increment), then wait until the counter shows both arrivals of this epoch
@@ -272,6 +103,7 @@ __device__ __forceinline__ void pair_barrier(int* cnt, int& epoch) {
   asm volatile("" ::: "memory");
 }
 
+template <int NWC>                                      // waves per column: 1 (R <= 32) or 2 (R <= 64)
 __global__ __launch_bounds__(512) void k_tok1p(const float* __restrict__ ctx, const uint8_t* __restrict__ mask,
                                                float* __restrict__ x, AttnW wr, AttnW wc, int B, int R, int C,
                                                int Epad, int skip_col) {
@@ -286,11 +118,17 @@ __global__ __launch_bounds__(512) void k_tok1p(const float* __restrict__ ctx, co
   // column slot of the workgroup, row tile of the column.  Consecutive waves land on different SIMDs: the two
   // waves of a column (which run in lockstep) sit on two SIMDs, and each SIMD hosts waves of two different,
   // unsynchronised columns -- one's VALU phases overlap the other's MFMA phases
-  const int slot = wave >> 1, rt = wave & 1;
-  float* kimg = smem + 20480 + slot * (64 * 36 + 64 * 32);   // K image [64][36]
-  // V^T image: two fp16 planes of [32 (head, d)][64 keys], keys in fragment order (see the P.V loop), 8 KiB
-  uint8_t* vimg = reinterpret_cast<uint8_t*>(kimg + 64 * 36);
-  int* cnt = reinterpret_cast<int*>(smem + 20480 + 4 * (64 * 36 + 64 * 32)) + slot;
+  // (NWC = 1: every wave owns a column, no barrier at all.)
+  constexpr int NSLOT = 8 / NWC;                        // columns in flight per workgroup
+  constexpr int KR = 32 * NWC;                          // rows (= keys) of the column images
+  constexpr int SLOTF = KR * 36 + KR * 32;              // floats of a slot: K image [KR][36] + V^T image
+  constexpr int VCH = 4 * NWC;                          // 16-byte chunks of a V^T image row (8 keys each)
+  constexpr int VPL = 32 * KR * 2;                      // bytes of a V^T plane
+  const int slot = wave / NWC, rt = wave % NWC;
+  float* kimg = smem + 20480 + slot * SLOTF;            // K image [KR][36]
+  // V^T image: two fp16 planes of [32 (head, d)][KR keys], keys in fragment order (see the P.V loop)
+  uint8_t* vimg = reinterpret_cast<uint8_t*>(kimg + KR * 36);
+  int* cnt = reinterpret_cast<int*>(smem + 20480 + NSLOT * SLOTF) + slot;
   // f16x3 operand images (4 B per element: the same 16 KiB per matrix as an fp32 image)
   stage_weight_b6<64>(W0, wr.Wo, 64, tid, 512);
   stage_weight_b6<64>(Wo_l, wc.Wo, 64, tid, 512);
@@ -300,7 +138,7 @@ __global__ __launch_bounds__(512) void k_tok1p(const float* __restrict__ ctx, co
     stage_weight_b6<64>(Wqkv_l + hf * QKV, wc.Wk + hf * 32 * 64, 32, tid, 512, 32, 96);
     stage_weight_b6<64>(Wqkv_l + hf * QKV, wc.Wv + hf * 32 * 64, 32, tid, 512, 64, 96);
   }
-  if (tid < 4) reinterpret_cast<int*>(smem + 20480 + 4 * (64 * 36 + 64 * 32))[tid] = 0;
+  if (tid < NSLOT) reinterpret_cast<int*>(smem + 20480 + NSLOT * SLOTF)[tid] = 0;
   __syncthreads();
   int epoch = 0;
   const int tok = lane & 31, hh = lane >> 5;
@@ -324,13 +162,13 @@ __global__ __launch_bounds__(512) void k_tok1p(const float* __restrict__ ctx, co
         co[mt][4 * g + 0] = v[0]; co[mt][4 * g + 1] = v[1]; co[mt][4 * g + 2] = v[2]; co[mt][4 * g + 3] = v[3];
       }
   };
-  const long cstride = (long)gridDim.x * 4;
+  const long cstride = (long)gridDim.x * NSLOT;
   f32x16 xn[2], cn[2];
   {
-    const long col0 = (long)blockIdx.x * 4 + slot;
+    const long col0 = (long)blockIdx.x * NSLOT + slot;
     if (col0 < ncols) load_col(col0, xn, cn);
   }
-  for (long col = (long)blockIdx.x * 4 + slot; col < ncols; col += cstride) {
+  for (long col = (long)blockIdx.x * NSLOT + slot; col < ncols; col += cstride) {
     asm volatile("" ::: "memory");                      // keep parameter loads inside the loop (hoisted, they would occupy ~200 VGPRs)
     const int b = (int)(col / C), c = (int)(col % C);
     const bool padded = mask && mask[(size_t)b * C + c];
@@ -388,7 +226,7 @@ __global__ __launch_bounds__(512) void k_tok1p(const float* __restrict__ ctx, co
           __builtin_amdgcn_sched_barrier(0);
         });
       }
-      pair_barrier(cnt, epoch);                         // the partner has finished reading the previous images
+      if constexpr (NWC == 2) pair_barrier(cnt, epoch);  // the partner has finished reading the previous images
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const f32x4 k4 = {kh[4 * g], kh[4 * g + 1], kh[4 * g + 2], kh[4 * g + 3]};
@@ -400,17 +238,17 @@ __global__ __launch_bounds__(512) void k_tok1p(const float* __restrict__ ctx, co
         split2(vT[4 * g], vT[4 * g + 1], h01, m01);
         split2(vT[4 * g + 2], vT[4 * g + 3], h23, m23);
         const int chunk = 4 * rt + 2 * (g >> 1) + hh;
-        uint8_t* dst = vimg + tok * 128 + 16 * wswz6<8>(tok, chunk) + 8 * (g & 1);
+        uint8_t* dst = vimg + tok * (16 * VCH) + 16 * wswz6<VCH>(tok, chunk) + 8 * (g & 1);
         *reinterpret_cast<uint2*>(dst) = make_uint2(h01, h23);
-        *reinterpret_cast<uint2*>(dst + 4096) = make_uint2(m01, m23);
+        *reinterpret_cast<uint2*>(dst + VPL) = make_uint2(m01, m23);
       }
-      pair_barrier(cnt, epoch);                         // both row tiles' K and V are in the images
+      if constexpr (NWC == 2) pair_barrier(cnt, epoch);  // both row tiles' K and V are in the images
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         // S^T[key j x query i]: A = K image rows (lane = key), B = this wave's q registers (lane = query)
-        f32x16 sc_[2];
+        f32x16 sc_[NWC];
 #pragma unroll
-        for (int jt = 0; jt < 2; ++jt) {
+        for (int jt = 0; jt < NWC; ++jt) {
           const f32x4 ka = *reinterpret_cast<const f32x4*>(kimg + (32 * jt + tok) * 36 + 8 * g + 4 * hh);
 #pragma unroll
           for (int k = 0; k < 16; ++k) sc_[jt][k] = 0.f;
@@ -422,18 +260,18 @@ __global__ __launch_bounds__(512) void k_tok1p(const float* __restrict__ ctx, co
         // softmax of equal scores is the same.  Keys beyond the rows exist only in the second tile (R > 32).
         float m = -INFINITY;
 #pragma unroll
-        for (int jt = 0; jt < 2; ++jt)
+        for (int jt = 0; jt < NWC; ++jt)
 #pragma unroll
           for (int k = 0; k < 16; ++k) {
             float v = sc_[jt][k];
-            if (jt == 1 && 32 + (k & 3) + 8 * (k >> 2) + 4 * hh >= R) v = -INFINITY;
+            if (jt == NWC - 1 && 32 * jt + (k & 3) + 8 * (k >> 2) + 4 * hh >= R) v = -INFINITY;
             sc_[jt][k] = v;
             m = fmaxf(m, v);
           }
         m = fmaxf(m, __shfl_xor(m, 32));
         float l = 0.f;
 #pragma unroll
-        for (int jt = 0; jt < 2; ++jt)
+        for (int jt = 0; jt < NWC; ++jt)
 #pragma unroll
           for (int k = 0; k < 16; ++k) {
             const float p = nnj_exp(sc_[jt][k] - m);
@@ -447,13 +285,13 @@ __global__ __launch_bounds__(512) void k_tok1p(const float* __restrict__ ctx, co
         f32x16 o;
 #pragma unroll
         for (int k = 0; k < 16; ++k) o[k] = 0.f;
-        static_for<0, 4>([&](auto si) {
+        static_for<0, 2 * NWC>([&](auto si) {
           constexpr int ks = decltype(si)::value;
           Frag3 pf, vf;
           split8<8 * (ks & 1)>(pf, sc_[ks >> 1]);
-          const uint8_t* src = vimg + tok * 128 + 16 * wswz6<8>(tok, 2 * ks + hh);
+          const uint8_t* src = vimg + tok * (16 * VCH) + 16 * wswz6<VCH>(tok, 2 * ks + hh);
           vf.h = *reinterpret_cast<const u32x4*>(src);
-          vf.m = *reinterpret_cast<const u32x4*>(src + 4096);
+          vf.m = *reinterpret_cast<const u32x4*>(src + VPL);
           o = mfma_b6(vf, pf, o);
         });
         const float inv = nnj_rcp(l);
