@@ -130,6 +130,20 @@ int nnj_env_step(nnj_handle* h, const float* state_dev, const int32_t* ij_dev,
 int nnj_select_pair(nnj_handle* h, const float* logits_dev, int32_t* ij_out_dev,
                     float* top2_gap_out_dev, int32_t B, int32_t n, void* stream);
 
+/* One iteration of the reference's loop body in its device order -- environment.py:760-835 (merge the pair
+ * chosen in the previous iteration: nnj_env_step), then model.py:184-201 + utils.py:213-251 (score the new
+ * pairs, assemble the table: nnj_pair_scores_incr), then finetune_rl_search.py:145,159-160 (argmax:
+ * nnj_select_pair) -- as ONE call with no host round trip in between.
+ *   state_dev        [B,n+1,C,D]   rows before the merge          ij_dev        int32 [B,2] the pair to merge
+ *   logits_prev_dev  [B,P(n+1)]    the table ij_dev was chosen from
+ *   forced_next_dev  NULL, or int32 [B,2]: returned in chosen_ij_dev instead of the argmax (teacher forcing)
+ *   state_out_dev    [B,n,C,D]     logits_out_dev [B,P(n)]   chosen_ij_dev int32 [B,2]   top2_gap_dev [B] or NULL
+ * n = number of rows AFTER the merge, n >= 2. */
+int nnj_step(nnj_handle* h, const float* state_dev, const uint8_t* mask_dev, const int32_t* ij_dev,
+             const float* logits_prev_dev, const int32_t* forced_next_dev, float* state_out_dev,
+             float* logits_out_dev, int32_t* chosen_ij_dev, float* top2_gap_dev, int32_t B, int32_t n, int32_t L,
+             void* ws_dev, size_t ws_bytes, void* stream);
+
 /* The whole eval+argmax branch of reinforce_rollout -- reference
  * finetune_rl_search.py:78-189 -- resident on the device with no host sync:
  * encode, then T-1 x (score new pairs, assemble table, argmax, merge).

@@ -47,6 +47,8 @@ _SIGS = {
     "nnj_profile_read": ([_vp, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int32], C.c_int),
     "nnj_debug_encoder_stop": ([_vp, C.c_int32], C.c_int),
     "nnj_numeric_status": ([_vp, C.POINTER(C.c_int32), _vp], C.c_int),
+    "nnj_step": ([_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int32, C.c_int32, C.c_int32, _vp, C.c_size_t,
+                  _vp], C.c_int),
 }
 
 _lib = None
@@ -256,6 +258,25 @@ class Nnj:
         if want_state:
             out["state"] = st
         return out
+
+    def step(self, state, mask, ij, logits_prev, forced_next=None):
+        """One loop iteration on the device: merge `ij` (env.step), score the new pairs and assemble the table
+        (decode_zxr), argmax.  state [B,n+1,L,D] -> dict(state [B,n,L,D], logits [B,P(n)], ij [B,2], top2_gap [B])."""
+        state = self._f32(state)
+        B, n1, L, _ = state.shape
+        n = n1 - 1
+        mask = self._u8(mask)
+        ij = self._i32(ij)
+        lp = self._f32(logits_prev)
+        fn = None if forced_next is None else self._i32(forced_next)
+        st = torch.empty((B, n, L, self.D), dtype=torch.float32, device=self.device)
+        lo = torch.empty((B, n * (n - 1) // 2), dtype=torch.float32, device=self.device)
+        cij = torch.empty((B, 2), dtype=torch.int32, device=self.device)
+        gap = torch.empty((B,), dtype=torch.float32, device=self.device)
+        ws = self.workspace(B, n1, L)
+        self._chk(self.lib.nnj_step(self.h, _p(state), _p(mask), _p(ij), _p(lp), _p(fn), _p(st), _p(lo), _p(cij),
+                                    _p(gap), B, n, L, _p(ws), ws.numel(), self._stream()))
+        return dict(state=st, logits=lo, ij=cij, top2_gap=gap)
 
     def check_numeric(self):
         """Synchronises the stream and raises if any pair-score table written since the last call held a

@@ -767,6 +767,22 @@ int nnj_select_pair(nnj_handle* h, const float* logits, int32_t* ij_out, float* 
   return NNJ_OK;
 }
 
+int nnj_step(nnj_handle* h, const float* state, const uint8_t* mask, const int32_t* ij, const float* logits_prev,
+             const int32_t* forced_next, float* state_out, float* logits_out, int32_t* chosen_ij, float* top2_gap,
+             int32_t B, int32_t n, int32_t L, void* ws, size_t ws_bytes, void* stream) {
+  if (int rc = ready(h)) return rc;
+  if (!state || !ij || !logits_prev || !state_out || !logits_out || !chosen_ij || n < 2)
+    return fail(h, NNJ_ERR_ARG, "nnj_step: bad argument (n = rows after the merge, >= 2)");
+  // the three stages run back to back on the stream; each checks its own shapes against the workspace
+  if (int rc = nnj_env_step(h, state, ij, state_out, B, n + 1, L, ws, ws_bytes, stream)) return rc;
+  if (int rc = nnj_pair_scores_incr(h, state_out, mask, ij, logits_prev, logits_out, B, n, L, ws, ws_bytes, stream)) return rc;
+  if (int rc = nnj_select_pair(h, logits_out, chosen_ij, top2_gap, B, n, stream)) return rc;
+  if (forced_next)
+    HIPCHK(h, hipMemcpyAsync(chosen_ij, forced_next, (size_t)B * 2 * sizeof(int32_t), hipMemcpyDeviceToDevice,
+                             static_cast<hipStream_t>(stream)));
+  return NNJ_OK;
+}
+
 static int rollout_impl(nnj_handle* h, const uint8_t* codes, const uint8_t* mask_in, int32_t B, int32_t T, int32_t L,
                         int32_t n_encode, const int32_t* forced, const float* uniforms, float inv_temp,
                         int32_t* merges_out, float* trace, float* gap, float* state_out, void* ws, size_t ws_bytes,

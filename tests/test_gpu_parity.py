@@ -191,6 +191,29 @@ def test_mask_none_equals_all_false(ctx_cache):
     assert torch.equal(a["logits"], b["logits"]) and torch.equal(a["merges"], b["merges"])
 
 
+def test_fused_step_reproduces_the_rollout(ctx_cache):
+    """nnj_step (merge + new scores + table + argmax in one call) iterated from the encoder output gives the
+    tables and merges of nnj_rollout_argmax bit for bit -- both run the same kernels in the same order."""
+    z, cfgs, packed = load_golden("synth_b2_t8_l128_s1")
+    g = ctx_cache(cfgs, packed)
+    codes, mask = torch.from_numpy(z["codes"]), torch.from_numpy(z["mask"])
+    B, T, L = z["codes"].shape
+    ref = g.rollout_argmax(codes, mask, want_trace=True, want_state=True)
+    tables = split_trace(ref["logits"].cpu().numpy(), T)
+    merges = ref["merges"].cpu().numpy()
+    state = g.encode(codes, mask)
+    logits = g.pair_scores_full(state, mask)
+    assert np.array_equal(logits.cpu().numpy(), tables[0])
+    ij, _ = g.select_pair(logits, T)
+    assert np.array_equal(ij.cpu().numpy(), merges[:, 0])
+    for step, n in enumerate(range(T - 1, 1, -1), start=1):
+        r = g.step(state, mask, ij, logits)
+        state, logits, ij = r["state"], r["logits"], r["ij"]
+        assert np.array_equal(logits.cpu().numpy(), tables[step]), f"table after merge {step}"
+        assert np.array_equal(ij.cpu().numpy(), merges[:, step])
+    g.check_numeric()
+
+
 def test_batch_shards_reproduce_the_whole_batch(ctx_cache):
     """Multi-GPU sharding is a contiguous split of the batch: a shard must give what the same
     alignments give inside the whole batch.  Launch geometry (site chunks per workgroup, small-batch kernels)
