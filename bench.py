@@ -70,7 +70,7 @@ def kernel_models(B, T, L, layers):
     return m
 
 
-def cpu_baseline(cfgs, packed, T, L, budget_s=15.0):
+def cpu_baseline(cfgs, packed, T, L, budget_s=8.0):
     """Times the CPU oracle (oracle/nnj_oracle.c, kind "port") on all host cores."""
     sys.path.insert(0, os.path.join(REPO, "tests"))
     from oracle_lib import Oracle
@@ -90,8 +90,19 @@ def cpu_baseline(cfgs, packed, T, L, budget_s=15.0):
         el = time.time() - t0
         if el >= budget_s or n >= 64:
             break
-    return dict(value=n / el, unit="trees/sec", cores=cores, kind="port",
-                sample=f"{n} single-MSA Argmax rollouts of {T} taxa x {L} sites, fp32 OpenMP oracle, {el:.1f} s")
+    out = dict(value=n / el, unit="trees/sec", cores=cores, kind="port",
+               sample=f"{n} single-MSA Argmax rollouts of {T} taxa x {L} sites, fp32 OpenMP oracle, {el:.1f} s")
+    # CPU model, and a one-thread figure beside the all-cores one (one rollout)
+    try:
+        with open("/proc/cpuinfo") as f:
+            out["cpu_model"] = next(l.split(":", 1)[1].strip() for l in f if l.startswith("model name"))
+    except (OSError, StopIteration):
+        out["cpu_model"] = "unknown"
+    o.set_threads(1)
+    t1 = time.time()
+    o.rollout_argmax(oh, mask)
+    out["one_thread"] = dict(value=1.0 / (time.time() - t1), unit="trees/sec", sample="1 rollout, 1 thread")
+    return out
 
 
 def main():
