@@ -105,6 +105,38 @@ def cpu_baseline(cfgs, packed, T, L, budget_s=8.0):
     return out
 
 
+def verify_sample(g, cfgs, packed, codes, merges, T, L, k=4):
+    """a fixed sample of the timed batch against the CPU oracle (outside the timed region).
+    The sampled alignments are rolled out again alone with the score trace and compared with the fp32 oracle
+    teacher-forced along the same merges: merge lists on every decisive step (RF = 0), and the score tables --
+    reported against the fp32 oracle and, with it, against the oracle's fp64 build: on this workload (stress
+    weights, i.i.d. sequences) two fp32 evaluations differ by about 1e-4 of the table scale, the fp32 oracle
+    itself is up to 1.5e-4 from the fp64 tables."""
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    from oracle_lib import Oracle
+    B = codes.shape[0]
+    idx = sorted({int(i) for i in np.linspace(0, B - 1, min(k, B))})
+    sub = codes[idx].contiguous()
+    r = g.rollout_argmax(sub, None, want_trace=True)
+    m = r["merges"].cpu().numpy()
+    same = bool(np.array_equal(m, merges.numpy()[idx]))
+    oh = synth.codes_to_onehot(sub.cpu().numpy()).astype(np.float32)
+    nomask = np.zeros((len(idx), L), bool)
+    ref = Oracle(cfgs, packed).rollout_argmax(oh, nomask, forced_merges=m)
+    ref64 = Oracle(cfgs, packed, "f64").rollout_argmax(oh, nomask, forced_merges=m)      # arbiter
+    hip = r["logits"].cpu().numpy()
+    scale = max(float(np.abs(ref["logits"]).max()), 1.0)
+    rel = lambda a, b: float(np.abs(a - b).max()) / scale  # noqa: E731
+    decisive = ref["top2_gap"] > 4e-4 * scale
+    agree = bool((ref["merges"][decisive] == m[decisive]).all())
+    return dict(trees=len(idx), same_merges_as_timed_run=same, merges_equal_on_decisive_steps=agree,
+                decisive_steps=int(decisive.sum()), steps=int(decisive.size),
+                score_err_rel_vs_fp32_oracle=rel(hip, ref["logits"]), score_err_rel_vs_fp64=rel(hip, ref64["logits"]),
+                fp32_oracle_err_rel_vs_fp64=rel(ref["logits"], ref64["logits"]),
+                note="errors relative to the largest score of the sampled tables; the fp64 build of the oracle "
+                     "arbitrates between two fp32-level evaluations (DESIGN.md 5a)")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -260,6 +292,7 @@ def main():
                                  "trees_per_sec": 1e3 / ms1}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfgs, packed, T, L)
+            out["verified"] = verify_sample(g, cfgs, packed, codes, merges, T, L)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
