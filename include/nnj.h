@@ -180,6 +180,12 @@ int nnj_rollout_sample(nnj_handle* h, const uint8_t* codes_dev, const uint8_t* m
  * call held a non-finite score: results must be discarded) and clears it.  The reference has no counterpart
  * (it computes in plain fp32); callers that fetch results to the host should call this once per batch. */
 int nnj_numeric_status(nnj_handle* h, int32_t* nonfinite_out, void* stream);
+/* Bits of the word nnj_numeric_status returns (0 = nothing to report).  NNJ_STATUS_BARRIER_TIMEOUT: kernels in
+ * which two or more waves of a workgroup build one LDS image meet at LDS-counter barriers with a bounded spin; a
+ * wave that gave up waiting (it never happens on a healthy device) computed on an incomplete image, so the results
+ * since the last call must be discarded exactly like non-finite ones. */
+#define NNJ_STATUS_NONFINITE 1
+#define NNJ_STATUS_BARRIER_TIMEOUT 2
 
 /* Kernel timing for bench.py's roofline object: when enabled, every kernel launch of
  * the entry points is bracketed by a HIP event pair on the launch stream, tagged with
@@ -190,6 +196,9 @@ int nnj_profile_enable(nnj_handle* h, int32_t on);
 int nnj_profile_kinds(void);
 const char* nnj_profile_kind_name(int32_t kind);
 int nnj_profile_read(nnj_handle* h, double* ms_out, int64_t* launches_out, int32_t cap);
+/* Launches since nnj_profile_enable that could NOT be bracketed (the event pool grows on demand; this counts
+ * failed event creations).  Non-zero means the per-kind times under-report: bench.py refuses to print them. */
+int nnj_profile_dropped(nnj_handle* h, int64_t* dropped_out);
 
 /* Test tap: make nnj_encode stop inside layer 0 (1 = after the row-attention block,
  * 2 = after the column-attention block, 0 = run everything). */

@@ -45,6 +45,7 @@ _SIGS = {
     "nnj_profile_kinds": ([], C.c_int),
     "nnj_profile_kind_name": ([C.c_int32], C.c_char_p),
     "nnj_profile_read": ([_vp, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int32], C.c_int),
+    "nnj_profile_dropped": ([_vp, C.POINTER(C.c_int64)], C.c_int),
     "nnj_debug_encoder_stop": ([_vp, C.c_int32], C.c_int),
     "nnj_numeric_status": ([_vp, C.POINTER(C.c_int32), _vp], C.c_int),
     "nnj_step": ([_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int32, C.c_int32, C.c_int32, _vp, C.c_size_t,
@@ -92,9 +93,11 @@ class Nnj:
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         if self.device.type != "cuda":
             raise RuntimeError("neuralnj_amd runs on HIP devices only")
+        if self.device.index is None:         # "cuda" = torch's current device, not device 0
+            self.device = torch.device("cuda", torch.cuda.current_device())
         m = cfgs.model
         self.cfg = NnjConfig(int(m.vocab_size), int(m.patch_size), int(m.embed_dim), int(m.num_enc_heads),
-                             int(m.num_enc_layers), int(self.device.index or 0))
+                             int(m.num_enc_layers), int(self.device.index))
         self.cfgs = cfgs
         self.D = int(m.embed_dim)
         self.h = _vp()
@@ -284,7 +287,11 @@ class Nnj:
         before trusting merge lists fetched to the host."""
         flag = C.c_int32(0)
         self._chk(self.lib.nnj_numeric_status(self.h, C.byref(flag), self._stream()))
-        if flag.value:
+        if flag.value & 2:
+            raise RuntimeError(
+                "a partner-wave barrier of a HIP kernel timed out (NNJ_STATUS_BARRIER_TIMEOUT): the results of "
+                "this batch were computed on incomplete LDS images and are invalid")
+        if flag.value & 1:
             raise FloatingPointError(
                 "non-finite pair scores: an operand magnitude exceeded the fp16 piece range (65504) of the "
                 "f16x3 GEMMs; the results of this batch are invalid")
@@ -321,7 +328,11 @@ class Nnj:
         k = self.lib.nnj_profile_kinds()
         ms = (C.c_double * k)()
         cnt = (C.c_int64 * k)()
+        dropped = C.c_int64(0)
+        self._chk(self.lib.nnj_profile_dropped(self.h, C.byref(dropped)))
         self._chk(self.lib.nnj_profile_read(self.h, ms, cnt, k))
+        if dropped.value:
+            raise RuntimeError(f"{dropped.value} kernel launches could not be timed (event creation failed)")
         return {self.lib.nnj_profile_kind_name(i).decode(): (ms[i], cnt[i]) for i in range(k)}
 
     def debug_encoder_stop(self, stage):

@@ -1,6 +1,12 @@
-"""Builds libnnj_hip.so (gfx950) in-tree with hipcc.  hipcc cross-compiles without a GPU."""
+"""Builds libnnj_hip.so (gfx950) in-tree with hipcc.  hipcc cross-compiles without a GPU.
+
+Staleness is decided by CONTENT, not by mtime: the sha256 of every source the library is compiled from
+(csrc/*.hip, csrc/*.hpp, include/nnj.h) and of the compile command is stored next to the library; a snapshot
+copied to another machine (fresh mtimes everywhere) is rebuilt only if a source really differs."""
 from __future__ import annotations
 
+import glob
+import hashlib
 import os
 import shutil
 import subprocess
@@ -8,28 +14,46 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libnnj_hip.so")
+STAMP = LIB + ".srchash"
 SOURCES = ["nnj_api.hip"]
-HEADERS = ["nnj_common.hpp", "nnj_encoder.hpp", "nnj_scorer.hpp", os.path.join("..", "..", "include", "nnj.h")]
+# No -ffast-math (nor -fassociative-math): the f16x3 operand split relies on exact IEEE subtractions
+# (x - fp16(x)); with reassociation the pieces no longer add up and the parity tests fail at 4e-4.
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value"]
+
+
+def source_files():
+    """Every file the library is compiled from (all headers of csrc/ are included by nnj_api.hip)."""
+    files = sorted(glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.hpp")))
+    files.append(os.path.join(HERE, "..", "include", "nnj.h"))
+    return files
+
+
+def source_hash() -> str:
+    h = hashlib.sha256(" ".join(FLAGS + SOURCES).encode())
+    for f in source_files():
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
 
 
 def _stale() -> bool:
-    if not os.path.exists(LIB):
+    if not os.path.exists(LIB) or not os.path.exists(STAMP):
         return True
-    t = os.path.getmtime(LIB)
-    return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
+    with open(STAMP) as f:
+        return f.read().strip() != source_hash()
 
 
 def build_hip(force: bool = False, verbose: bool = False) -> str:
     if not force and not _stale():
         return LIB
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    # No -ffast-math (nor -fassociative-math): the f16x3 operand split relies on exact IEEE subtractions
-    # (x - fp16(x)); with reassociation the pieces no longer add up and the parity tests fail at 4e-4.
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-Wno-unused-value", "-o", LIB] + SOURCES
+    cmd = [hipcc] + FLAGS + ["-o", LIB] + SOURCES
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, cwd=CSRC, check=True)
+    with open(STAMP, "w") as f:
+        f.write(source_hash() + "\n")
     return LIB
 
 

@@ -59,6 +59,7 @@ struct nnj_handle {
   std::vector<hipEvent_t> ev;
   std::vector<int> ev_kind;
   size_t ev_used = 0;
+  int64_t prof_dropped = 0;      // launches that could not be recorded (event creation failed): reported, never silent
   double prof_ms[PK_COUNT] = {0};
   int64_t prof_n[PK_COUNT] = {0};
 };
@@ -109,9 +110,19 @@ ScorerW scorer_ptrs(const nnj_handle* h) {
 struct Scope {
   nnj_handle* h; hipStream_t st; int kind; bool on;
   Scope(nnj_handle* h_, hipStream_t st_, int kind_) : h(h_), st(st_), kind(kind_), on(false) {
-    if (h->prof && h->ev_used + 2 <= h->ev.size()) {
+    if (!h->prof) return;
+    if (h->ev_used + 2 > h->ev.size()) {          // the pool grows on demand: no launch goes unrecorded
+      const size_t old = h->ev.size();
+      h->ev.resize(old + 2048);
+      h->ev_kind.resize(h->ev.size() / 2, 0);
+      for (size_t i = old; i < h->ev.size(); ++i)
+        if (hipEventCreate(&h->ev[i]) != hipSuccess) { h->ev.resize(i & ~(size_t)1); h->prof_dropped++; break; }
+    }
+    if (h->ev_used + 2 <= h->ev.size()) {
       on = true;
       hipEventRecord(h->ev[h->ev_used], st);
+    } else {
+      h->prof_dropped++;
     }
   }
   ~Scope() {
@@ -324,13 +335,13 @@ int launch_encoder(nnj_handle* h, const uint8_t* codes, const float* onehot, con
         const size_t lds = (size_t)(5 * 4096 + 4 * (64 * 36 + 64 * 32) + 16) * sizeof(float);
         if (int rc = set_lds(h, k_tok1p<2>, lds)) return rc;
         hipLaunchKernelGGL(k_tok1p<2>, dim3(grid1), dim3(512), lds, st, ctx, mask, x, attn_ptrs(h, h->lo[l].row),
-                           attn_ptrs(h, h->lo[l].col), B, T, C, d.Epad, dbg);
+                           attn_ptrs(h, h->lo[l].col), B, T, C, d.Epad, dbg, h->d_flag);
       } else {            // R <= 32: one wave per column, eight columns in flight
         const unsigned grid1 = (unsigned)std::min<long>((long)(((size_t)B * C + 7) / 8), (long)h->num_cu);
         const size_t lds = (size_t)(5 * 4096 + 8 * (32 * 36 + 32 * 32) + 16) * sizeof(float);
         if (int rc = set_lds(h, k_tok1p<1>, lds)) return rc;
         hipLaunchKernelGGL(k_tok1p<1>, dim3(grid1), dim3(512), lds, st, ctx, mask, x, attn_ptrs(h, h->lo[l].row),
-                           attn_ptrs(h, h->lo[l].col), B, T, C, d.Epad, dbg);
+                           attn_ptrs(h, h->lo[l].col), B, T, C, d.Epad, dbg, h->d_flag);
       }
     }
     if (l == 0 && (h->debug_stop == 1 || h->debug_stop == 2)) break;
@@ -385,7 +396,7 @@ int launch_pair_scores(nnj_handle* h, const RowSet& rs, const int* ij_prev, cons
 #define NNJ_IA(NG)                                                                                          \
   case NG:                                                                                                  \
     if (int rc = set_lds(h, k_inc_alpha16<NG>, lds)) return rc;                                             \
-    hipLaunchKernelGGL((k_inc_alpha16<NG>), grid, blk16, lds, st, rs, sw, ij_prev, base + w.alpha_part, n, C, g.cs); \
+    hipLaunchKernelGGL((k_inc_alpha16<NG>), grid, blk16, lds, st, rs, sw, ij_prev, base + w.alpha_part, n, C, g.cs, h->d_flag); \
     break;
         switch (ng) { NNJ_IA(1) NNJ_IA(2) NNJ_IA(3) NNJ_IA(4) }
 #undef NNJ_IA
@@ -420,12 +431,12 @@ int launch_pair_scores(nnj_handle* h, const RowSet& rs, const int* ij_prev, cons
         const size_t lds = (size_t)(3 * IMG64 + 4 * b6_floats(64, 64) + 16) * sizeof(float);
         if (int rc = set_lds(h, k_inc_score<2, true>, lds)) return rc;
         hipLaunchKernelGGL((k_inc_score<2, true>), grid, dim3(512), lds, st, rs, sw, ij_prev, base + w.alpha, mask,
-                           base + w.score_part, n, C, g.cs);
+                           base + w.score_part, n, C, g.cs, h->d_flag);
       } else {                                             // 17..32: the 32-pair kernel (k_inc_score_w<2> measured equal)
         const size_t lds = (size_t)(3 * IMG64 + 8 * b6_floats(64, 32) + 16) * sizeof(float);
         if (int rc = set_lds(h, k_inc_score<1, true>, lds)) return rc;
         hipLaunchKernelGGL((k_inc_score<1, true>), grid, dim3(512), lds, st, rs, sw, ij_prev, base + w.alpha, mask,
-                           base + w.score_part, n, C, g.cs);
+                           base + w.score_part, n, C, g.cs, h->d_flag);
       }
     }
     return NNJ_OK;
@@ -873,12 +884,8 @@ int nnj_profile_enable(nnj_handle* h, int32_t on) {
   if (!h) return fail(nullptr, NNJ_ERR_ARG, "null handle");
   HIPCHK(h, hipSetDevice(h->cfg.device));
   h->prof = on != 0;
-  if (h->prof && h->ev.empty()) {
-    h->ev.resize(16384);
-    h->ev_kind.assign(8192, 0);
-    for (auto& e : h->ev) HIPCHK(h, hipEventCreate(&e));
-  }
   h->ev_used = 0;
+  h->prof_dropped = 0;
   for (int k = 0; k < PK_COUNT; ++k) { h->prof_ms[k] = 0; h->prof_n[k] = 0; }
   return NNJ_OK;
 }
@@ -892,6 +899,12 @@ int nnj_numeric_status(nnj_handle* h, int32_t* nonfinite_out, void* stream) {
   HIPCHK(h, hipMemsetAsync(h->d_flag, 0, sizeof(int), st));
   HIPCHK(h, hipStreamSynchronize(st));
   *nonfinite_out = v;
+  return NNJ_OK;
+}
+
+int nnj_profile_dropped(nnj_handle* h, int64_t* dropped_out) {
+  if (!h || !dropped_out) return fail(h, NNJ_ERR_ARG, "nnj_profile_dropped: null argument");
+  *dropped_out = h->prof_dropped;
   return NNJ_OK;
 }
 

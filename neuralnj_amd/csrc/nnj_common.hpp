@@ -24,6 +24,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define NNJ_NHEAD 8           // heads
 #define NNJ_DH 8          // head dim
 #define NNJ_F 256         // FFN hidden
+// bits of the sticky per-handle status word (nnj_numeric_status)
+#define NNJ_FLAG_NONFINITE 1          // a pair-score table held a non-finite score
+#define NNJ_FLAG_BARRIER_TIMEOUT 2    // an LDS-counter barrier between partner waves gave up waiting
 
 // compile-time loop: f(std::integral_constant<int, I>) for I in [0, N)
 template <int I, int N, typename F>

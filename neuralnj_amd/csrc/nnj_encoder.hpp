@@ -92,21 +92,24 @@ __global__ __launch_bounds__(256) void k_embed(const uint8_t* __restrict__ codes
 // projections of a head-half go through per-column LDS images; with NWC = 2 the two waves of a column meet at a
 // pair barrier built on an LDS counter (never a workgroup barrier: the column slots run unsynchronised).
 // Persistent: the five weight images are staged once (80 KiB) + 8/NWC x (K image + V^T image) = 149 KiB.
-__device__ __forceinline__ void pair_barrier(int* cnt, int& epoch) {
+__device__ __forceinline__ void pair_barrier(int* cnt, int& epoch, int* flag) {
   // both waves of the pair arrive (LDS executes a wave's operations in order: its image writes are
   // in place before its increment), then wait until the counter shows both arrivals of this epoch
   epoch += 2;
   asm volatile("" ::: "memory");
   if ((threadIdx.x & 63) == 0) atomicAdd(cnt, 1);
-  // bounded spin: a lost partner ends in wrong numbers (caught by the parity tests), never in a hung GPU
-  for (int spins = 0; *reinterpret_cast<volatile int*>(cnt) < epoch && spins < (1 << 22); ++spins) __builtin_amdgcn_s_sleep(1);
+  // bounded spin: a lost partner never hangs the GPU; it sets the sticky status bit NNJ_FLAG_BARRIER_TIMEOUT
+  // (nnj_numeric_status), so the wrong numbers that follow are never returned silently
+  int spins = 0;
+  for (; *reinterpret_cast<volatile int*>(cnt) < epoch && spins < (1 << 22); ++spins) __builtin_amdgcn_s_sleep(1);
+  if (spins == (1 << 22) && (threadIdx.x & 63) == 0) atomicOr(flag, NNJ_FLAG_BARRIER_TIMEOUT);
   asm volatile("" ::: "memory");
 }
 
 template <int NWC>                                      // waves per column: 1 (R <= 32) or 2 (R <= 64)
 __global__ __launch_bounds__(512) void k_tok1p(const float* __restrict__ ctx, const uint8_t* __restrict__ mask,
                                                float* __restrict__ x, AttnW wr, AttnW wc, int B, int R, int C,
-                                               int Epad, int skip_col) {
+                                               int Epad, int skip_col, int* __restrict__ status) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int QKV = b6_floats(96, 64);                // q | k | v rows of one head half: one operand image
   static_assert(IMG64 == 4096 && QKV == 6144, "the LDS layout below assumes 4-byte operand elements");
@@ -226,7 +229,7 @@ __global__ __launch_bounds__(512) void k_tok1p(const float* __restrict__ ctx, co
           __builtin_amdgcn_sched_barrier(0);
         });
       }
-      if constexpr (NWC == 2) pair_barrier(cnt, epoch);  // the partner has finished reading the previous images
+      if constexpr (NWC == 2) pair_barrier(cnt, epoch, status);  // the partner has finished reading the previous images
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const f32x4 k4 = {kh[4 * g], kh[4 * g + 1], kh[4 * g + 2], kh[4 * g + 3]};
@@ -242,7 +245,7 @@ __global__ __launch_bounds__(512) void k_tok1p(const float* __restrict__ ctx, co
         *reinterpret_cast<uint2*>(dst) = make_uint2(h01, h23);
         *reinterpret_cast<uint2*>(dst + VPL) = make_uint2(m01, m23);
       }
-      if constexpr (NWC == 2) pair_barrier(cnt, epoch);  // both row tiles' K and V are in the images
+      if constexpr (NWC == 2) pair_barrier(cnt, epoch, status);  // both row tiles' K and V are in the images
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         // S^T[key j x query i]: A = K image rows (lane = key), B = this wave's q registers (lane = query)

@@ -428,12 +428,13 @@ __device__ __forceinline__ void inc_gate(f32x16 (&x)[NT][2], const IncRaw<NT>& r
 // softmax over r (k_alpha_softmax); the S rows are in registers anyway (the gate needs them).
 
 // barrier of the two waves that share a site slot (LDS counter; see k_tok1p's pair_barrier)
-__device__ __forceinline__ void pair_barrier_lds(int* cnt, int& epoch) {
+__device__ __forceinline__ void pair_barrier_lds(int* cnt, int& epoch, int* flag) {
   epoch += 2;
   asm volatile("" ::: "memory");
   if ((threadIdx.x & 63) == 0) atomicAdd(cnt, 1);
-  for (int spins = 0; *reinterpret_cast<volatile int*>(cnt) < epoch && spins < (1 << 22); ++spins)
-    __builtin_amdgcn_s_sleep(1);
+  int spins = 0;
+  for (; *reinterpret_cast<volatile int*>(cnt) < epoch && spins < (1 << 22); ++spins) __builtin_amdgcn_s_sleep(1);
+  if (spins == (1 << 22) && (threadIdx.x & 63) == 0) atomicOr(flag, NNJ_FLAG_BARRIER_TIMEOUT);   // never silent
   asm volatile("" ::: "memory");
 }
 
@@ -448,7 +449,8 @@ template <int KT, bool CTX>
 __global__ __launch_bounds__(512) void k_inc_score(RowSet rs, ScorerW w, const int* __restrict__ ij_prev,
                                                    const float* __restrict__ alpha,
                                                    const uint8_t* __restrict__ mask,
-                                                   float* __restrict__ score_part, int n, int C, int cs) {
+                                                   float* __restrict__ score_part, int n, int C, int cs,
+                                                   int* __restrict__ status) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Wg_l = smem;                                      // operand images
   float* S0_l = smem + IMG64;
@@ -521,7 +523,7 @@ __global__ __launch_bounds__(512) void k_inc_score(RowSet rs, ScorerW w, const i
         __builtin_amdgcn_sched_barrier(0);
       }
       if constexpr (CTX) {
-        if constexpr (KT == 2) pair_barrier_lds(cnt, epoch);   // the partner is done with the previous site's image
+        if constexpr (KT == 2) pair_barrier_lds(cnt, epoch, status);   // the partner is done with the previous site's image
         unsigned short* t16 = reinterpret_cast<unsigned short*>(img_t);
         constexpr int PL = 64 * 32 * KT;                       // plane stride in fp16 elements
 #pragma unroll
@@ -544,7 +546,7 @@ __global__ __launch_bounds__(512) void k_inc_score(RowSet rs, ScorerW w, const i
       inc_load_shared(sh, rs, L, bo, C, c, hh);
       inc_gate<1>(x, raw, sh, L, w.bh, hh);
     }
-    if constexpr (CTX && KT == 2) pair_barrier_lds(cnt, epoch);   // all 64 columns are in the image
+    if constexpr (CTX && KT == 2) pair_barrier_lds(cnt, epoch, status);   // all 64 columns are in the image
     const float mc = (mask && mask[(size_t)b * C + c]) ? 0.f : 1.f;     // seq_mask (model.py:96)
     const int cn = c + NSLOT;
     inc_load<1>(raw, rs, L, bo, n, C, cn < c1 ? cn : c, hh);           // prefetch behind the MFMAs (last: harmless reload)
@@ -876,7 +878,7 @@ __global__ __launch_bounds__(256) void k_assemble_argmax(const float* __restrict
     if (v > best || (v == best && p < besti)) { best = v; besti = p; }
     // a score that is not finite means an operand left the range of the fp16 pieces (nnj_common.hpp): sticky flag,
     // read back by nnj_numeric_status -- the library must not return a wrong tree silently
-    if (!(fabsf(v) <= 3.402823466e38f) && nonfinite) *nonfinite = 1;
+    if (!(fabsf(v) <= 3.402823466e38f) && nonfinite) atomicOr(nonfinite, NNJ_FLAG_NONFINITE);
   }
   red_v[tid] = best; red_i[tid] = besti;
   __syncthreads();

@@ -17,12 +17,13 @@
 
 // barrier of the NG waves that share a site slot (LDS counter; see k_tok1p's pair_barrier)
 template <int NG>
-__device__ __forceinline__ void group_barrier_lds(int* cnt, int& epoch) {
+__device__ __forceinline__ void group_barrier_lds(int* cnt, int& epoch, int* flag) {
   epoch += NG;
   asm volatile("" ::: "memory");
   if ((threadIdx.x & 63) == 0) atomicAdd(cnt, 1);
-  for (int spins = 0; *reinterpret_cast<volatile int*>(cnt) < epoch && spins < (1 << 22); ++spins)
-    __builtin_amdgcn_s_sleep(1);
+  int spins = 0;
+  for (; *reinterpret_cast<volatile int*>(cnt) < epoch && spins < (1 << 22); ++spins) __builtin_amdgcn_s_sleep(1);
+  if (spins == (1 << 22) && (threadIdx.x & 63) == 0) atomicOr(flag, NNJ_FLAG_BARRIER_TIMEOUT);   // never silent
   asm volatile("" ::: "memory");
 }
 
@@ -63,7 +64,8 @@ constexpr int T16_WAVES = 12;
 // part[b][sc*NSLOT+slot][pair r][r'].
 template <int NG>
 __global__ __launch_bounds__(64 * T16_WAVES) void k_inc_alpha16(RowSet rs, ScorerW w, const int* __restrict__ ij_prev,
-                                                                float* __restrict__ alpha_part, int n, int C, int cs) {
+                                                                float* __restrict__ alpha_part, int n, int C, int cs,
+                                                                int* __restrict__ status) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int NSLOT = T16_WAVES / NG;
   constexpr int IMG = 16 * NG * 64 * NPL / 2;              // floats of an image
@@ -125,14 +127,14 @@ __global__ __launch_bounds__(64 * T16_WAVES) void k_inc_alpha16(RowSet rs, Score
       }
       gate16(x, sr, ur, sm, um, w.bh, L.sgn, kq);
     }
-    if constexpr (NG > 1) group_barrier_lds<NG>(cnt, epoch);     // everyone is done with the previous image
+    if constexpr (NG > 1) group_barrier_lds<NG>(cnt, epoch, status);     // everyone is done with the previous image
     // row r of the image: chunk 4*ks + kq = this lane's tiles 2ks, 2ks+1
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       const int o = L.r * 8 + wswz6<8>(L.r, 4 * ks + kq);
       im4[o] = sf[ks].h; im4[PL + o] = sf[ks].m;
     }
-    if constexpr (NG > 1) group_barrier_lds<NG>(cnt, epoch);     // all rows are in the image
+    if constexpr (NG > 1) group_barrier_lds<NG>(cnt, epoch, status);     // all rows are in the image
     const int cn = c + NSLOT < c1 ? c + NSLOT : c;               // prefetch behind the MFMAs (last: harmless reload)
     load_v64(sr, Sr + (size_t)cn * 64, kq);
     V64 xp;

@@ -267,6 +267,68 @@ def main():
             run_case(nm, codes, mask, 0, "sharp", ref, keys=batch["seq_keys"])
         add(nm, fn)
 
+    # ---- round 2: BASELINE-size cases the round-1 set lacked
+    # reference-scale ("plain") weights at 50 x 1024, on tree-evolved and on i.i.d. (bench-style) data
+    def plain50_tree():
+        codes = synth.synth_codes_tree(1, 50, 1024, 2006)
+        run_case("plain_b1_t50_l1024_s6", codes, np.zeros((1, 1024), dtype=bool), 6, "plain", ref)
+    add("plain_b1_t50_l1024_s6", plain50_tree)
+
+    def plain50_iid():
+        codes = synth.synth_codes(1, 50, 1024, 2007, gap_frac=0.2)
+        run_case("plainiid_b1_t50_l1024_s7", codes, np.zeros((1, 1024), dtype=bool), 7, "plain", ref)
+    add("plainiid_b1_t50_l1024_s7", plain50_iid)
+
+    # the bench's own data law (synth_codes, gap 0.2) under the bench's weights (seed 0, sharp)
+    def bench_like():
+        codes = synth.synth_codes(1, 50, 1024, 1000, gap_frac=0.2)
+        run_case("benchlike_b1_t50_l1024_s0", codes, np.zeros((1, 1024), dtype=bool), 0, "sharp", ref)
+    add("benchlike_b1_t50_l1024_s0", bench_like)
+
+    # site counts that are not multiples of 4 / 16 / 32 (real alignments: 1,023 or 1,501 sites)
+    def ragged_small():
+        codes = synth.synth_codes_tree(2, 9, 30, 2008)
+        run_case("ragged_b2_t9_l30_s8", codes, np.zeros((2, 30), dtype=bool), 8, "sharp", ref)
+    add("ragged_b2_t9_l30_s8", ragged_small)
+
+    def ragged_mid():
+        codes = synth.synth_codes_tree(1, 20, 251, 2009)
+        codes[:, :, 240:] = 5
+        mask = np.zeros((1, 251), dtype=bool)
+        mask[:, 240:] = True
+        run_case("ragged_b1_t20_l251_s9", codes, mask, 9, "sharp", ref)
+    add("ragged_b1_t20_l251_s9", ragged_mid)
+
+    def ragged_big():
+        codes = synth.synth_codes_tree(1, 50, 1023, 2010)
+        run_case("ragged_b1_t50_l1023_s10", codes, np.zeros((1, 1023), dtype=bool), 10, "sharp", ref)
+    add("ragged_b1_t50_l1023_s10", ragged_big)
+
+    # more than 64 taxa: the reference's bundled evaluation set has 100-taxon alignments
+    def wide_synth():
+        codes = synth.synth_codes_tree(1, 100, 256, 2011)
+        run_case("synth_b1_t100_l256_s11", codes, np.zeros((1, 256), dtype=bool), 11, "sharp", ref)
+    add("synth_b1_t100_l256_s11", wide_synth)
+
+    def wide_70():
+        codes = synth.synth_codes_tree(2, 70, 64, 2012)
+        run_case("synth_b2_t70_l64_s12", codes, np.zeros((2, 64), dtype=bool), 12, "plain", ref)
+    add("synth_b2_t70_l64_s12", wide_70)
+
+    for length, fname in ((256, "G_l_256_n_100_0_0.01_101.phy"), (1024, None)):
+        d = os.path.join(REF, "data_gen", "data", "test", f"len{length}", "taxa100")
+        if fname is None:
+            fname = sorted(f for f in os.listdir(d) if f.endswith(".phy"))[0]
+        nm = "data_" + fname[:-4].replace(".", "p")
+        def fn(nm=nm, d=d, fname=fname):
+            from phydata import load_pi_instance  # reference loader
+            batch = load_pi_instance(os.path.join(d, fname))
+            onehot = batch["data"].numpy()
+            codes = synth.onehot_to_codes(onehot)
+            mask = (batch["seq_weights"].numpy() == 0)
+            run_case(nm, codes, mask, 0, "sharp", ref, keys=batch["seq_keys"])
+        add(nm, fn)
+
     for nm, fn in cases:
         fn()
 

@@ -62,3 +62,59 @@ def decisive_steps(top2_gap, logits_scale, rel=1e-4):
     """Steps whose top-2 gap is far above the allowed score error: the argmax there
     must agree exactly; elsewhere a flip is a legitimate fp32 near-tie."""
     return top2_gap > 4.0 * rel * logits_scale
+
+
+# ---------------------------------------------------------------- RF = 0 gate (free-running rollouts)
+def newick_from_merges(merges_b, keys_b):
+    """Replays one merge list [T-1,2] on host trees (neuralnj_amd.environment, no GPU) -> Newick string."""
+    from neuralnj_amd.environment import PhyInferEnv
+    env = PhyInferEnv(utils.shipped_config(), "cpu")
+    keys_b = [str(k) for k in keys_b]
+    env.init_states([[""] * len(keys_b)], [keys_b], None)
+    env.apply_merges(np.asarray(merges_b)[None])
+    return env.states[0].subtrees[0].utree_op_str
+
+
+def flat_pair(n, i, j):
+    return i * n - i * (i + 1) // 2 + (j - i - 1)
+
+
+def free_run_verdict(free_merges, free_tables, ref_merges, ref_tables, ref_newick, keys, truth_tables_fn):
+    """The RF = 0 gate for ONE alignment.
+
+    free_merges [T-1,2] / free_tables (list over steps of [P(n)]): the free-running rollout under test;
+    ref_*: the reference's (golden) or the fp32 oracle's free run of the same alignment;
+    truth_tables_fn(): list over steps of fp64 tables TEACHER-FORCED along ref_merges (evaluated lazily, only
+    when the merge lists differ).
+
+    Identical merge lists: RF = 0, done.  Otherwise the first divergent step must be a near-tie by the fp64
+    evaluation -- |t64[ref pick] - t64[our pick]| within the fp32 noise MEASURED at that step (the larger of
+    the two fp32-level tables' distance from the fp64 table, doubled: two independent roundings) -- and our
+    pick must be the reference's runner-up there.  Anything else is a failure of the path under test.
+    Returns a dict (rf, first_divergent_step, ...); raises AssertionError on a gate failure."""
+    T = len(keys)
+    mine = newick_from_merges(free_merges, keys)
+    rf, nrf = utils.rf_distance(mine, str(ref_newick))
+    row = dict(rf=int(rf), rf_norm=float(nrf), identical_merges=bool(np.array_equal(free_merges, ref_merges)))
+    if row["identical_merges"]:
+        assert rf == 0
+        return row
+    differs = np.any(np.asarray(free_merges) != np.asarray(ref_merges), axis=1)
+    s = int(np.argmax(differs))
+    n = T - s
+    assert n > 2, "the last decision has one candidate: merge lists cannot differ there"
+    t64 = np.asarray(truth_tables_fn()[s], dtype=np.float64)
+    ref_t, my_t = np.asarray(ref_tables[s], np.float64), np.asarray(free_tables[s], np.float64)
+    p_ref = flat_pair(n, int(ref_merges[s][0]), int(ref_merges[s][1]))
+    p_me = flat_pair(n, int(free_merges[s][0]), int(free_merges[s][1]))
+    gap64 = abs(float(t64[p_ref] - t64[p_me]))
+    noise = 2.0 * max(float(np.abs(ref_t - t64).max()), float(np.abs(my_t - t64).max()))
+    order = np.argsort(-ref_t, kind="stable")
+    row.update(first_divergent_step=s, rows_at_step=n, gap_fp64=gap64, fp32_noise_at_step=noise,
+               ref_top2_gap_fp32=float(ref_t[order[0]] - ref_t[order[1]]),
+               pick_is_ref_runner_up=bool(order[1] == p_me), fp64_prefers="ref" if t64[p_ref] >= t64[p_me] else "ours")
+    assert order[0] == p_ref, "the reference's own pick is not the argmax of its table"
+    assert gap64 <= noise, (f"step {s}: the free run left the reference's merge list where the fp64 evaluation "
+                            f"separates the two picks by {gap64:.3e} > fp32 noise {noise:.3e}")
+    assert row["pick_is_ref_runner_up"], f"step {s}: the pick is not the reference's runner-up"
+    return row

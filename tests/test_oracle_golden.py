@@ -10,7 +10,7 @@ SMALL = golden_names(max_taxa=20)
 BIG = golden_names(min_taxa=21)
 
 
-def _check(name, precision="f32"):
+def _check(name, precision="f32", rel=1e-4):
     z, cfgs, packed = load_golden(name)
     o = Oracle(cfgs, packed, precision)
     oh, mask = onehot_f32(z["codes"]), z["mask"]
@@ -29,7 +29,7 @@ def _check(name, precision="f32"):
                                    atol=1e-4 * np.abs(z["enc_slice"]).max())
         assert abs(r["state"].astype(np.float64).sum() - float(z["enc_checksum"])) \
             <= 1e-5 * float(z["enc_abs_checksum"])
-    assert_logits_close(r["logits"], z["logits"], rel=1e-4)
+    assert_logits_close(r["logits"], z["logits"], rel=rel)
     # argmax of each table: must agree wherever the reference's own top-2 gap is decisive
     scale = np.abs(z["logits"]).max()
     decisive = z["top2_gap"] > 4e-4 * scale
@@ -50,6 +50,42 @@ def test_oracle_matches_reference_small(name):
 @pytest.mark.parametrize("name", BIG[:2])
 def test_oracle_matches_reference_50x1024(name):
     _check(name)
+
+
+# round 2: reference-scale weights and bench-style data at 50 x 1024, a ragged site count, more than 64 taxa
+# (the reference's bundled 100-taxon evaluation alignments through its own loader)
+@pytest.mark.parametrize("name", ["plain_b1_t50_l1024_s6", "benchlike_b1_t50_l1024_s0", "ragged_b1_t50_l1023_s10",
+                                  "synth_b2_t70_l64_s12", "synth_b1_t100_l256_s11",
+                                  "data_G_l_256_n_100_0_0p01_101"])
+def test_oracle_matches_reference_round2_cases(name):
+    if name == "synth_b1_t100_l256_s11":
+        # 100 rows under the sharpened stress weights: the fp32 oracle's sequential sums are 1.2e-4 of the score
+        # scale from an fp64 evaluation (the reference's blocked kernels: 4.4e-5).  The fp64 build carries the
+        # 1e-4 pin of the semantics; the fp32 build is held to 2e-4 here.
+        _check(name, "f64")
+        _check(name, "f32", rel=2e-4)
+    else:
+        _check(name)
+
+
+def test_oracle_free_run_rf_gate():
+    """The RF = 0 gate of the GPU tests, exercised on the CPU: the fp32 oracle's free run against the
+    reference's free run, fp64 build as arbiter where the merge lists part (helpers.free_run_verdict)."""
+    from helpers import free_run_verdict
+    for name in ("synth_b1_t20_l256_s2", "ragged_b2_t9_l30_s8"):
+        z, cfgs, packed = load_golden(name)
+        oh, mask = onehot_f32(z["codes"]), z["mask"]
+        B, T, L = z["codes"].shape
+        r = Oracle(cfgs, packed).rollout_argmax(oh, mask)
+        mine, ref = split_trace(r["logits"], T), split_trace(z["logits"], T)
+        for b in range(B):
+            def truth(b=b):
+                t = Oracle(cfgs, packed, "f64").rollout_argmax(oh[b:b + 1], mask[b:b + 1],
+                                                                forced_merges=z["merges"][b:b + 1])
+                return [x[0] for x in split_trace(t["logits"], T)]
+            row = free_run_verdict(r["merges"][b], [x[b] for x in mine], z["merges"][b], [x[b] for x in ref],
+                                   z["newick"][b], z["keys"][b], truth)
+            assert row["rf"] == 0 or "first_divergent_step" in row
 
 
 @pytest.mark.parametrize("name", SMALL[:3])
