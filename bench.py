@@ -36,6 +36,9 @@ PEAK_F16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense fp16 / bf16 (v_mfma_
 # fp16 peak / 3.
 PEAK_F32_VIA_F16X3_TFLOPS = PEAK_F16_MFMA_TFLOPS / 3.0
 PEAK_HBM_GBS = 8000.0
+# the per-step kernels of the NJ loop (profile kinds of libnnj_hip.so)
+NJ_STEP_KINDS = ("k_pair_alpha_incr", "k_alpha_softmax", "k_pair_score_incr", "k_assemble_argmax", "k_agg_alpha",
+                 "k_agg_finish", "k_step_small")
 
 
 def kernel_models(B, T, L, layers):
@@ -105,14 +108,18 @@ def cpu_baseline(cfgs, packed, T, L, budget_s=8.0):
     return out
 
 
-def verify_sample(g, cfgs, packed, codes, merges, T, L, k=4):
-    """a fixed sample of the timed batch against the CPU oracle (outside the timed region).
-    The sampled alignments are rolled out again alone with the score trace and compared with the fp32 oracle
-    teacher-forced along the same merges: merge lists on every decisive step (RF = 0), and the score tables --
-    reported against the fp32 oracle and, with it, against the oracle's fp64 build: on this workload (stress
-    weights, i.i.d. sequences) two fp32 evaluations differ by about 1e-4 of the table scale, the fp32 oracle
-    itself is up to 1.5e-4 from the fp64 tables."""
+def verify_sample(g, cfgs, packed, codes, merges, T, L, k=8, threads=16, tol=1e-4):
+    """SURVEY 8(d) / VERDICT r1 item 1(d): a fixed sample of >= 8 trees of THIS rank's timed batch against the CPU
+    oracle, outside the timed region.  The sampled alignments are rolled out again alone with the score trace.
+      * RF: the HIP free run against the FREE runs of the fp32 oracle and of its fp64 build (Robinson-Foulds
+        distance of the trees; helpers.free_run_verdict arbitrates a differing merge list: first divergent step a
+        near-tie by fp64 and the HIP pick the runner-up -- anything else fails);
+      * scores: HIP tables against the fp32 and fp64 oracles teacher-forced along HIP's merges.
+    `ok` is False -- and bench.py exits non-zero -- when a merge list fails the gate, or when the score error against
+    the fp32 oracle exceeds `tol` while HIP is not at least as close to the fp64 tables as the fp32 oracle itself
+    (two fp32-level evaluations of this workload differ by about 1e-4; the fp64 build arbitrates)."""
     sys.path.insert(0, os.path.join(REPO, "tests"))
+    from helpers import free_run_verdict, newick_from_merges, split_trace
     from oracle_lib import Oracle
     B = codes.shape[0]
     idx = sorted({int(i) for i in np.linspace(0, B - 1, min(k, B))})
@@ -122,19 +129,83 @@ def verify_sample(g, cfgs, packed, codes, merges, T, L, k=4):
     same = bool(np.array_equal(m, merges.numpy()[idx]))
     oh = synth.codes_to_onehot(sub.cpu().numpy()).astype(np.float32)
     nomask = np.zeros((len(idx), L), bool)
-    ref = Oracle(cfgs, packed).rollout_argmax(oh, nomask, forced_merges=m)
-    ref64 = Oracle(cfgs, packed, "f64").rollout_argmax(oh, nomask, forced_merges=m)      # arbiter
+    o32, o64 = Oracle(cfgs, packed), Oracle(cfgs, packed, "f64")
+    o32.set_threads(threads)
+    free32 = o32.rollout_argmax(oh, nomask)
+    free64 = o64.rollout_argmax(oh, nomask)
+    same32 = np.array([np.array_equal(free32["merges"][i], m[i]) for i in range(len(idx))])
+    same64 = np.array([np.array_equal(free64["merges"][i], m[i]) for i in range(len(idx))])
+    # teacher-forced along HIP's merges (a free run that took the same merges IS that run)
+    ref, ref64 = dict(free32), dict(free64)
+    if not same32.all():
+        ref = o32.rollout_argmax(oh, nomask, forced_merges=m)
+    if not same64.all():
+        ref64 = o64.rollout_argmax(oh, nomask, forced_merges=m)
     hip = r["logits"].cpu().numpy()
     scale = max(float(np.abs(ref["logits"]).max()), 1.0)
     rel = lambda a, b: float(np.abs(a - b).max()) / scale  # noqa: E731
+    keys = [f"taxon{i + 1}" for i in range(T)]
+    hip_t = split_trace(hip, T)
+    rf_rows, gate_ok = [], True
+    for name, free, same_v, orc in (("fp32", free32, same32, o64), ("fp64", free64, same64, o64)):
+        ft = split_trace(free["logits"], T)
+        for i in range(len(idx)):
+            def truth(i=i, free=free):
+                t = orc.rollout_argmax(oh[i:i + 1], nomask[i:i + 1], forced_merges=free["merges"][i:i + 1])
+                return [x[0] for x in split_trace(t["logits"], T)]
+            try:
+                row = free_run_verdict(m[i], [x[i] for x in hip_t], free["merges"][i], [x[i] for x in ft],
+                                       newick_from_merges(free["merges"][i], keys), keys, truth)
+                row["gate"] = "pass"
+            except AssertionError as e:
+                row = dict(rf=None, gate="FAIL", why=str(e)[:300])
+                gate_ok = False
+            rf_rows.append(dict(tree=idx[i], oracle=name, **row))
+    e32, e64, o3264 = rel(hip, ref["logits"]), rel(hip, ref64["logits"]), rel(ref["logits"], ref64["logits"])
+    scores_ok = (e32 <= tol) or (e64 <= max(o3264, tol))
     decisive = ref["top2_gap"] > 4e-4 * scale
-    agree = bool((ref["merges"][decisive] == m[decisive]).all())
-    return dict(trees=len(idx), same_merges_as_timed_run=same, merges_equal_on_decisive_steps=agree,
+    return dict(trees=len(idx), ok=bool(gate_ok and scores_ok and same), same_merges_as_timed_run=same,
+                rf_vs_fp32_oracle=[r_["rf"] for r_ in rf_rows if r_["oracle"] == "fp32"],
+                rf_vs_fp64_oracle=[r_["rf"] for r_ in rf_rows if r_["oracle"] == "fp64"],
+                merge_lists_identical_to_fp32_oracle=int(same32.sum()), merge_lists_identical_to_fp64_oracle=int(same64.sum()),
+                arbitrated=[r_ for r_ in rf_rows if r_.get("gate") != "pass" or not r_.get("identical_merges", True)],
                 decisive_steps=int(decisive.sum()), steps=int(decisive.size),
-                score_err_rel_vs_fp32_oracle=rel(hip, ref["logits"]), score_err_rel_vs_fp64=rel(hip, ref64["logits"]),
-                fp32_oracle_err_rel_vs_fp64=rel(ref["logits"], ref64["logits"]),
-                note="errors relative to the largest score of the sampled tables; the fp64 build of the oracle "
-                     "arbitrates between two fp32-level evaluations (DESIGN.md 5a)")
+                merges_equal_on_decisive_steps=bool((ref["merges"][decisive] == m[decisive]).all()),
+                score_tolerance=tol, score_err_rel_vs_fp32_oracle=e32, score_err_rel_vs_fp64=e64,
+                fp32_oracle_err_rel_vs_fp64=o3264, scores_ok=bool(scores_ok), rf_gate_ok=bool(gate_ok),
+                note="errors relative to the largest score of the sampled tables; the run FAILS (exit 3) when a "
+                     "merge list leaves the oracle's without being an fp64-certified near-tie, or when the score "
+                     "error against the fp32 oracle exceeds the tolerance while HIP is farther from the fp64 "
+                     "tables than the fp32 oracle itself")
+
+
+def compat_path(cfgs, packed, codes, T, L, dev):
+    """Throughput of the API-compatible step-by-step path (neuralnj_amd.rollout.reinforce_rollout_argmax: the
+    reference's own call sequence through model.PhyloATTN / environment.PhyInferEnv, one host round trip per
+    step) on the same batch: what "finetune_rl_search.py drops in unchanged" delivers, next to the fused
+    nnj_rollout_argmax figure that is `value`."""
+    from neuralnj_amd.environment import PhyInferEnv
+    from neuralnj_amd.model import PhyloATTN
+    from neuralnj_amd.rollout import reinforce_rollout_argmax
+    agent = PhyloATTN(cfgs)
+    sd = weights.seeded_state(cfgs, 0, "sharp")
+    agent.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    agent = agent.to(dev)
+    B = codes.shape[0]
+    keys = [[f"taxon{i + 1}" for i in range(T)] for _ in range(B)]
+    c = codes.cpu().numpy()
+    batch = {"data": torch.from_numpy(synth.codes_to_onehot(c)), "seqs": [[""] * T for _ in range(B)],
+             "seq_keys": keys, "seq_weights": torch.ones((B, L), dtype=torch.float32)}
+    env = PhyInferEnv(cfgs, dev)
+    reinforce_rollout_argmax(batch, agent, env)            # warm-up (workspace, weights)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    env = PhyInferEnv(cfgs, dev)
+    _, _, m = reinforce_rollout_argmax(batch, agent, env)
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    return dict(workload=f"Batch={B}, {T}x{L}, reinforce_rollout_argmax (model/environment API, per-step host loop)",
+                trees_per_sec=B / dt, ms_per_rollout=1e3 * dt), m
 
 
 def main():
@@ -146,9 +217,11 @@ def main():
     ap.add_argument("--taxa", type=int, default=50)
     ap.add_argument("--sites", type=int, default=1024)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-verify", action="store_true", help="skip the oracle verification of a sample of the batch")
+    ap.add_argument("--no-compat", action="store_true", help="skip the API-compatible (per-step) path figure")
     ap.add_argument("--no-single-msa", action="store_true",
                     help="skip the Batch=1 latency figure (keeps a rocprofv3 summary of this command to the timed workload)")
-    ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel HIP events")
+    ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel HIP events pass")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -200,18 +273,27 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    if not args.no_profile:
-        g.profile_enable(True)
+    # ---- the timed region: K steps, NO per-kernel events (they are collected in a separate pass)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         merges = step()
     barrier()
-    elapsed = time.perf_counter() - t0
-    prof = {} if args.no_profile else g.profile_read()
-    if not args.no_profile:
-        g.profile_enable(False)
+    elapsed_local = time.perf_counter() - t0
+    elapsed = elapsed_local
     g.check_numeric()                       # outside the timed region: no score table of the run was non-finite
+    # ---- separate profiled pass: every launch bracketed by HIP events on its stream (same work, same inputs)
+    prof, prof_steps = {}, 0
+    if not args.no_profile:
+        prof_steps = min(args.steps, 3)
+        g.profile_enable(True)
+        for _ in range(prof_steps):
+            m2 = step()
+        torch.cuda.synchronize(dev)
+        prof = g.profile_read()
+        g.profile_enable(False)
+        assert torch.equal(m2, merges), "the profiled pass did not reproduce the timed pass"
+    per_rank = None
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -220,6 +302,31 @@ def main():
         gathered = [torch.empty_like(merges, device=cdev) for _ in range(world)]
         dist.all_gather(gathered, merges.to(cdev))
         assert all(tuple(x.shape) == (B, T - 1, 2) for x in gathered)
+        # per-rank throughput and the device each rank really ran on (distinct ordinals = one GPU per rank)
+        info = torch.tensor([B * args.steps / elapsed_local, float(torch.cuda.current_device())],
+                            dtype=torch.float64, device=cdev)
+        infos = [torch.empty_like(info) for _ in range(world)]
+        dist.all_gather(infos, info)
+        per_rank = {"trees_per_sec": [float(x[0]) for x in infos], "device_ordinal": [int(x[1]) for x in infos],
+                    "distinct_devices": len({int(x[1]) for x in infos})}
+    # ---- every rank verifies >= 8 of ITS trees against the oracle, outside the timed region; pass flags are reduced
+    verified = None
+    if not args.no_verify:
+        try:
+            cores = len(os.sched_getaffinity(0))
+        except AttributeError:
+            cores = os.cpu_count() or 1
+        verified = verify_sample(g, cfgs, packed, codes, merges, T, L, k=8, threads=max(1, min(16, cores // world)))
+        if dist is not None:
+            okf = torch.tensor([1.0 if verified["ok"] else 0.0], dtype=torch.float64, device=cdev)
+            dist.all_reduce(okf, op=dist.ReduceOp.MIN)
+            errs = torch.tensor([verified["score_err_rel_vs_fp32_oracle"], verified["score_err_rel_vs_fp64"]],
+                                dtype=torch.float64, device=cdev)
+            dist.all_reduce(errs, op=dist.ReduceOp.MAX)
+            verified["all_ranks_ok"] = bool(okf.item() == 1.0)
+            verified["worst_rank_score_err_rel_vs_fp32_oracle"] = float(errs[0])
+            verified["worst_rank_score_err_rel_vs_fp64"] = float(errs[1])
+            verified["ranks_verified"] = world
     trees = world * B * args.steps
     out = {
         "metric": "trees/sec (Argmax) on 50-taxa x 1024-site MSAs",
@@ -228,52 +335,80 @@ def main():
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "precision": "fp32 results (GEMM operands split into two fp16 pieces on the fp16 matrix pipe, three piece "
                      "products per fp32 product, fp32 accumulation; score tables as close to an fp64 evaluation as "
-                     "the reference's own fp32 tables, profiles/r01/parity_margin_f16x3.json)",
+                     "the reference's own fp32 tables, profiles/r02/parity_margin.json)",
         "config": {"workload": f"Batch={B} synthetic {T}x{L} MSAs per GPU, Argmax rollout (BASELINE configs[2]; "
                                f"configs[3] when sharded over 8 GPUs)",
                    "batch_per_gpu": B, "taxa": T, "sites": L, "gap_frac": 0.2, "model": "dim64 heads8 layers6 patch1",
                    "weights": "seeded random (no checkpoint ships with the reference)"},
     }
+    if per_rank is not None:
+        out["per_rank"] = per_rank
     if rank == 0:
         roof = None
         if prof:
             models = kernel_models(B, T, L, int(cfgs.model.num_enc_layers))
             name, (ms, cnt) = max(prof.items(), key=lambda kv: kv[1][0])
             total_ms = sum(v[0] for v in prof.values())
+            tpath = os.path.join(REPO, "profiles", "traffic.json")
+            tfile = json.load(open(tpath)) if os.path.exists(tpath) and (B, T, L) == (256, 50, 1024) else {}
+
+            def measured_traffic(kind):
+                # HBM bytes per launch from the committed rocprofv3 --pmc passes of this round's build (profiles/traffic.json
+                # names the passes); PMC counters cannot be collected from inside the process, so a figure is shown only
+                # when that file was made from the same source hash as the library running now
+                from neuralnj_amd import build as nbuild
+                if tfile.get("source_hash") != nbuild.source_hash():
+                    return None
+                return tfile.get("per_kind", {}).get(kind, {}).get("hbm_bytes_per_launch")
             if name in models and cnt > 0:
                 avg_s = ms / cnt / 1e3
                 ach = models[name]["flops"] / avg_s / 1e12
-                traffic = None
-                tpath = os.path.join(REPO, "profiles", "traffic.json")
-                if os.path.exists(tpath) and (B, T, L) == (256, 50, 1024):
-                    # measured HBM bytes per launch (rocprofv3 PMC passes, see profiles/traffic.json "source")
-                    traffic = json.load(open(tpath)).get("per_kind", {}).get(name, {}).get("hbm_bytes_per_launch")
                 peak = models[name]["peak"]
                 roof = {"kernel": name, "bound": "mfma", "achieved": ach, "peak": peak,
-                        "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic,
+                        "unit": "TFLOP/s", "frac": ach / peak, "traffic": measured_traffic(name),
                         "peak_basis": ("dense fp16 MFMA peak / 3 (fp32 GEMM as three fp16 piece products, fp32 accumulate)"
                                        if peak == PEAK_F32_VIA_F16X3_TFLOPS else "dense fp32 MFMA peak"),
                         # the same kernel against the HBM roofline, by its algorithmic bytes
                         "hbm": {"achieved": models[name]["bytes"] / avg_s / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                 "frac": models[name]["bytes"] / avg_s / 1e9 / PEAK_HBM_GBS},
-                        "avg_launch_ms": ms / cnt, "launches": cnt,
+                        "avg_launch_ms": ms / cnt, "launches": cnt, "profiled_steps": prof_steps,
                         "share_of_kernel_time": ms / total_ms if total_ms else None,
                         "algorithmic_flops_per_launch": models[name]["flops"],
                         "algorithmic_bytes_per_launch": models[name]["bytes"]}
-            out["kernel_ms_per_step"] = {k: round(v[0] / args.steps, 3) for k, v in prof.items() if v[1]}
+            out["kernel_ms_per_step"] = {k: round(v[0] / prof_steps, 3) for k, v in prof.items() if v[1]}
+            out["kernel_events"] = "separate pass of %d rollouts after the timed region (same inputs, merges identical)" % prof_steps
             if roof is not None:
                 # the BASELINE "NJ Q-matrix kernel" quantity: all per-step kernels of the NJ loop against
                 # the HBM roofline, bytes = sum over steps of (n+1) rows + the score tables = 0.334 GB per 50x1024 tree
-                step_kinds = ("k_pair_alpha_incr", "k_pair_score_incr", "k_assemble_argmax", "k_agg_alpha", "k_agg_finish")
-                step_ms = sum(prof[k][0] for k in step_kinds if k in prof) / args.steps
+                step_kinds = NJ_STEP_KINDS
+                step_ms = sum(prof[k][0] for k in step_kinds if k in prof) / prof_steps
                 C, D = L, 64
                 P = lambda n: n * (n - 1) // 2  # noqa: E731
                 step_bytes = B * sum((n + 1) * C * D * 4 + 4 * (P(n + 1) + n + P(n)) for n in range(T - 1, 1, -1))
                 if step_ms > 0:
                     gbs = step_bytes / (step_ms / 1e3) / 1e9
-                    roof["nj_loop_hbm"] = {"kernels": list(step_kinds), "ms_per_rollout": step_ms,
+                    meas = [measured_traffic(k) for k in step_kinds if k in prof and prof[k][1]]
+                    meas_total = (sum(mt * prof[k][1] / prof_steps for k, mt in
+                                      zip([k for k in step_kinds if k in prof and prof[k][1]], meas))
+                                  if meas and all(x is not None for x in meas) else None)
+                    roof["nj_loop_hbm"] = {"kernels": [k for k in step_kinds if k in prof and prof[k][1]],
+                                           "ms_per_rollout": step_ms,
                                            "algorithmic_bytes_per_rollout": step_bytes, "achieved": gbs,
-                                           "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS}
+                                           "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
+                                           "measured_bytes_per_rollout": meas_total,
+                                           "measured_over_algorithmic": (meas_total / step_bytes) if meas_total else None}
+                # the memory-only kernel of the step on its own: table assemble + argmax + state/live
+                # update; bytes = 4*(P(n+1) + n + 2 P(n)) per step and alignment (read old table + new scores, write the
+                # table, read it back for the runner-up)
+                if "k_assemble_argmax" in prof and prof["k_assemble_argmax"][1]:
+                    a_ms, a_cnt = prof["k_assemble_argmax"]
+                    a_bytes = B * sum(4 * (P(n + 1) + n + 2 * P(n)) for n in range(T, 1, -1)) / max(1, T - 1)
+                    a_s = a_ms / a_cnt / 1e3
+                    roof["assemble_hbm"] = {"kernel": "k_assemble_argmax", "avg_launch_ms": a_ms / a_cnt, "launches": a_cnt,
+                                            "algorithmic_bytes_per_launch": a_bytes, "achieved": a_bytes / a_s / 1e9,
+                                            "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": a_bytes / a_s / 1e9 / PEAK_HBM_GBS,
+                                            "note": "1.5 MB per launch at B=256: a launch-latency-sized kernel, far too "
+                                                    "small to approach the HBM roofline (8 TB/s x 5 us = 40 MB)"}
         out["roofline"] = roof
         if world == 1 and not args.no_single_msa:
             # BASELINE configs[1] beside the batched figure: ONE 50 x 1024 alignment per rollout (latency bound)
@@ -290,12 +425,19 @@ def main():
             ms1 = 1e3 * (time.perf_counter() - t1) / reps
             out["single_msa"] = {"workload": f"Batch=1, {T}x{L} (BASELINE configs[1])", "ms_per_tree": ms1,
                                  "trees_per_sec": 1e3 / ms1}
+        if world == 1 and not args.no_compat:
+            cp, m_api = compat_path(cfgs, packed, codes, T, L, dev)
+            cp["merges_equal_fused_path_on_all_trees"] = bool(np.array_equal(m_api, merges.numpy()))
+            out["compat_path"] = cp
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfgs, packed, T, L)
-            out["verified"] = verify_sample(g, cfgs, packed, codes, merges, T, L)
+        if verified is not None:
+            out["verified"] = verified
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
+    if verified is not None and not verified.get("all_ranks_ok", verified["ok"]):
+        sys.exit(3)
 
 
 if __name__ == "__main__":

@@ -146,7 +146,6 @@ int set_lds(nnj_handle* h, K kernel, size_t bytes) {
 int check_shape(nnj_handle* h, int B, int T, int L) {
   if (B <= 0 || T < 1 || L <= 0) return fail(h, NNJ_ERR_ARG, "bad shape B=%d T=%d L=%d", B, T, L);
   if (T > 64) return fail(h, NNJ_ERR_UNSUPPORTED, "T=%d: this build covers up to 64 rows (one column per wave, row-attention head dim 512)", T);
-  if (L % 4) return fail(h, NNJ_ERR_UNSUPPORTED, "L=%d must be a multiple of 4", L);
   return NNJ_OK;
 }
 
