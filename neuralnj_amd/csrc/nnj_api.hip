@@ -17,6 +17,7 @@
 #include "nnj_rowattn.hpp"
 #include "nnj_scorer.hpp"
 #include "nnj_scorer16.hpp"
+#include "nnj_scorer_wide.hpp"
 
 namespace {
 
@@ -145,7 +146,7 @@ int set_lds(nnj_handle* h, K kernel, size_t bytes) {
 // ---- shapes the kernels cover
 int check_shape(nnj_handle* h, int B, int T, int L) {
   if (B <= 0 || T < 1 || L <= 0) return fail(h, NNJ_ERR_ARG, "bad shape B=%d T=%d L=%d", B, T, L);
-  if (T > 64) return fail(h, NNJ_ERR_UNSUPPORTED, "T=%d: this build covers up to 64 rows (one column per wave, row-attention head dim 512)", T);
+  if (T > 256) return fail(h, NNJ_ERR_UNSUPPORTED, "T=%d: this build covers up to 256 rows (eight waves per alignment column, 256-row scorer images)", T);
   return NNJ_OK;
 }
 
@@ -153,13 +154,39 @@ struct EncDims { int Epad, NT; size_t hm; };   // hm = floats of the head-major 
 EncDims enc_dims(int B, int T, int C) {
   EncDims d;
   d.Epad = (T * 8 + 15) / 16 * 16;             // row length of ctx [B,8,C,Epad]
-  d.NT = T <= 32 ? 1 : 2;
+  d.NT = T <= 32 ? 1 : (T <= 64 ? 2 : (T <= 128 ? 4 : 8));   // waves per column in k_tok1p
   d.hm = (size_t)B * NNJ_NHEAD * C * d.Epad;
   return d;
 }
 
 // pair-scorer launch geometry
-struct PairGeom { int npairs, tpw, pg, ppad, nsc, nsc_a, cs, blocks; };   // nsc / nsc_a: partial sets of the scores / of alpha
+struct PairGeom {
+  int npairs, tpw, pg, ppad, nsc, nsc_a, cs, blocks;     // nsc / nsc_a: partial sets of the scores / of alpha
+  const float* score_src = nullptr;                      // where k_assemble_argmax reads the partials (nullptr: w.score_part)
+};
+
+// more than 64 live rows: star launches of nnj_scorer_wide.hpp
+WideGeom wide_geom(int n, int B, int C, bool full) {
+  WideGeom g;
+  g.PT = n <= 128 ? 1 : 2;
+  g.RP = 128 * g.PT;
+  g.M = full ? n - 1 : 1;
+  long nsc = (512 + (long)g.M * B - 1) / ((long)g.M * B);            // ~2 workgroups per CU
+  const long max_nsc = (C + 15) / 16;                                 // at least 16 sites per workgroup (weight staging)
+  if (nsc > max_nsc) nsc = max_nsc;
+  // at most 128 sites per workgroup: the alpha logits are sums over 64 C products, accumulated by the matrix pipe in
+  // fp32 site after site; over thousands of sites the roundings of the running sum reach 1e-4 of the scores
+  // (measured at 200 x 4096).  Chunk sums of <= 128 sites, added in k_wide_softmax, keep them at the fp32 level.
+  if (nsc < (C + 127) / 128) nsc = (C + 127) / 128;
+  if (nsc < 1) nsc = 1;
+  g.cs = (int)((C + nsc - 1) / nsc);
+  g.nsc = (C + g.cs - 1) / g.cs;
+  const size_t per_star = (size_t)B * g.nsc * g.RP * g.RP;            // floats of alpha partials per star
+  size_t mb = ((size_t)1 << 29) / per_star;                           // <= 2 GiB of partials per launch
+  if (mb < 1) mb = 1;
+  g.MB = (int)std::min<size_t>(mb, (size_t)g.M);
+  return g;
+}
 PairGeom pair_geom(int mode, int n, int B, int C) {
   PairGeom g;
   if (mode == PAIRS_INCR) {
@@ -194,7 +221,7 @@ PairGeom pair_geom(int mode, int n, int B, int C) {
 
 // workspace regions of the NJ loop (after the state/slots buffer), in floats
 struct LoopWs {
-  size_t U, Kp, beta, alpha_part, alpha, score_part, agg_part, logits0, logits1, merged, live, ij, end;
+  size_t U, Kp, beta, alpha_part, alpha, score_part, full, agg_part, logits0, logits1, merged, live, ij, end;
 };
 LoopWs loop_ws(int B, int T, int C) {
   LoopWs w;
@@ -205,19 +232,31 @@ LoopWs loop_ws(int B, int T, int C) {
   w.U = take(rows);
   w.Kp = take(rows);
   w.beta = take((size_t)B * T * nt32);
-  size_t ap = 0, al = 0, sp = 0;
+  size_t ap = 0, al = 0, sp = 0, fu = 0;
+  const int Tn = std::min(T, 64);                                  // the 64-row kernels
   for (int mode = 0; mode < 2; ++mode)
-    for (int n : {T, std::min(T, 48), std::min(T, 32), std::min(T, 16)}) {      // the incremental geometry changes at n = 48, 32 and 16
+    for (int n : {Tn, std::min(Tn, 48), std::min(Tn, 32), std::min(Tn, 16)}) {   // the incremental geometry changes at n = 48, 32 and 16
       if (n < 2) continue;
       PairGeom g = pair_geom(mode, n, B, C);
       ap = std::max(ap, (size_t)B * g.nsc_a * g.ppad * 64);
       al = std::max(al, (size_t)B * g.ppad * 64);
       sp = std::max(sp, (size_t)B * g.nsc * g.ppad);
     }
+  if (T > 64) {                                                    // the star kernels (more than 64 live rows)
+    for (int full = 0; full < 2; ++full)
+      for (int n : {T, std::min(T, 128)}) {
+        const WideGeom g = wide_geom(n, B, C, full != 0);
+        ap = std::max(ap, (size_t)B * g.MB * g.nsc * g.RP * g.RP);
+        al = std::max(al, (size_t)B * g.MB * g.RP * g.RP);
+        sp = std::max(sp, (size_t)B * g.MB * g.nsc * g.RP);
+      }
+    fu = (size_t)B * T * (T - 1) / 2;
+  }
   w.alpha_part = take(ap);
   w.alpha = take(al);
   w.score_part = take(sp);
-  w.agg_part = take((size_t)B * ((C + 15) / 16) * 64);
+  w.full = take(fu);
+  w.agg_part = take((size_t)B * ((C + 15) / 16) * (T > 128 ? 256 : (T > 64 ? 128 : 64)));
   w.logits0 = take((size_t)B * T * (T - 1) / 2 + 1);
   w.logits1 = take((size_t)B * T * (T - 1) / 2 + 1);
   w.merged = take((size_t)B * C * 64);
@@ -275,10 +314,10 @@ int launch_encoder(nnj_handle* h, const uint8_t* codes, const float* onehot, con
   {
     Scope sc(h, st, PK_EMBED);
     const size_t lds = 4096 * sizeof(float);
-    if (int rc = set_lds(h, k_embed<NT>, lds)) return rc;
+    if (int rc = set_lds(h, k_embed, lds)) return rc;
     const float* wp = h->d_w;
     const EmbedW ew{wp + h->oE0, wp + h->oe0, wp + h->oE2, wp + h->oe2};
-    hipLaunchKernelGGL(k_embed<NT>, dim3(colblocks), dim3(256), lds, st, codes, onehot, ew, lut, x, B, T, C);
+    hipLaunchKernelGGL(k_embed, dim3(colblocks), dim3(256), lds, st, codes, onehot, ew, lut, x, B, T, C);
     hipLaunchKernelGGL(k_key_classes, dim3((unsigned)(((size_t)B * g6.Cp + 255) / 256)), dim3(256), 0, st, mask, cls, B,
                        C, g6.Cp);
     // V6 keys beyond the alignment meet probabilities that are exactly 0: they only have to be finite
@@ -301,17 +340,26 @@ int launch_encoder(nnj_handle* h, const uint8_t* codes, const float* onehot, con
     }
     {
       Scope sc(h, st, PK_ROW_S);
-      constexpr int QW = 128;
-      const size_t lds = (size_t)RsShape<QW>::NST * RsShape<QW>::STAGE;
-      if (int rc = set_lds(h, k_row_s<QW>, lds)) return rc;
-      const long nblocks = (long)(nbh + 7) / 8 * 8 * g6.nrb * (g6.Cp / QW);
-      const unsigned grid = (unsigned)nblocks;
-      hipLaunchKernelGGL(k_row_s<QW>, dim3(grid), dim3(256), lds, st, (const uint8_t*)Q6, (const uint8_t*)K6,
-                         (const uint8_t*)cls, Sbuf, Mbuf, g6, nbh, fill);
+      const float qs = 1.0f / (sqrtf((float)NNJ_DH) * sqrtf((float)T));
+      if (T <= 64) {
+        constexpr int QW = 128;
+        const size_t lds = (size_t)RsShape<QW>::NST * RsShape<QW>::STAGE;
+        if (int rc = set_lds(h, k_row_s<QW>, lds)) return rc;
+        const unsigned grid = (unsigned)((long)(nbh + 7) / 8 * 8 * g6.nrb * (g6.Cp / QW));
+        hipLaunchKernelGGL(k_row_s<QW>, dim3(grid), dim3(256), lds, st, (const uint8_t*)Q6, (const uint8_t*)K6,
+                           (const uint8_t*)cls, Sbuf, Mbuf, g6, nbh, fill, qs);
+      } else {              // more than 64 rows: chunked accumulation of the 8R-term logits (see k_row_s)
+        constexpr int QW = 64, CHK = 8;
+        const size_t lds = (size_t)RsShape<QW>::NST * RsShape<QW>::STAGE;
+        if (int rc = set_lds(h, (k_row_s<QW, CHK>), lds)) return rc;
+        const unsigned grid = (unsigned)((long)(nbh + 7) / 8 * 8 * g6.nrb * (g6.Cp / QW));
+        hipLaunchKernelGGL((k_row_s<QW, CHK>), dim3(grid), dim3(256), lds, st, (const uint8_t*)Q6, (const uint8_t*)K6,
+                           (const uint8_t*)cls, Sbuf, Mbuf, g6, nbh, fill, qs);
+      }
     }
     {
       Scope sc(h, st, PK_ROW_PV);
-      const unsigned grid = (unsigned)((nbh + 7) / 8 * 8 * (g6.Cp / 128));
+      const unsigned grid = (unsigned)((nbh + 7) / 8 * 8 * (g6.Cp / 128) * g6.nech);
 #define NNJ_PV_CASE(N)                                                                                   \
   case N: {                                                                                              \
     const size_t stg = (N * NPL * 1024 + 4095) / 4096 * 4096, lds = (4 * stg <= 163840 ? 4 : 3) * stg;        \
@@ -319,29 +367,23 @@ int launch_encoder(nnj_handle* h, const uint8_t* codes, const float* onehot, con
     hipLaunchKernelGGL(k_row_pv<N>, dim3(grid), dim3(256), lds, st, (const uint8_t*)V6, (const float*)Sbuf, \
                        (const float*)Mbuf, ctx, g6, nbh);                                                \
   } break;
-      switch (g6.ET) {
+      switch (g6.ETc) {
         NNJ_PV_CASE(1) NNJ_PV_CASE(2) NNJ_PV_CASE(4) NNJ_PV_CASE(6) NNJ_PV_CASE(8) NNJ_PV_CASE(10) NNJ_PV_CASE(13)
         NNJ_PV_CASE(16)
-        default: return fail(h, NNJ_ERR_UNSUPPORTED, "row attention: no instantiation for %d head tiles", g6.ET);
+        default: return fail(h, NNJ_ERR_UNSUPPORTED, "row attention: no instantiation for %d head tiles", g6.ETc);
       }
 #undef NNJ_PV_CASE
     }
     {
       Scope sc(h, st, PK_TOK1);
       const int dbg = ((l == 0 && h->debug_stop == 1) ? 1 : 0) | (h->debug_stop >= 16 ? (h->debug_stop >> 4) << 1 : 0);
-      if (NT == 2) {      // 32 < R <= 64: two waves per column, four columns in flight per workgroup
-        const unsigned grid1 = (unsigned)std::min<long>((long)(((size_t)B * C + 3) / 4), (long)h->num_cu);   // persistent
-        const size_t lds = (size_t)(5 * 4096 + 4 * (64 * 36 + 64 * 32) + 16) * sizeof(float);
-        if (int rc = set_lds(h, k_tok1p<2>, lds)) return rc;
-        hipLaunchKernelGGL(k_tok1p<2>, dim3(grid1), dim3(512), lds, st, ctx, mask, x, attn_ptrs(h, h->lo[l].row),
-                           attn_ptrs(h, h->lo[l].col), B, T, C, d.Epad, dbg, h->d_flag);
-      } else {            // R <= 32: one wave per column, eight columns in flight
-        const unsigned grid1 = (unsigned)std::min<long>((long)(((size_t)B * C + 7) / 8), (long)h->num_cu);
-        const size_t lds = (size_t)(5 * 4096 + 8 * (32 * 36 + 32 * 32) + 16) * sizeof(float);
-        if (int rc = set_lds(h, k_tok1p<1>, lds)) return rc;
-        hipLaunchKernelGGL(k_tok1p<1>, dim3(grid1), dim3(512), lds, st, ctx, mask, x, attn_ptrs(h, h->lo[l].row),
-                           attn_ptrs(h, h->lo[l].col), B, T, C, d.Epad, dbg, h->d_flag);
-      }
+      // NT waves per column (32 rows each), 8 / NT columns in flight per workgroup; persistent
+      constexpr int NSLOT = 8 / NT;
+      const unsigned grid1 = (unsigned)std::min<long>((long)(((size_t)B * C + NSLOT - 1) / NSLOT), (long)h->num_cu);
+      const size_t lds = (size_t)(5 * 4096 + NSLOT * (32 * NT * 36 + 32 * NT * 32) + 16) * sizeof(float);
+      if (int rc = set_lds(h, k_tok1p<NT>, lds)) return rc;
+      hipLaunchKernelGGL(k_tok1p<NT>, dim3(grid1), dim3(512), lds, st, ctx, mask, x, attn_ptrs(h, h->lo[l].row),
+                         attn_ptrs(h, h->lo[l].col), B, T, C, d.Epad, dbg, h->d_flag);
     }
     if (l == 0 && (h->debug_stop == 1 || h->debug_stop == 2)) break;
     {
@@ -363,8 +405,12 @@ int launch_encoder(nnj_handle* h, const uint8_t* codes, const float* onehot, con
 
 int run_encoder(nnj_handle* h, const uint8_t* codes, const uint8_t* mask, float* x, float* scratch, int B, int T,
                 int C, hipStream_t st, const float* onehot = nullptr) {
-  return T <= 32 ? launch_encoder<1>(h, codes, onehot, mask, x, scratch, B, T, C, st)
-                 : launch_encoder<2>(h, codes, onehot, mask, x, scratch, B, T, C, st);
+  switch (enc_dims(B, T, C).NT) {
+    case 1: return launch_encoder<1>(h, codes, onehot, mask, x, scratch, B, T, C, st);
+    case 2: return launch_encoder<2>(h, codes, onehot, mask, x, scratch, B, T, C, st);
+    case 4: return launch_encoder<4>(h, codes, onehot, mask, x, scratch, B, T, C, st);
+    default: return launch_encoder<8>(h, codes, onehot, mask, x, scratch, B, T, C, st);
+  }
 }
 
 // ------------------------------------------------------------------ NJ-loop launches
@@ -378,10 +424,66 @@ int launch_row_xf(nnj_handle* h, const float* S, float* U, float* Kp, float* bet
   return NNJ_OK;
 }
 
+// more than 64 live rows: the star kernels of nnj_scorer_wide.hpp (incremental: one star per batch element;
+// all pairs: n-1 stars in launches of at most MB)
+int launch_pair_scores_wide(nnj_handle* h, const RowSet& rs, const int* ij_prev, const uint8_t* mask, float* base,
+                            const LoopWs& w, int mode, int n, int B, int C, PairGeom& g, hipStream_t st) {
+  const bool full = mode == PAIRS_FULL;
+  const WideGeom wg = wide_geom(n, B, C, full);
+  const ScorerW sw = scorer_ptrs(h);
+  const int* ijp = full ? nullptr : ij_prev;
+  const size_t lds_a = (size_t)(2 * IMG64 + 64 * wg.RP) * sizeof(float);
+  const size_t lds_s = (size_t)(3 * IMG64 + 64 * wg.RP) * sizeof(float);
+  for (int m0 = 0; m0 < wg.M; m0 += wg.MB) {
+    const int mc = std::min(wg.MB, wg.M - m0);
+    const dim3 grid((unsigned)wg.nsc, (unsigned)mc, (unsigned)B);
+    {
+      Scope sc(h, st, full ? PK_PAIR_ALPHA : PK_PAIR_ALPHA_INCR);
+      if (wg.PT == 1) {
+        if (int rc = set_lds(h, k_wide_alpha<1>, lds_a)) return rc;
+        hipLaunchKernelGGL(k_wide_alpha<1>, grid, dim3(512), lds_a, st, rs, sw, ijp, m0, base + w.alpha_part, n, C, wg.cs,
+                           wg.nsc);
+      } else {
+        if (int rc = set_lds(h, k_wide_alpha<2>, lds_a)) return rc;
+        hipLaunchKernelGGL(k_wide_alpha<2>, dim3(grid.x * 2, grid.y, grid.z), dim3(512), lds_a, st, rs, sw, ijp, m0,
+                           base + w.alpha_part, n, C, wg.cs, wg.nsc);
+      }
+    }
+    {
+      Scope sc(h, st, PK_ALPHA_SOFTMAX);
+      hipLaunchKernelGGL(k_wide_softmax, dim3((unsigned)(wg.RP / 4), (unsigned)mc, (unsigned)B), dim3(256), 0, st, rs, sw,
+                         ijp, m0, base + w.alpha_part, base + w.alpha, n, C, wg.RP, wg.nsc);
+    }
+    {
+      Scope sc(h, st, full ? PK_PAIR_SCORE : PK_PAIR_SCORE_INCR);
+      if (wg.PT == 1) {
+        if (int rc = set_lds(h, k_wide_score<1>, lds_s)) return rc;
+        hipLaunchKernelGGL(k_wide_score<1>, grid, dim3(512), lds_s, st, rs, sw, ijp, m0, base + w.alpha, mask,
+                           base + w.score_part, n, C, wg.cs);
+      } else {
+        if (int rc = set_lds(h, k_wide_score<2>, lds_s)) return rc;
+        hipLaunchKernelGGL(k_wide_score<2>, grid, dim3(512), lds_s, st, rs, sw, ijp, m0, base + w.alpha, mask,
+                           base + w.score_part, n, C, wg.cs);
+      }
+    }
+    if (full) {
+      Scope sc(h, st, PK_MISC);
+      hipLaunchKernelGGL(k_wide_gather_full, dim3((unsigned)((mc * wg.RP + 255) / 256), (unsigned)B), dim3(256), 0, st,
+                         base + w.score_part, base + w.full, n, wg.RP, wg.nsc, m0, mc);
+    }
+  }
+  g.npairs = full ? n * (n - 1) / 2 : n;
+  if (full) { g.nsc = 1; g.ppad = n * (n - 1) / 2; g.score_src = base + w.full; }
+  else { g.nsc = wg.nsc; g.ppad = wg.RP; g.score_src = base + w.score_part; }
+  return NNJ_OK;
+}
+
 // scores of the pairs of `mode` into score_part (and alpha scratch)
 int launch_pair_scores(nnj_handle* h, const RowSet& rs, const int* ij_prev, const uint8_t* mask, float* base,
                        const LoopWs& w, int mode, int n, int B, int C, PairGeom& g, hipStream_t st) {
+  if (n > 64) return launch_pair_scores_wide(h, rs, ij_prev, mask, base, w, mode, n, B, C, g, st);
   g = pair_geom(mode, n, B, C);
+  g.score_src = base + w.score_part;
   const ScorerW sw = scorer_ptrs(h);
   const int has_ctx = n > 2 ? 1 : 0;
   if (mode == PAIRS_INCR) {
@@ -470,23 +572,26 @@ int launch_aggregate(nnj_handle* h, const RowSet& rs, const int* ij, float* base
                      int n, int B, int C, hipStream_t st) {
   const ScorerW sw = scorer_ptrs(h);
   const int nch = (C + 15) / 16;
+  const int rpt = n <= 64 ? 1 : (n <= 128 ? 2 : 4);             // 64-row groups of the alpha vector
   if (n > 2) {
     Scope sc(h, st, PK_AGG_ALPHA);
-    hipLaunchKernelGGL(k_agg_alpha, dim3((unsigned)nch, (unsigned)B), dim3(256), 0, st, rs, sw, ij, base + w.agg_part, n, C);
+    hipLaunchKernelGGL(k_agg_alpha, dim3((unsigned)nch, (unsigned)B), dim3(256), 0, st, rs, sw, ij, base + w.agg_part, n, C,
+                       64 * rpt);
   }
   {
     Scope sc(h, st, PK_AGG_FINISH);
-    if ((long)B * ((C + 127) / 128) < (long)h->num_cu) {     // small batches: one 32-site tile per workgroup, rows split over its waves
-      const size_t lds = (3 * 4096 + 64 + 8192) * sizeof(float);
-      if (int rc = set_lds(h, k_agg_finish<true>, lds)) return rc;
-      hipLaunchKernelGGL(k_agg_finish<true>, dim3((unsigned)((C + 31) / 32), (unsigned)B), dim3(256), lds, st, rs, sw, ij,
-                         base + w.agg_part, nch, S_out, U_out, Kp_out, beta_out, out_bstride, out_slots, in_place, n, C);
-      return NNJ_OK;
-    }
-    const size_t lds = (3 * 4096 + 64 + 256) * sizeof(float);
-    if (int rc = set_lds(h, k_agg_finish<false>, lds)) return rc;
-    hipLaunchKernelGGL(k_agg_finish<false>, dim3((unsigned)((C + 127) / 128), (unsigned)B), dim3(256), lds, st, rs, sw, ij,
-                       base + w.agg_part, nch, S_out, U_out, Kp_out, beta_out, out_bstride, out_slots, in_place, n, C);
+    const bool split = (long)B * ((C + 127) / 128) < (long)h->num_cu;   // small batches: one 32-site tile per workgroup, rows split over its waves
+    const size_t lds = (size_t)(3 * 4096 + 256 + (split ? 8192 : 1024)) * sizeof(float);
+    const dim3 grid(split ? (unsigned)((C + 31) / 32) : (unsigned)((C + 127) / 128), (unsigned)B);
+#define NNJ_AGG(SP, RPT)                                                                                       \
+  {                                                                                                            \
+    if (int rc = set_lds(h, k_agg_finish<SP, RPT>, lds)) return rc;                                            \
+    hipLaunchKernelGGL((k_agg_finish<SP, RPT>), grid, dim3(256), lds, st, rs, sw, ij, base + w.agg_part, nch, S_out, \
+                       U_out, Kp_out, beta_out, out_bstride, out_slots, in_place, n, C);                       \
+  }
+    if (split) { if (rpt == 1) NNJ_AGG(true, 1) else if (rpt == 2) NNJ_AGG(true, 2) else NNJ_AGG(true, 4) }
+    else { if (rpt == 1) NNJ_AGG(false, 1) else if (rpt == 2) NNJ_AGG(false, 2) else NNJ_AGG(false, 4) }
+#undef NNJ_AGG
   }
   return NNJ_OK;
 }
@@ -684,7 +789,7 @@ int nnj_pair_scores_full(nnj_handle* h, const float* state, const uint8_t* mask,
   if (int rc = launch_pair_scores(h, rs, ij, mask, base, w, PAIRS_FULL, n, B, L, g, st)) return rc;
   {
     Scope sc(h, st, PK_ASSEMBLE);
-    hipLaunchKernelGGL(k_assemble_argmax, dim3((unsigned)B), dim3(256), 0, st, base + w.score_part, g.nsc, g.ppad,
+    hipLaunchKernelGGL(k_assemble_argmax, dim3((unsigned)B), dim3(256), 0, st, g.score_src, g.nsc, g.ppad,
                        (const float*)nullptr, (const int*)nullptr, logits_out, (float*)nullptr, 0L, (const int*)nullptr,
                        0L, (int*)nullptr, 0L, (float*)nullptr, 0L, ij, (int)PAIRS_FULL, n, (const float*)nullptr, 0L, 1.0f,
                        h->d_flag);
@@ -709,7 +814,7 @@ int nnj_pair_scores_incr(nnj_handle* h, const float* state, const uint8_t* mask,
   if (int rc = launch_pair_scores(h, rs, ij_prev, mask, base, w, PAIRS_INCR, n, B, L, g, st)) return rc;
   {
     Scope sc(h, st, PK_ASSEMBLE);
-    hipLaunchKernelGGL(k_assemble_argmax, dim3((unsigned)B), dim3(256), 0, st, base + w.score_part, g.nsc, g.ppad,
+    hipLaunchKernelGGL(k_assemble_argmax, dim3((unsigned)B), dim3(256), 0, st, g.score_src, g.nsc, g.ppad,
                        logits_prev, ij_prev, logits_out, (float*)nullptr, 0L, (const int*)nullptr, 0L, (int*)nullptr, 0L,
                        (float*)nullptr, 0L, ij, (int)PAIRS_INCR, n, (const float*)nullptr, 0L, 1.0f, h->d_flag);
   }
@@ -840,7 +945,7 @@ static int rollout_impl(nnj_handle* h, const uint8_t* codes, const uint8_t* mask
     if (int rc = launch_pair_scores(h, rs, ij, mask, base, w, mode, n, B, C, g, st)) return rc;   // :121-126
     {
       Scope sc(h, st, PK_ASSEMBLE);                                                                 // :140-160
-      hipLaunchKernelGGL(k_assemble_argmax, dim3((unsigned)B), dim3(256), 0, st, base + w.score_part, g.nsc, g.ppad,
+      hipLaunchKernelGGL(k_assemble_argmax, dim3((unsigned)B), dim3(256), 0, st, g.score_src, g.nsc, g.ppad,
                          (const float*)lg[(step + 1) & 1], (const int*)ij, lg[step & 1], trace ? trace + off : nullptr,
                          (long)total, forced ? forced + 2 * step : nullptr, (long)(T - 1) * 2, merges_out + 2 * step,
                          (long)(T - 1) * 2, gap ? gap + step : nullptr, (long)(T - 1), ij, mode, n,

@@ -28,11 +28,10 @@ struct EmbedW {           // embed = Linear(4 -> 64), GELU, Linear(64 -> 64)  (r
 // ------------------------------------------------------------------ k_embed
 // codes uint8 [B,R,L] (patch_size 1: C == L); lut [6][64] = embed MLP of the six site
 // vectors (reference model.py:39-43,76-77 evaluated on phydata.py:38-46's vectors).
-template <int NT>
 __global__ __launch_bounds__(256) void k_embed(const uint8_t* __restrict__ codes,
-                                                   const float* __restrict__ onehot, EmbedW ew,
-                                                   const float* __restrict__ lut,
-                                                   float* __restrict__ x, int B, int R, int C) {
+                                               const float* __restrict__ onehot, EmbedW ew,
+                                               const float* __restrict__ lut,
+                                               float* __restrict__ x, int B, int R, int C) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* E2_l = smem;             // only staged for the general float input
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -42,14 +41,14 @@ __global__ __launch_bounds__(256) void k_embed(const uint8_t* __restrict__ codes
   if (col >= (long)B * C) return;
   const int b = (int)(col / C), c = (int)(col % C);
   const int tok = lane & 31, hh = lane >> 5;
-  f32x16 xr[NT][2];
-  if (onehot) {
-    // general float input [B,R,L,4]: the embed MLP itself (first Linear on the VALU, second by MFMA)
-    f32x16 t1[NT][2];
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      const int r = 32 * nt + tok;
-      const bool valid = r < R;
+  // a wave owns one alignment column and walks its rows 32 at a time (any number of rows)
+  for (int r0 = 0; r0 < R; r0 += 32) {
+    const int r = r0 + tok;
+    const bool valid = r < R;
+    f32x16 xr[1][2];
+    if (onehot) {
+      // general float input [B,R,L,4]: the embed MLP itself (first Linear on the VALU, second by MFMA)
+      f32x16 t1[1][2];
       const f32x4 oh = *reinterpret_cast<const f32x4*>(onehot + (((size_t)b * R + (valid ? r : 0)) * C + c) * 4);
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt)
@@ -60,27 +59,16 @@ __global__ __launch_bounds__(256) void k_embed(const uint8_t* __restrict__ codes
           for (int t = 0; t < 4; ++t) {
             const f32x4 wv = *reinterpret_cast<const f32x4*>(ew.E0 + (32 * mt + 8 * g + 4 * hh + t) * 4);
             const float s = b4[t] + wv[0] * oh[0] + wv[1] * oh[1] + wv[2] * oh[2] + wv[3] * oh[3];
-            t1[nt][mt][4 * g + t] = valid ? gelu_erf(s) : 0.f;
+            t1[0][mt][4 * g + t] = valid ? gelu_erf(s) : 0.f;
           }
         }
-    }
-    linear_T<2, 2, NT>(xr, t1, E2_l, ew.e2, lane);
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      const int r = 32 * nt + tok;
-      if (!(r < R)) { xr[nt][0] = (f32x16)(0.f); xr[nt][1] = (f32x16)(0.f); }
-      store_token64(xr[nt], x + (((size_t)b * R + r) * C + c) * 64, r < R, hh);
-    }
-  } else {
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      const int r = 32 * nt + tok;
-      const bool valid = r < R;
+      linear_T<2, 2, 1>(xr, t1, E2_l, ew.e2, lane);
+    } else {
       int code = codes[((size_t)b * R + (valid ? r : 0)) * C + c];
       if (!valid || code > 5) code = 5;
-      load_token64(xr[nt], lut + code * 64, valid, hh);
-      store_token64(xr[nt], x + (((size_t)b * R + r) * C + c) * 64, valid, hh);
+      load_token64(xr[0], lut + code * 64, valid, hh);
     }
+    store_token64(xr[0], x + (((size_t)b * R + r) * C + c) * 64, valid, hh);
   }
 }
 
@@ -92,10 +80,11 @@ __global__ __launch_bounds__(256) void k_embed(const uint8_t* __restrict__ codes
 // projections of a head-half go through per-column LDS images; with NWC = 2 the two waves of a column meet at a
 // pair barrier built on an LDS counter (never a workgroup barrier: the column slots run unsynchronised).
 // Persistent: the five weight images are staged once (80 KiB) + 8/NWC x (K image + V^T image) = 149 KiB.
+template <int NWC>
 __device__ __forceinline__ void pair_barrier(int* cnt, int& epoch, int* flag) {
-  // both waves of the pair arrive (LDS executes a wave's operations in order: its image writes are
-  // in place before its increment), then wait until the counter shows both arrivals of this epoch
-  epoch += 2;
+  // all NWC waves of the column arrive (LDS executes a wave's operations in order: its image writes are
+  // in place before its increment), then wait until the counter shows every arrival of this epoch
+  epoch += NWC;
   asm volatile("" ::: "memory");
   if ((threadIdx.x & 63) == 0) atomicAdd(cnt, 1);
   // bounded spin: a lost partner never hangs the GPU; it sets the sticky status bit NNJ_FLAG_BARRIER_TIMEOUT
@@ -106,7 +95,7 @@ __device__ __forceinline__ void pair_barrier(int* cnt, int& epoch, int* flag) {
   asm volatile("" ::: "memory");
 }
 
-template <int NWC>                                      // waves per column: 1 (R <= 32) or 2 (R <= 64)
+template <int NWC>                                      // waves per column: 1 (R <= 32), 2 (<= 64), 4 (<= 128), 8 (<= 256)
 __global__ __launch_bounds__(512) void k_tok1p(const float* __restrict__ ctx, const uint8_t* __restrict__ mask,
                                                float* __restrict__ x, AttnW wr, AttnW wc, int B, int R, int C,
                                                int Epad, int skip_col, int* __restrict__ status) {
@@ -229,7 +218,7 @@ __global__ __launch_bounds__(512) void k_tok1p(const float* __restrict__ ctx, co
           __builtin_amdgcn_sched_barrier(0);
         });
       }
-      if constexpr (NWC == 2) pair_barrier(cnt, epoch, status);  // the partner has finished reading the previous images
+      if constexpr (NWC >= 2) pair_barrier<NWC>(cnt, epoch, status);  // the partners have finished reading the previous images
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const f32x4 k4 = {kh[4 * g], kh[4 * g + 1], kh[4 * g + 2], kh[4 * g + 3]};
@@ -245,7 +234,8 @@ __global__ __launch_bounds__(512) void k_tok1p(const float* __restrict__ ctx, co
         *reinterpret_cast<uint2*>(dst) = make_uint2(h01, h23);
         *reinterpret_cast<uint2*>(dst + VPL) = make_uint2(m01, m23);
       }
-      if constexpr (NWC == 2) pair_barrier(cnt, epoch, status);  // both row tiles' K and V are in the images
+      if constexpr (NWC >= 2) pair_barrier<NWC>(cnt, epoch, status);  // every row tile's K and V are in the images
+      if constexpr (NWC <= 2) {
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         // S^T[key j x query i]: A = K image rows (lane = key), B = this wave's q registers (lane = query)
@@ -304,6 +294,64 @@ __global__ __launch_bounds__(512) void k_tok1p(const float* __restrict__ ctx, co
 #pragma unroll
           for (int k = 1; k < 16; ++k) ov = (k == 4 * g + t) ? o[k] : ov;
           cx[0][hf][4 * g + t] = ov * inv;
+        }
+      }
+      } else {
+        // More than two row tiles (R > 64): one key tile at a time with a running maximum (online softmax), so the
+        // register cost does not grow with the number of tiles.  Same operands as above.
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          float m = -INFINITY, l = 0.f;
+          f32x16 o;
+#pragma unroll
+          for (int k = 0; k < 16; ++k) o[k] = 0.f;
+#pragma unroll 1
+          for (int jt = 0; jt < NWC; ++jt) {
+            const f32x4 ka = *reinterpret_cast<const f32x4*>(kimg + (32 * jt + tok) * 36 + 8 * g + 4 * hh);
+            f32x16 sc;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) sc[k] = 0.f;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) sc = mfma32(ka[t], qh[4 * g + t] * qscale, sc);
+            float mt = -INFINITY;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+              float v = sc[k];
+              if (32 * jt + (k & 3) + 8 * (k >> 2) + 4 * hh >= R) v = -INFINITY;     // keys beyond the rows
+              sc[k] = v;
+              mt = fmaxf(mt, v);
+            }
+            mt = fmaxf(mt, __shfl_xor(mt, 32));
+            const float mn = fmaxf(m, mt);                  // finite from the first tile on (rows 0..31 exist)
+            const float corr = nnj_exp(m - mn);             // first tile: exp(-inf) = 0 on l = 0, o = 0
+            l *= corr;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+              o[k] *= corr;
+              const float p = nnj_exp(sc[k] - mn);          // masked keys: exp(-inf) = 0
+              sc[k] = p;
+              l += p;
+            }
+            m = mn;
+            static_for<0, 2>([&](auto ui) {
+              constexpr int u = decltype(ui)::value;
+              Frag3 pf, vf;
+              split8<8 * u>(pf, sc);
+              const uint8_t* src = vimg + tok * (16 * VCH) + 16 * wswz6<VCH>(tok, 2 * (2 * jt + u) + hh);
+              vf.h = *reinterpret_cast<const u32x4*>(src);
+              vf.m = *reinterpret_cast<const u32x4*>(src + VPL);
+              o = mfma_b6(vf, pf, o);
+            });
+          }
+          l += __shfl_xor(l, 32);
+          const float inv = nnj_rcp(l);
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            float ov = o[0];
+#pragma unroll
+            for (int k = 1; k < 16; ++k) ov = (k == 4 * g + t) ? o[k] : ov;
+            cx[0][hf][4 * g + t] = ov * inv;
+          }
         }
       }
     }

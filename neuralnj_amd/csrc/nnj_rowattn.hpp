@@ -33,7 +33,9 @@ struct Ra6 {
   int C, T;        // alignment columns (keys = queries), rows
   int KS;          // 16-wide k-steps of the head dimension: ceil(8T/16)
   int Cp;          // C rounded up to 256
-  int ET;          // 32-row tiles of the head dimension in V6 / the context accumulators (bucketed)
+  int ET;          // 32-row tiles of the head dimension in V6 (= nech * ETc)
+  int ETc;         // ... per e-chunk of k_row_pv (bucketed, <= 16: its context accumulators)
+  int nech;        // e-chunks: k_row_pv workgroups per query block (1 up to 64 rows; 100 rows: 2 x 13 tiles; 200: 4 x 13)
   int nrb;         // Cp / 256
   int nt32;        // Cp / 32
   int nk16;        // Cp / 16
@@ -50,8 +52,11 @@ inline Ra6 ra6_geom(int T, int C, int Epad) {
   g.Cp = (C + 255) / 256 * 256;
   static const int buckets[] = {1, 2, 4, 6, 8, 10, 13, 16};
   const int need = (16 * g.KS + 31) / 32;
-  g.ET = 16;
-  for (int k : buckets) if (need <= k) { g.ET = k; break; }
+  g.nech = (need + 15) / 16;
+  const int per = (need + g.nech - 1) / g.nech;
+  g.ETc = 16;
+  for (int k : buckets) if (per <= k) { g.ETc = k; break; }
+  g.ET = g.nech * g.ETc;
   g.nrb = g.Cp / 256; g.nt32 = g.Cp / 32; g.nk16 = g.Cp / 16;
   g.qk_bh = (size_t)g.KS * g.nrb * NPL * 8192;
   g.v_bh = (size_t)g.nk16 * NPL * g.ET * 32 * 32;
@@ -94,7 +99,6 @@ __global__ __launch_bounds__(512) void k_qkv6(const float* __restrict__ x, const
   const int RP = (R + 1) / 2, CB = (C + 15) / 16;
   const int tiles_per_b = RP * CB, groups_per_b = (tiles_per_b + 7) / 8;
   const int ngroups = groups_per_b * B;
-  const float qs = rsqrtf((float)NNJ_DH) / sqrtf((float)R);
   const int lam = lane & 31, c16 = lam & 15, rr = lam >> 4;
   const unsigned sel = (lane & 1) ? 0x03020706u : 0x05040100u;      // see the 4x4 transpose below
   const bool bit1 = (lane >> 1) & 1;
@@ -123,7 +127,10 @@ __global__ __launch_bounds__(512) void k_qkv6(const float* __restrict__ x, const
     if (grp + (int)gridDim.x < ngroups) load_token64(xr, tok_addr(grp + gridDim.x), true, hh);
     if (!tile_ok) continue;
     const bool padded = mask && valid && mask[(size_t)b * C + c];
-    const float qscale = padded ? 0.0f : qs;
+    // q goes to the operand planes UNSCALED (zero for padded sites, axial_attention.py:78-82): scaled by
+    // dh^-0.5 / sqrt(R) its low fp16 piece would sit in the fp16 denormal range from about 50 rows on and the pair
+    // would carry 19-20 instead of 22 significand bits; k_row_s applies the scale to the fp32 logits instead
+    const float qscale = padded ? 0.0f : 1.0f;
     linear6_T_nb<6, 2, 1>(o, y, Wl, lane);
     const int rb = c >> 8;
     const size_t qk_row = (size_t)(c & 255) * 32 + 16 * (rr ^ ((c >> 3) & 1)) + 8 * hh;
@@ -198,10 +205,17 @@ struct RsShape {
   static constexpr int NPK = NPL * 8;                                // 1-KiB pieces of the K tile
   static constexpr int NP = (NPK + NPL * QW / 32) / 4;               // DMA pieces per wave and k-step
 };
-template <int QW>
-__global__ __launch_bounds__(256, QW == 128 ? 2 : 1) void k_row_s(const uint8_t* __restrict__ Q6, const uint8_t* __restrict__ K6,
+// CHK > 0 (used above 64 alignment rows, with QW = 64): CHUNKED accumulation.  A logit is a sum of 8R products; on
+// the matrix pipe every MFMA rounds the running fp32 sum once, i.e. 3 x R/2 roundings at the magnitude of the logit
+// itself -- measured 1.1e-4 absolute on logits of magnitude 100 at R = 200 (stress weights), against 2e-5 for the
+// reference, whose no-grad path adds per-chunk partial sums (axial_attention.py:35-64).  With CHK the k-steps are
+// accumulated CHK at a time into a zeroed accumulator and the chunk sums are added to the total by the vector
+// unit: the many roundings happen on small partial sums, only KS/CHK on the large one (same error as the
+// reference's order).  The second accumulator set is paid for by the narrower wave tile (128 keys x 32 queries).
+template <int QW, int CHK = 0>
+__global__ __launch_bounds__(256, 2) void k_row_s(const uint8_t* __restrict__ Q6, const uint8_t* __restrict__ K6,
                                                              const uint8_t* __restrict__ cls, float* __restrict__ S,
-                                                             float* __restrict__ M, Ra6 g, int nbh, float fill) {
+                                                             float* __restrict__ M, Ra6 g, int nbh, float fill, float qs) {
   using SH = RsShape<QW>;
   constexpr int NJ = SH::NJ, NP = SH::NP, NST = SH::NST;
   constexpr unsigned QPL = SH::QPL, STAGE = SH::STAGE, KTB = SH::KTB;
@@ -251,6 +265,15 @@ __global__ __launch_bounds__(256, QW == 128 ? 2 : 1) void k_row_s(const uint8_t*
     for (int j = 0; j < NJ; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  f32x16 tot[CHK > 0 ? 4 : 1][CHK > 0 ? NJ : 1];          // chunk sums are folded into this (CHK > 0)
+  if constexpr (CHK > 0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) tot[i][j][r] = 0.f;
+  }
   Frag3 A[4], Bf[2];
   auto readA = [&](unsigned base) {
     static_for<0, 4>([&](auto ii) {
@@ -293,6 +316,24 @@ __global__ __launch_bounds__(256, QW == 128 ? 2 : 1) void k_row_s(const uint8_t*
         });
       });
     });
+    if constexpr (CHK > 0) {
+      if ((ks + 1) % CHK == 0 || ks + 1 == KS) {           // fold the chunk sum into the total, restart the chunk
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) {
+            tot[i][j] += acc[i][j];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+          }
+      }
+    }
+  }
+  if constexpr (CHK > 0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) acc[i][j] = tot[i][j];
   }
   wait_vmem_le<0>();                         // nothing of the ring may still be landing when the workgroup ends
   // ---- epilogue: key classes, tile maxima, register images
@@ -320,7 +361,7 @@ __global__ __launch_bounds__(256, QW == 128 ? 2 : 1) void k_row_s(const uint8_t*
       float tmax = -INFINITY;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        float s = acc[i][j][r];
+        float s = acc[i][j][r] * qs;           // align_scaling (axial_attention.py:31-33, 77), see k_qkv6
         s = ((is1 >> r) & 1u) ? fill : s;
         s = ((is2 >> r) & 1u) ? -INFINITY : s;
         acc[i][j][r] = s;
@@ -344,6 +385,10 @@ __global__ __launch_bounds__(256, QW == 128 ? 2 : 1) void k_row_s(const uint8_t*
 // lane's 8 probabilities exp(S - max) -- S read back as the register image k_row_s wrote, the next tile
 // prefetched -- are split into a B fragment in registers, and ET A fragments stream from LDS through a
 // two-deep software pipeline (hand-issued reads).  sum(P) is carried per lane; ctx = O / sum.
+// More than 16 head tiles (more than 64 alignment rows): the head dimension is cut into g.nech chunks of ET tiles,
+// one workgroup per (query block, chunk) -- each recomputes the probabilities (the exponentials are cheap next to
+// the ET x 3 MFMAs per 16 keys) and owns its slice of the context rows; the chunks of a query block sit on
+// consecutive workgroup slots of one XCD, so the score images they share are served by its L2.
 template <int ET>
 __global__ __launch_bounds__(256) void k_row_pv(const uint8_t* __restrict__ V6, const float* __restrict__ S,
                                                 const float* __restrict__ M, float* __restrict__ ctx, Ra6 g,
@@ -355,19 +400,22 @@ __global__ __launch_bounds__(256) void k_row_pv(const uint8_t* __restrict__ V6, 
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, HH = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int nqb = g.Cp / 128;
+  const int nqb = g.Cp / 128, nech = g.nech;
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-  const int bh = (slot / nqb) * 8 + xcd;
+  const int bh = (slot / (nqb * nech)) * 8 + xcd;
   if (bh >= nbh) return;
-  const int qb = slot % nqb, qt = qb * 4 + wave;
+  const int qb = (slot % (nqb * nech)) / nech, ech = slot % nech, qt = qb * 4 + wave;
   const int nk16 = g.nk16;
-  const uint8_t* Vt = V6 + (size_t)bh * g.v_bh;
+  const size_t tile_g = (size_t)g.ET * NPL * 1024u;                   // bytes of a whole V6 tile (all chunks) in HBM
+  const size_t plane_g = (size_t)g.ET * 1024u;
+  const uint8_t* Vt = V6 + (size_t)bh * g.v_bh + (size_t)ech * ET * 1024u;
   auto issue_piece = [&](auto pi, int k, int stage) {              // DMA piece i of NIW per wave and tile
     constexpr int i = decltype(pi)::value;
     const int kk = k < nk16 ? k : nk16 - 1;
     const unsigned I = (unsigned)(wave * NIW + i);                    // wave-uniform
-    const unsigned so = I * 1024u < TILE ? I * 1024u : 0u;            // beyond the tile: filler into the stage's pad
-    lds_dma16(reinterpret_cast<const float*>(Vt + (size_t)kk * TILE + so + lane * 16),
+    // piece I = (plane I / ET, head tile I % ET) of this chunk; beyond the tile: filler into the stage's pad
+    const size_t so = I * 1024u < TILE ? (size_t)(I / ET) * plane_g + (size_t)(I % ET) * 1024u : 0u;
+    lds_dma16(reinterpret_cast<const float*>(Vt + (size_t)kk * tile_g + so + lane * 16),
               reinterpret_cast<float*>(reinterpret_cast<uint8_t*>(smem) + stage * STG + I * 1024u));
   };
   auto issue = [&](int k, int stage) {
@@ -466,7 +514,7 @@ __global__ __launch_bounds__(256) void k_row_pv(const uint8_t* __restrict__ V6, 
     for (int t = 0; t < ET; ++t)
 #pragma unroll
       for (int gq = 0; gq < 4; ++gq) {
-        const int e = 32 * t + 8 * gq + 4 * HH;
+        const int e = 32 * (ech * ET + t) + 8 * gq + 4 * HH;
         if (e < E)
           *reinterpret_cast<f32x4*>(dst + e) = (f32x4){acc[t][4 * gq] * inv, acc[t][4 * gq + 1] * inv,
                                                        acc[t][4 * gq + 2] * inv, acc[t][4 * gq + 3] * inv};

@@ -641,9 +641,10 @@ __global__ __launch_bounds__(256) void k_row_xf(const float* __restrict__ S, flo
 
 // ------------------------------------------------------------------ merged-row aggregate
 // k_agg_alpha: alpha partials of the ONE merged pair per batch element (VALU stream).
-// part[b][chunk][r] = sum_{c in chunk} x[c,:] . K'_r[c,:]; chunk = 16 sites.
+// part[b][chunk][r] = sum_{c in chunk} x[c,:] . K'_r[c,:]; chunk = 16 sites; rp = row stride of part (64, or 128 / 256
+// while more than 64 rows are live).
 __global__ __launch_bounds__(256) void k_agg_alpha(RowSet rs, ScorerW w, const int* __restrict__ ij,
-                                                   float* __restrict__ part, int n, int C) {
+                                                   float* __restrict__ part, int n, int C, int rp) {
   __shared__ __attribute__((aligned(16))) float xl[1024];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int chunk = blockIdx.x, b = blockIdx.y;
@@ -684,7 +685,7 @@ __global__ __launch_bounds__(256) void k_agg_alpha(RowSet rs, ScorerW w, const i
     }
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) acc += __shfl_xor(acc, o);
-    if (lane == 0) part[((size_t)b * nch + chunk) * 64 + r] = acc;
+    if (lane == 0) part[((size_t)b * nch + chunk) * rp + r] = acc;
   }
 }
 
@@ -695,7 +696,7 @@ __global__ __launch_bounds__(256) void k_agg_alpha(RowSet rs, ScorerW w, const i
 //   SPLIT (small batches, where 128-site workgroups would not fill the chip): the workgroup owns ONE 32-site
 //   tile and its four waves split the rows of the x_g sum (every 4th row each, partial sums added in wave order
 //   through LDS); wave 0 finishes the tile.
-template <bool SPLIT>
+template <bool SPLIT, int RPT>                            // RPT: 64-row groups of the alpha vector (1; 2 or 4 above 64 live rows)
 __global__ __launch_bounds__(256) void k_agg_finish(RowSet rs, ScorerW w, const int* __restrict__ ij,
                                                     const float* __restrict__ part, int nch, float* S_out,
                                                     float* U_out, float* Kp_out, float* beta_out,
@@ -704,7 +705,7 @@ __global__ __launch_bounds__(256) void k_agg_finish(RowSet rs, ScorerW w, const 
   float* Wg_l = smem;
   float* Wh_l = smem + 4096;
   float* A_l = smem + 8192;
-  float* al = smem + 12288;       // alpha[64]
+  float* al = smem + 12288;       // alpha[64 * RPT] (256 floats reserved), then 1024 floats of reduction scratch
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5;
   const int b = blockIdx.y;
   const int pi = min(max(ij[2 * b], 0), n - 1), pj = min(max(ij[2 * b + 1], 0), n - 1);
@@ -714,38 +715,55 @@ __global__ __launch_bounds__(256) void k_agg_finish(RowSet rs, ScorerW w, const 
     stage_weight_b6<64>(A_l, w.A, 64, tid, 256);
   }
   const bool has_ctx = n > 2;                       // model.py:111
+  constexpr int RP = 64 * RPT;
   {
     // alpha logits of the merged pair: the chunk partials of k_agg_alpha and the rows' beta partials are summed by
     // all four waves (every 4th term each, all loads of a wave in flight at once; the serial loop of one wave was
-    // most of this kernel's latency at small batch), the four sums meet in LDS in wave order
-    const bool in = has_ctx && lane < n && lane != pi && lane != pj;
-    float s = 0.f;
-    if (in) {
+    // most of this kernel's latency at small batch), the four sums meet in LDS in wave order.  Lane = row mod 64.
+    float* red4 = al + 256;                         // [4][RP]
+    bool in[RPT];
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
+      const int r = 64 * k + lane;
+      in[k] = has_ctx && r < n && r != pi && r != pj;
+      float s = 0.f;
+      if (in[k]) {
 #pragma unroll 16
-      for (int ch = wave; ch < nch; ch += 4) s += part[((size_t)b * nch + ch) * 64 + lane];
-      const float* bp = rs.beta_part + ((size_t)b * (rs.bstride / ((long)C * 64)) + slot_of(rs, b, lane)) * rs.ntile32;
-      float beta = 0.f;
+        for (int ch = wave; ch < nch; ch += 4) s += part[((size_t)b * nch + ch) * RP + r];
+        const float* bp = rs.beta_part + ((size_t)b * (rs.bstride / ((long)C * 64)) + slot_of(rs, b, r)) * rs.ntile32;
+        float beta = 0.f;
 #pragma unroll 8
-      for (int t = wave; t < rs.ntile32; t += 4) beta += bp[t];
-      s += beta;
+        for (int t = wave; t < rs.ntile32; t += 4) beta += bp[t];
+        s += beta;
+      }
+      red4[wave * RP + r] = s;
     }
-    float* red4 = al + 64;                          // [4][64]
-    red4[wave * 64 + lane] = s;
     __syncthreads();
     if (wave == 0) {
-      float a = -INFINITY;
-      if (in) {
-        const float tot = ((red4[lane] + red4[64 + lane]) + red4[128 + lane]) + red4[192 + lane] + (float)C * w.t0;
-        a = tot * (1.0f / sqrtf(64.0f * (float)C));
+      float a[RPT];
+      float mx = -INFINITY;
+#pragma unroll
+      for (int k = 0; k < RPT; ++k) {
+        const int r = 64 * k + lane;
+        a[k] = -INFINITY;
+        if (in[k]) {
+          const float tot = ((red4[r] + red4[RP + r]) + red4[2 * RP + r]) + red4[3 * RP + r] + (float)C * w.t0;
+          a[k] = tot * (1.0f / sqrtf(64.0f * (float)C));
+        }
+        mx = fmaxf(mx, a[k]);
       }
-      float mx = a;
 #pragma unroll
       for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
-      float e = in ? expf(a - mx) : 0.f;
-      float se = e;
+      float se = 0.f;
+#pragma unroll
+      for (int k = 0; k < RPT; ++k) {
+        a[k] = in[k] ? expf(a[k] - mx) : 0.f;
+        se += a[k];
+      }
 #pragma unroll
       for (int o = 32; o >= 1; o >>= 1) se += __shfl_xor(se, o);
-      al[lane] = (se > 0.f) ? e / se : 0.f;
+#pragma unroll
+      for (int k = 0; k < RPT; ++k) al[64 * k + lane] = (se > 0.f) ? a[k] / se : 0.f;
     }
   }
   __syncthreads();
@@ -789,7 +807,7 @@ __global__ __launch_bounds__(256) void k_agg_finish(RowSet rs, ScorerW w, const 
       for (int mt = 0; mt < 2; ++mt) xg[0][mt] += a * sr[mt];
     }
     if (SPLIT) {
-      float* red = al + 64;                            // [4 waves][64 lanes][32]
+      float* red = al + 256;                           // [4 waves][64 lanes][32] (the alpha scratch is dead)
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -842,7 +860,7 @@ __global__ __launch_bounds__(256) void k_assemble_argmax(const float* __restrict
                                                          int* ij_cur, int mode, int n,
                                                          const float* __restrict__ uniforms, long u_bstride,
                                                          float inv_temp, int* __restrict__ nonfinite) {
-  __shared__ float newsc[64];
+  __shared__ float newsc[256];
   __shared__ float red_v[256];
   __shared__ int red_i[256];
   const int tid = threadIdx.x, b = blockIdx.x;

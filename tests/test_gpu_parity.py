@@ -13,6 +13,11 @@ from neuralnj_amd import synth, utils, weights
 pytestmark = pytest.mark.gpu
 
 RTOL = 1e-4
+# Per-fixture exceptions, each with its measured reason (tests/wide_margin.py, profiles/r02/wide_margin.txt).
+# synth_b1_t100_l256_s11: 100 rows under the sharpened stress weights amplify encoder rounding about 7x into the
+# scores; against the fp64 oracle the fp32 oracle is at 1.2e-4 of the score scale, HIP at 1.1e-4, the reference's own
+# table at 4e-5 -- three fp32-level evaluations.  The reference's real 100-taxon alignments (data_G_*) hold 1e-4.
+RTOL_FIXTURE = {"synth_b1_t100_l256_s11": 2e-4}
 
 
 @pytest.fixture(scope="module")
@@ -35,6 +40,11 @@ def ctx_cache():
 def _oracle(cfgs, packed):
     from oracle_lib import Oracle
     return Oracle(cfgs, packed)
+
+
+def _oracle_f64(cfgs, packed):
+    from oracle_lib import Oracle
+    return Oracle(cfgs, packed, "f64")
 
 
 RF_ROWS = []          # one row per (fixture, alignment): written to gpurun_out/rf_table.json at module teardown
@@ -69,7 +79,7 @@ def test_rollout_matches_reference_golden(name, ctx_cache):
     B, T, L = z["codes"].shape
     r = g.rollout_argmax(codes, mask, forced_merges=z["merges"], want_trace=True, want_state=True)
     logits = r["logits"].cpu().numpy()
-    assert_logits_close(logits, z["logits"], RTOL)
+    assert_logits_close(logits, z["logits"], RTOL_FIXTURE.get(name, RTOL))
     st = r["state"].cpu().numpy()
     if "enc" in z.files:
         np.testing.assert_allclose(st, z["enc"], atol=RTOL * np.abs(z["enc"]).max())
@@ -115,7 +125,7 @@ def test_encoder_taps_match_oracle(name, ctx_cache):
 
 
 @pytest.mark.parametrize("name", ["synth_b2_t8_l128_s1", "padded_b2_t8_l128_s3", "plain_b1_t12_l96_s4",
-                                  "synth_b1_t20_l256_s1"])
+                                  "synth_b1_t20_l256_s1", "synth_b2_t70_l64_s12"])
 def test_entry_points_match_oracle_step_by_step(name, ctx_cache):
     """The reference's call sequence (decode_zxr / argmax / env.step) through the separate
     C-ABI entry points, each compared with the oracle on the same inputs."""
@@ -167,7 +177,10 @@ def test_seeded_random_inputs_vs_oracle(ctx_cache):
     # block, mostly padding), L not a multiple of 16 / 256, L > 1024 (five 256-row operand blocks)
     for (B, T, L, seed) in ((3, 5, 36, 1), (1, 2, 64, 2), (2, 33, 100, 3), (1, 17, 260, 4), (1, 50, 128, 5),
                             (1, 64, 64, 6), (2, 57, 96, 7), (2, 9, 4, 8), (1, 20, 12, 9), (1, 40, 268, 10),
-                            (1, 3, 1028, 11), (1, 48, 32, 12), (1, 49, 16, 13)):      # 64 = the largest row count this build covers
+                            (1, 3, 1028, 11), (1, 48, 32, 12), (1, 49, 16, 13),
+                            # more than 64 rows: 4 / 8 waves per column, e-chunked row context, star scorer kernels
+                            # (128-row images up to 128 rows, 256-row images above), 256 = the largest row count covered
+                            (1, 65, 32, 14), (2, 100, 48, 15), (1, 129, 40, 16), (1, 200, 36, 17), (1, 256, 20, 18)):
         codes = synth.synth_codes_tree(B, T, L, seed)
         mask = np.zeros((B, L), bool)
         if seed % 2:
@@ -182,6 +195,56 @@ def test_seeded_random_inputs_vs_oracle(ctx_cache):
         assert (ref["merges"][decisive] == merges[decisive]).all()
         assert (merges[:, :, 0] < merges[:, :, 1]).all()
         assert (merges[:, :, 1] < np.arange(T, 1, -1)[None, :]).all()
+
+
+@pytest.mark.parametrize("shape", [(2, 70, 64), (1, 100, 96), (1, 130, 40), (1, 200, 64), (1, 256, 32)])
+def test_wide_encoder_matches_oracle(shape, ctx_cache):
+    """More than 64 alignment rows: k_tok1p with 4 / 8 waves per column (online softmax), k_row_pv over e-chunks."""
+    B, T, L = shape
+    cfgs = utils.shipped_config()
+    packed = weights.pack(cfgs, weights.seeded_state(cfgs, 41, "sharp"))
+    g = ctx_cache(cfgs, packed)
+    codes = synth.synth_codes_tree(B, T, L, 500 + T)
+    mask = np.zeros((B, L), bool)
+    mask[:, L - 5:] = True
+    codes[:, :, L - 5:] = 5
+    ref = _oracle(cfgs, packed).encode(onehot_f32(codes), mask)
+    got = g.encode(torch.from_numpy(codes), torch.from_numpy(mask)).cpu().numpy()
+    np.testing.assert_allclose(got, ref, atol=RTOL * np.abs(ref).max())
+
+
+def test_config5_200x4096_properties(ctx_cache):
+    """BASELINE configs[4] shape (200 taxa x 4096 sites; the reference's formulation does not fit this container, so
+    there is no golden): size-independent properties of the HIP rollout at the full shape -- (1) two copies of the
+    alignment in one batch give bit-identical tables and merges; (2) teacher-forcing the free run's own merges
+    reproduces its tables bit for bit; (3) merges are valid pair indices; (4) the encoder output and the all-pairs
+    table of step 0 on a window of the SAME alignment (first 160 sites; the oracle needs minutes for 4096) equal
+    the oracle -- with 200 rows live, i.e. through the same 8-waves-per-column, e-chunked and 256-row-image kernels."""
+    cfgs = utils.shipped_config()
+    packed = weights.pack(cfgs, weights.seeded_state(cfgs, 0, "sharp"))
+    g = ctx_cache(cfgs, packed)
+    T, L = 200, 4096
+    one = synth.synth_codes_tree(1, T, L, seed=4242)
+    codes = torch.from_numpy(np.concatenate([one, one], 0))
+    r = g.rollout_argmax(codes, None, want_trace=True)
+    g.check_numeric()
+    merges, logits = r["merges"].cpu().numpy(), r["logits"].cpu().numpy()
+    assert np.array_equal(merges[0], merges[1]) and np.array_equal(logits[0], logits[1])
+    assert (merges[:, :, 0] < merges[:, :, 1]).all()
+    assert (merges[:, :, 1] < np.arange(T, 1, -1)[None, :]).all()
+    rf = g.rollout_argmax(codes[:1], None, forced_merges=merges[:1], want_trace=True)
+    # a batch of one runs other launch geometries (site chunks per workgroup): tables within tolerance, and the
+    # same geometry again is bit-identical
+    assert_logits_close(rf["logits"].cpu().numpy(), logits[:1], RTOL, "B=1 vs B=2")
+    rf2 = g.rollout_argmax(codes[:1], None, forced_merges=merges[:1], want_trace=True)
+    assert torch.equal(rf["logits"], rf2["logits"]) and torch.equal(rf["merges"], rf2["merges"])
+    win = one[:, :, :160]
+    o = _oracle(cfgs, packed)
+    ref = o.rollout_argmax(onehot_f32(win), None, forced_merges=None)
+    got = g.rollout_argmax(torch.from_numpy(win), None, forced_merges=ref["merges"], want_trace=True)
+    assert_logits_close(got["logits"].cpu().numpy(), ref["logits"], 2 * RTOL, "200 x 160 window vs the fp32 oracle")
+    ref64 = _oracle_f64(cfgs, packed).rollout_argmax(onehot_f32(win), None, forced_merges=ref["merges"])
+    assert_logits_close(got["logits"].cpu().numpy(), ref64["logits"], RTOL, "200 x 160 window vs the fp64 oracle")
 
 
 def test_full_size_batch_properties(ctx_cache):
@@ -293,8 +356,8 @@ def test_unsupported_shapes_fail_loudly(ctx_cache):
     cfgs = utils.shipped_config()
     packed = weights.pack(cfgs, weights.seeded_state(cfgs, 0, "sharp"))
     g = ctx_cache(cfgs, packed)
-    with pytest.raises(RuntimeError, match="64 rows"):
-        g.rollout_argmax(torch.zeros(1, 65, 64, dtype=torch.uint8))
+    with pytest.raises(RuntimeError, match="256 rows"):
+        g.rollout_argmax(torch.zeros(1, 257, 64, dtype=torch.uint8))
     from neuralnj_amd._lib import Nnj
     g2 = Nnj(cfgs, "cuda:0")
     with pytest.raises(RuntimeError, match="weights not loaded"):
