@@ -173,6 +173,14 @@ int nnj_rollout_sample(nnj_handle* h, const uint8_t* codes_dev, const uint8_t* m
                        int32_t* merges_out_dev, float* logits_trace_dev,
                        void* ws_dev, size_t ws_bytes, void* stream);
 
+/* Concurrency of the rollout entry points.  The alignments of a batch are independent; with streams = k (1..4,
+ * default 2) a rollout of B >= 64 alignments is cut into k contiguous sub-batches that run on k streams owned by the
+ * handle, forked from and joined to the caller's `stream` with events: the call is still asynchronous on `stream` and
+ * results are identical to those of the sub-batches run alone (bit for bit; launch geometry depends on the
+ * sub-batch size).  The reference has no counterpart (one device, one stream).  streams = 1 keeps every launch on the
+ * caller's stream. */
+int nnj_set_concurrency(nnj_handle* h, int32_t streams);
+
 /* Numeric guard.  The GEMMs of this library split fp32 operands into two fp16 pieces: operand
  * magnitudes beyond 65504 overflow to infinity instead of being rounded as fp32 would.  Every pair-score table
  * the library writes is scanned by the kernel that writes it; a non-finite entry sets a sticky per-handle flag.

@@ -46,6 +46,7 @@ _SIGS = {
     "nnj_profile_kind_name": ([C.c_int32], C.c_char_p),
     "nnj_profile_read": ([_vp, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int32], C.c_int),
     "nnj_profile_dropped": ([_vp, C.POINTER(C.c_int64)], C.c_int),
+    "nnj_set_concurrency": ([_vp, C.c_int32], C.c_int),
     "nnj_debug_encoder_stop": ([_vp, C.c_int32], C.c_int),
     "nnj_numeric_status": ([_vp, C.POINTER(C.c_int32), _vp], C.c_int),
     "nnj_step": ([_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int32, C.c_int32, C.c_int32, _vp, C.c_size_t,
@@ -240,13 +241,18 @@ class Nnj:
         self._chk(self.lib.nnj_select_pair(self.h, _p(logits), _p(ij), _p(gap), B, n, self._stream()))
         return ij, gap
 
-    def rollout_argmax(self, codes, mask=None, forced_merges=None, want_trace=False, want_state=False):
-        """Device-resident Argmax rollout.  Returns dict of device tensors (no host sync)."""
+    def rollout_argmax(self, codes, mask=None, forced_merges=None, want_trace=False, want_state=False, out=None):
+        """Device-resident Argmax rollout.  Returns dict of device tensors (no host sync).
+        `out`: the dict returned by an earlier call with the same shapes -- its tensors are written again instead
+        of fresh ones being allocated (a small-batch call whose arguments all repeat is replayed as a hipGraph)."""
         codes = self._u8(codes)
         B, T, L = codes.shape
         mask = self._u8(mask)
         fm = None if forced_merges is None else self._i32(forced_merges)
-        merges = torch.empty((B, T - 1, 2), dtype=torch.int32, device=self.device)
+        if out is not None and not want_trace and not want_state and tuple(out["merges"].shape) == (B, T - 1, 2):
+            merges = out["merges"]
+        else:
+            merges = torch.empty((B, T - 1, 2), dtype=torch.int32, device=self.device)
         total = sum(n * (n - 1) // 2 for n in range(2, T + 1))
         trace = torch.empty((B, total), dtype=torch.float32, device=self.device) if want_trace else None
         gap = torch.empty((B, T - 1), dtype=torch.float32, device=self.device) if want_trace else None
@@ -280,6 +286,10 @@ class Nnj:
         self._chk(self.lib.nnj_step(self.h, _p(state), _p(mask), _p(ij), _p(lp), _p(fn), _p(st), _p(lo), _p(cij),
                                     _p(gap), B, n, L, _p(ws), ws.numel(), self._stream()))
         return dict(state=st, logits=lo, ij=cij, top2_gap=gap)
+
+    def set_concurrency(self, streams: int):
+        """Sub-batches of a rollout that run on streams of the library's own (include/nnj.h nnj_set_concurrency)."""
+        self._chk(self.lib.nnj_set_concurrency(self.h, int(streams)))
 
     def check_numeric(self):
         """Synchronises the stream and raises if any pair-score table written since the last call held a

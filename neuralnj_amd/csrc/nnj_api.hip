@@ -54,6 +54,23 @@ struct nnj_handle {
   int debug_stop = 0;            // encoder debug tap (nnj_debug_encoder_stop)
   int num_cu = 256;              // compute units of the device (persistent-kernel grid size)
   int* d_flag = nullptr;         // sticky "a pair score was not finite" flag (nnj_numeric_status)
+  int concurrency = 2;           // sub-batches of a rollout that run on streams of their own (nnj_set_concurrency)
+  // small batches: the ~370 launches of a rollout are captured once into a hipGraph and replayed while the call's
+  // arguments stay the same (launch-bound regime: BASELINE configs[1], one alignment per rollout)
+  struct GraphKey {
+    const void *codes, *mask, *forced, *uniforms, *merges, *trace, *gap, *state, *ws;
+    int B, T, L, n_encode, debug_stop; float inv_temp;
+    bool operator==(const GraphKey& o) const {
+      return codes == o.codes && mask == o.mask && forced == o.forced && uniforms == o.uniforms && merges == o.merges &&
+             trace == o.trace && gap == o.gap && state == o.state && ws == o.ws && B == o.B && T == o.T && L == o.L &&
+             n_encode == o.n_encode && debug_stop == o.debug_stop && inv_temp == o.inv_temp;
+    }
+  };
+  GraphKey gkey{}, gcand{};      // key of the instantiated graph; key of the previous small-batch call
+  hipGraphExec_t gexec = nullptr;
+  int use_graph = 1;
+  hipStream_t sub[4] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev_fork = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
   char err[512] = "";
   // profiling
   bool prof = false;
@@ -286,11 +303,20 @@ EncWs enc_ws(int B, int T, int C) {
   return w;
 }
 
-size_t ws_floats(int B, int T, int C) {
+size_t ws_floats_one(int B, int T, int C) {
   const size_t state = align_up((size_t)B * T * C * 64, 64);
   const size_t enc = enc_ws(B, T, C).end;
   const size_t loop = loop_ws(B, T, C).end;
   return state + std::max(enc, loop) + 256;
+}
+// a rollout may run as up to NNJ_MAX_SUB independent sub-batches on streams of their own (nnj_set_concurrency):
+// the workspace holds either the whole batch or every split of it
+constexpr int NNJ_MAX_SUB = 4;
+size_t ws_floats(int B, int T, int C) {
+  size_t need = ws_floats_one(B, T, C);
+  for (int ns = 2; ns <= NNJ_MAX_SUB; ++ns)
+    if (B >= ns) need = std::max(need, (size_t)ns * align_up(ws_floats_one((B + ns - 1) / ns, T, C), 64));
+  return need;
 }
 
 // ------------------------------------------------------------------ encoder launches
@@ -666,6 +692,12 @@ int nnj_destroy(nnj_handle* h) {
   hipSetDevice(h->cfg.device);
   if (h->d_w) hipFree(h->d_w);
   if (h->d_flag) hipFree(h->d_flag);
+  if (h->gexec) hipGraphExecDestroy(h->gexec);
+  for (int k = 0; k < 4; ++k) {
+    if (h->sub[k]) hipStreamDestroy(h->sub[k]);
+    if (h->ev_join[k]) hipEventDestroy(h->ev_join[k]);
+  }
+  if (h->ev_fork) hipEventDestroy(h->ev_fork);
   for (hipEvent_t e : h->ev) hipEventDestroy(e);
   delete h;
   return NNJ_OK;
@@ -750,6 +782,7 @@ int nnj_load_weights(nnj_handle* h, const float* p, size_t n) {
     }
   }
   if (h->d_w) { hipFree(h->d_w); h->d_w = nullptr; }
+  if (h->gexec) { hipGraphExecDestroy(h->gexec); h->gexec = nullptr; }      // captured launches point at the old weights
   HIPCHK(h, hipMalloc(&h->d_w, total * sizeof(float)));
   HIPCHK(h, hipMemcpy(h->d_w, host.data(), total * sizeof(float), hipMemcpyHostToDevice));
   h->have_w = true;
@@ -898,16 +931,9 @@ int nnj_step(nnj_handle* h, const float* state, const uint8_t* mask, const int32
   return NNJ_OK;
 }
 
-static int rollout_impl(nnj_handle* h, const uint8_t* codes, const uint8_t* mask_in, int32_t B, int32_t T, int32_t L,
+static int rollout_core(nnj_handle* h, const uint8_t* codes, const uint8_t* mask_in, int32_t B, int32_t T, int32_t L,
                         int32_t n_encode, const int32_t* forced, const float* uniforms, float inv_temp,
-                        int32_t* merges_out, float* trace, float* gap, float* state_out, void* ws, size_t ws_bytes,
-                        void* stream) {
-  if (int rc = ready(h)) return rc;
-  if (!codes || !merges_out || T < 2) return fail(h, NNJ_ERR_ARG, "rollout: bad argument");
-  if (n_encode != B && n_encode != 1) return fail(h, NNJ_ERR_ARG, "rollout: n_encode must be 1 or B");
-  if (int rc = check_shape(h, B, T, L)) return rc;
-  if (int rc = need_ws(h, ws, ws_bytes, B, T, L)) return rc;
-  hipStream_t st = static_cast<hipStream_t>(stream);
+                        int32_t* merges_out, float* trace, float* gap, float* state_out, void* ws, hipStream_t st) {
   const int C = L;
   float* S = static_cast<float*>(ws);
   const size_t state = align_up((size_t)B * T * C * 64, 64);
@@ -960,6 +986,106 @@ static int rollout_impl(nnj_handle* h, const uint8_t* codes, const uint8_t* mask
     }
   }
   HIPCHK(h, hipGetLastError());
+  return NNJ_OK;
+}
+
+// The alignments of a batch are independent: a rollout of B >= 64 alignments runs as `concurrency`
+// sub-batches on streams of the library's own, forked from and joined to the caller's stream by events (the call
+// stays asynchronous on `stream`, nothing else changes for the caller).  The sub-batches drift apart by a kernel or
+// two, so HBM-bound launches of one (merged-row passes, q/k/v planes) overlap matrix- and vector-bound launches of
+// another, and the tail of every launch is filled by the other sub-batch.
+static int rollout_impl(nnj_handle* h, const uint8_t* codes, const uint8_t* mask_in, int32_t B, int32_t T, int32_t L,
+                        int32_t n_encode, const int32_t* forced, const float* uniforms, float inv_temp,
+                        int32_t* merges_out, float* trace, float* gap, float* state_out, void* ws, size_t ws_bytes,
+                        void* stream) {
+  if (int rc = ready(h)) return rc;
+  if (!codes || !merges_out || T < 2) return fail(h, NNJ_ERR_ARG, "rollout: bad argument");
+  if (n_encode != B && n_encode != 1) return fail(h, NNJ_ERR_ARG, "rollout: n_encode must be 1 or B");
+  if (int rc = check_shape(h, B, T, L)) return rc;
+  if (int rc = need_ws(h, ws, ws_bytes, B, T, L)) return rc;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  int ns = std::min(h->concurrency, NNJ_MAX_SUB);
+  if (n_encode != B || B < 64 || ns < 2) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    const bool graph_ok = h->use_graph && B <= 16 && !h->prof &&
+                          (st == nullptr || (hipStreamIsCapturing(st, &cs) == hipSuccess && cs == hipStreamCaptureStatusNone));
+    if (!graph_ok)
+      return rollout_core(h, codes, mask_in, B, T, L, n_encode, forced, uniforms, inv_temp, merges_out, trace, gap,
+                          state_out, ws, st);
+    // the legacy default stream cannot be captured: the graph then lives on a stream of the handle, forked from and
+    // joined to the caller's stream by events
+    hipStream_t gs = st;
+    if (st == nullptr) {
+      if (!h->sub[0]) HIPCHK(h, hipStreamCreateWithFlags(&h->sub[0], hipStreamNonBlocking));
+      if (!h->ev_fork) HIPCHK(h, hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+      if (!h->ev_join[0]) HIPCHK(h, hipEventCreateWithFlags(&h->ev_join[0], hipEventDisableTiming));
+      gs = h->sub[0];
+      HIPCHK(h, hipEventRecord(h->ev_fork, st));
+      HIPCHK(h, hipStreamWaitEvent(gs, h->ev_fork, 0));
+    }
+    const nnj_handle::GraphKey key{codes, mask_in, forced, uniforms, merges_out, trace, gap, state_out, ws,
+                                   B, T, L, n_encode, h->debug_stop, inv_temp};
+    if (!(h->gexec && key == h->gkey) && !(key == h->gcand)) {
+      // first call with these arguments: plain launches; a graph is built only when a call repeats (a caller that
+      // passes fresh buffers every time would otherwise pay a capture per call)
+      h->gcand = key;
+      if (int rc = rollout_core(h, codes, mask_in, B, T, L, n_encode, forced, uniforms, inv_temp, merges_out, trace, gap,
+                                state_out, ws, gs)) return rc;
+    } else if (!h->gexec || !(key == h->gkey)) {
+      if (h->gexec) { hipGraphExecDestroy(h->gexec); h->gexec = nullptr; }
+      // warm run outside the capture: kernel attributes (dynamic LDS sizes) are set by the launch helpers
+      if (int rc = rollout_core(h, codes, mask_in, B, T, L, n_encode, forced, uniforms, inv_temp, merges_out, trace, gap,
+                                state_out, ws, gs)) return rc;
+      HIPCHK(h, hipStreamBeginCapture(gs, hipStreamCaptureModeThreadLocal));
+      const int rc = rollout_core(h, codes, mask_in, B, T, L, n_encode, forced, uniforms, inv_temp, merges_out, trace,
+                                  gap, state_out, ws, gs);
+      hipGraph_t graph = nullptr;
+      const hipError_t e = hipStreamEndCapture(gs, &graph);
+      if (rc) { if (graph) hipGraphDestroy(graph); return rc; }
+      if (e != hipSuccess || !graph) return fail(h, NNJ_ERR_HIP, "hipStreamEndCapture failed: %s", hipGetErrorString(e));
+      const hipError_t e2 = hipGraphInstantiate(&h->gexec, graph, nullptr, nullptr, 0);
+      hipGraphDestroy(graph);
+      if (e2 != hipSuccess) { h->gexec = nullptr; return fail(h, NNJ_ERR_HIP, "hipGraphInstantiate failed: %s", hipGetErrorString(e2)); }
+      h->gkey = key;                       // the warm run above already produced this call's results
+    } else {
+      HIPCHK(h, hipGraphLaunch(h->gexec, gs));
+    }
+    if (gs != st) {
+      HIPCHK(h, hipEventRecord(h->ev_join[0], gs));
+      HIPCHK(h, hipStreamWaitEvent(st, h->ev_join[0], 0));
+    }
+    return NNJ_OK;
+  }
+  if (!h->ev_fork) HIPCHK(h, hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+  for (int k = 0; k < ns; ++k) {
+    if (!h->sub[k]) HIPCHK(h, hipStreamCreateWithFlags(&h->sub[k], hipStreamNonBlocking));
+    if (!h->ev_join[k]) HIPCHK(h, hipEventCreateWithFlags(&h->ev_join[k], hipEventDisableTiming));
+  }
+  size_t total = 0;
+  for (int n = T; n >= 2; --n) total += (size_t)n * (n - 1) / 2;
+  const int per = (B + ns - 1) / ns;
+  const size_t sub_floats = align_up(ws_floats_one(per, T, L), 64);
+  HIPCHK(h, hipEventRecord(h->ev_fork, st));
+  for (int k = 0; k < ns; ++k) {
+    const int b0 = k * per, bn = std::min(per, B - b0);
+    if (bn <= 0) break;
+    HIPCHK(h, hipStreamWaitEvent(h->sub[k], h->ev_fork, 0));
+    if (int rc = rollout_core(h, codes + (size_t)b0 * T * L, mask_in ? mask_in + (size_t)b0 * L : nullptr, bn, T, L, bn,
+                              forced ? forced + (size_t)b0 * (T - 1) * 2 : nullptr,
+                              uniforms ? uniforms + (size_t)b0 * (T - 1) : nullptr, inv_temp,
+                              merges_out + (size_t)b0 * (T - 1) * 2, trace ? trace + (size_t)b0 * total : nullptr,
+                              gap ? gap + (size_t)b0 * (T - 1) : nullptr,
+                              state_out ? state_out + (size_t)b0 * T * L * 64 : nullptr,
+                              static_cast<float*>(ws) + (size_t)k * sub_floats, h->sub[k])) return rc;
+    HIPCHK(h, hipEventRecord(h->ev_join[k], h->sub[k]));
+    HIPCHK(h, hipStreamWaitEvent(st, h->ev_join[k], 0));
+  }
+  return NNJ_OK;
+}
+
+int nnj_set_concurrency(nnj_handle* h, int32_t streams) {
+  if (!h || streams < 1 || streams > NNJ_MAX_SUB) return fail(h, NNJ_ERR_ARG, "nnj_set_concurrency: 1..%d", NNJ_MAX_SUB);
+  h->concurrency = streams;
   return NNJ_OK;
 }
 

@@ -861,8 +861,8 @@ __global__ __launch_bounds__(256) void k_assemble_argmax(const float* __restrict
                                                          const float* __restrict__ uniforms, long u_bstride,
                                                          float inv_temp, int* __restrict__ nonfinite) {
   __shared__ float newsc[256];
-  __shared__ float red_v[256];
-  __shared__ int red_i[256];
+  __shared__ float red_v[8];
+  __shared__ int red_i[4];
   const int tid = threadIdx.x, b = blockIdx.x;
   const int np = num_pairs(n), np_prev = num_pairs(n + 1);
   int ip = 0, jp = 0;
@@ -876,7 +876,10 @@ __global__ __launch_bounds__(256) void k_assemble_argmax(const float* __restrict
     }
     __syncthreads();
   }
-  float best = -INFINITY;
+  // one pass: every thread keeps the best (first maximal index wins) and the runner-up VALUE of its entries; the
+  // triples are merged by wavefront shuffles (6 steps) and once across the four waves through LDS -- two workgroup
+  // barriers instead of the 16 + 8 of a shared-memory tree
+  float best = -INFINITY, second = -INFINITY;
   int besti = 0x7fffffff;
   for (int p = tid; p < np; p += 256) {
     float v;
@@ -893,33 +896,29 @@ __global__ __launch_bounds__(256) void k_assemble_argmax(const float* __restrict
     }
     logits_out[(size_t)b * np + p] = v;
     if (trace_out) trace_out[(size_t)b * trace_bstride + p] = v;
-    if (v > best || (v == best && p < besti)) { best = v; besti = p; }
+    if (v > best) { second = best; best = v; besti = p; }       // p increases: a later equal value never replaces
+    else second = fmaxf(second, v);
     // a score that is not finite means an operand left the range of the fp16 pieces (nnj_common.hpp): sticky flag,
     // read back by nnj_numeric_status -- the library must not return a wrong tree silently
     if (!(fabsf(v) <= 3.402823466e38f) && nonfinite) atomicOr(nonfinite, NNJ_FLAG_NONFINITE);
   }
-  red_v[tid] = best; red_i[tid] = besti;
-  __syncthreads();
-  for (int s = 128; s >= 1; s >>= 1) {
-    if (tid < s) {
-      const float v2 = red_v[tid + s]; const int i2 = red_i[tid + s];
-      if (v2 > red_v[tid] || (v2 == red_v[tid] && i2 < red_i[tid])) { red_v[tid] = v2; red_i[tid] = i2; }
-    }
-    __syncthreads();
+  auto merge = [](float& b1, int& i1, float& s1, float b2, int i2, float s2) {
+    if (b2 > b1 || (b2 == b1 && i2 < i1)) { s1 = fmaxf(b1, s2); b1 = b2; i1 = i2; }
+    else s1 = fmaxf(s1, b2);
+  };
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    const float b2 = __shfl_xor(best, o), s2 = __shfl_xor(second, o);
+    const int i2 = __shfl_xor(besti, o);
+    merge(best, besti, second, b2, i2, s2);
   }
-  const int bi = (red_i[0] >= 0 && red_i[0] < np) ? red_i[0] : 0;   // all-NaN table: stay in range
-  const float bv = red_v[0];
+  if ((tid & 63) == 0) { red_v[tid >> 6] = best; red_i[tid >> 6] = besti; red_v[4 + (tid >> 6)] = second; }
   __syncthreads();
-  // second best for the top-2 gap
-  float second = -INFINITY;
-  for (int p = tid; p < np; p += 256)
-    if (p != bi) second = fmaxf(second, logits_out[(size_t)b * np + p]);
-  red_v[tid] = second;
-  __syncthreads();
-  for (int s = 128; s >= 1; s >>= 1) {
-    if (tid < s) red_v[tid] = fmaxf(red_v[tid], red_v[tid + s]);
-    __syncthreads();
-  }
+  best = red_v[0]; besti = red_i[0]; second = red_v[4];
+#pragma unroll
+  for (int wv = 1; wv < 4; ++wv) merge(best, besti, second, red_v[wv], red_i[wv], red_v[4 + wv]);
+  const int bi = (besti >= 0 && besti < np) ? besti : 0;   // all-NaN table: stay in range
+  const float bv = best;
   if (tid == 0) {
     int ci, cj;
     pair_from_index(n, bi, ci, cj);
@@ -939,7 +938,7 @@ __global__ __launch_bounds__(256) void k_assemble_argmax(const float* __restrict
       pair_from_index(n, k, ci, cj);
     }
     if (merges_out) { merges_out[(size_t)b * merges_bstride] = ci; merges_out[(size_t)b * merges_bstride + 1] = cj; }
-    if (gap_out) gap_out[(size_t)b * gap_bstride] = np > 1 ? bv - red_v[0] : 0.f;
+    if (gap_out) gap_out[(size_t)b * gap_bstride] = np > 1 ? bv - second : 0.f;
     if (forced) {
       const int fi = forced[(size_t)b * forced_bstride], fj = forced[(size_t)b * forced_bstride + 1];
       if (fi >= 0 && fi < fj && fj < n) { ci = fi; cj = fj; }       // out-of-range forcing is ignored
