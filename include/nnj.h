@@ -173,6 +173,13 @@ int nnj_rollout_sample(nnj_handle* h, const uint8_t* codes_dev, const uint8_t* m
                        int32_t* merges_out_dev, float* logits_trace_dev,
                        void* ws_dev, size_t ws_bytes, void* stream);
 
+/* Duplicate filter of the sampling mode -- the reference keeps one tree per `topo_repr` string (utils.py:76, the
+ * rooted topology with children ordered by their smallest leaf).  keys_out uint64 [B]: a 64-bit key of the same
+ * equivalence computed on the device from the merge lists int32 [B,T-1,2] (leaf = hash of its index, join = hash of
+ * the commutative sum of its children): equal keys <=> equal topo_repr, up to 2^-64 collisions. */
+int nnj_topology_hash(nnj_handle* h, const int32_t* merges_dev, int32_t B, int32_t T, uint64_t* keys_out_dev,
+                      void* stream);
+
 /* Concurrency of the rollout entry points.  The alignments of a batch are independent; with streams = k (1..4,
  * default 2) a rollout of B >= 64 alignments is cut into k contiguous sub-batches that run on k streams owned by the
  * handle, forked from and joined to the caller's `stream` with events: the call is still asynchronous on `stream` and

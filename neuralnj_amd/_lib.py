@@ -47,6 +47,7 @@ _SIGS = {
     "nnj_profile_read": ([_vp, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int32], C.c_int),
     "nnj_profile_dropped": ([_vp, C.POINTER(C.c_int64)], C.c_int),
     "nnj_set_concurrency": ([_vp, C.c_int32], C.c_int),
+    "nnj_topology_hash": ([_vp, _vp, C.c_int32, C.c_int32, _vp, _vp], C.c_int),
     "nnj_debug_encoder_stop": ([_vp, C.c_int32], C.c_int),
     "nnj_numeric_status": ([_vp, C.POINTER(C.c_int32), _vp], C.c_int),
     "nnj_step": ([_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int32, C.c_int32, C.c_int32, _vp, C.c_size_t,
@@ -286,6 +287,14 @@ class Nnj:
         self._chk(self.lib.nnj_step(self.h, _p(state), _p(mask), _p(ij), _p(lp), _p(fn), _p(st), _p(lo), _p(cij),
                                     _p(gap), B, n, L, _p(ws), ws.numel(), self._stream()))
         return dict(state=st, logits=lo, ij=cij, top2_gap=gap)
+
+    def topology_hash(self, merges):
+        """64-bit topology keys [B] (int64 view of the uint64 keys) of merge lists [B,T-1,2]: equal <=> same topo_repr."""
+        merges = self._i32(merges)
+        B, tm1, _ = merges.shape
+        keys = torch.empty((B,), dtype=torch.int64, device=self.device)
+        self._chk(self.lib.nnj_topology_hash(self.h, _p(merges), B, tm1 + 1, _p(keys), self._stream()))
+        return keys
 
     def set_concurrency(self, streams: int):
         """Sub-batches of a rollout that run on streams of the library's own (include/nnj.h nnj_set_concurrency)."""

@@ -1104,6 +1104,16 @@ int nnj_rollout_sample(nnj_handle* h, const uint8_t* codes, const uint8_t* mask,
                       nullptr, ws, ws_bytes, stream);
 }
 
+int nnj_topology_hash(nnj_handle* h, const int32_t* merges, int32_t B, int32_t T, uint64_t* keys_out, void* stream) {
+  if (!h) return fail(nullptr, NNJ_ERR_ARG, "null handle");
+  HIPCHK(h, hipSetDevice(h->cfg.device));
+  if (!merges || !keys_out || B <= 0 || T < 2 || T > 256) return fail(h, NNJ_ERR_ARG, "nnj_topology_hash: bad argument");
+  hipLaunchKernelGGL(k_topology_hash, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, static_cast<hipStream_t>(stream), merges,
+                     reinterpret_cast<unsigned long long*>(keys_out), B, T);
+  HIPCHK(h, hipGetLastError());
+  return NNJ_OK;
+}
+
 int nnj_debug_encoder_stop(nnj_handle* h, int32_t stage) {
   if (!h) return NNJ_ERR_ARG;
   h->debug_stop = stage;

@@ -919,24 +919,54 @@ __global__ __launch_bounds__(256) void k_assemble_argmax(const float* __restrict
   for (int wv = 1; wv < 4; ++wv) merge(best, besti, second, red_v[wv], red_i[wv], red_v[4 + wv]);
   const int bi = (besti >= 0 && besti < np) ? besti : 0;   // all-NaN table: stay in range
   const float bv = best;
-  if (tid == 0) {
-    int ci, cj;
-    pair_from_index(n, bi, ci, cj);
-    if (uniforms) {
-      // Categorical(logits / temperature).sample() by inverse CDF on a supplied uniform u in [0,1)
-      // (finetune_rl_search.py:147): smallest k with sum_{p<=k} e_p > u * sum_p e_p, fp64, flat order
-      const float* lg = logits_out + (size_t)b * np;
-      double total = 0.0;
-      for (int p = 0; p < np; ++p) total += exp((double)(lg[p] - bv) * (double)inv_temp);
-      const double target = (double)uniforms[(size_t)b * u_bstride] * total;
-      double run = 0.0;
-      int k = np - 1;
-      for (int p = 0; p < np; ++p) {
+  int pick = bi;
+  if (uniforms) {
+    // Categorical(logits / temperature).sample() by inverse CDF on a supplied uniform u in [0,1)
+    // (finetune_rl_search.py:147): smallest k with sum_{p<=k} e_p > u * sum_p e_p, fp64, flat pair order.
+    // Parallel: thread t owns the contiguous entries [t*chunk, (t+1)*chunk); local fp64 sums, an exclusive scan of the
+    // 256 sums (wavefront shuffles + the four wave totals through LDS), then the FIRST thread whose range crosses
+    // the target walks its entries.  (The running sum is associated per chunk, not strictly left to right: it can
+    // differ from a sequential sum in the last fp64 bit, i.e. only for a uniform within 1e-16 of a CDF boundary.)
+    __shared__ double wsum[4];
+    __shared__ int first_hit;
+    if (tid == 0) first_hit = 0x7fffffff;
+    const float* lg = logits_out + (size_t)b * np;
+    const int chunk = (np + 255) / 256;
+    const int p0 = min(tid * chunk, np), p1 = min(p0 + chunk, np);
+    double local = 0.0;
+    for (int p = p0; p < p1; ++p) local += exp((double)(lg[p] - bv) * (double)inv_temp);
+    double incl = local;                                   // inclusive scan inside the wave
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const double up = __shfl_up(incl, o);
+      if ((tid & 63) >= o) incl += up;
+    }
+    if ((tid & 63) == 63) wsum[tid >> 6] = incl;
+    __syncthreads();
+    double base = 0.0, total = 0.0;
+#pragma unroll
+    for (int wv = 0; wv < 4; ++wv) { if (wv < (tid >> 6)) base += wsum[wv]; total += wsum[wv]; }
+    const double before = base + incl - local;             // sum of all entries of lower flat index
+    const double target = (double)uniforms[(size_t)b * u_bstride] * total;
+    if (p1 > p0 && before + local > target) atomicMin(&first_hit, tid);
+    __syncthreads();
+    const int hit = first_hit;
+    if (hit == 0x7fffffff) pick = np - 1;                  // rounding: target >= total
+    else if (tid == hit) {
+      double run = before;
+      int k = p1 - 1;
+      for (int p = p0; p < p1; ++p) {
         run += exp((double)(lg[p] - bv) * (double)inv_temp);
         if (run > target) { k = p; break; }
       }
-      pair_from_index(n, k, ci, cj);
+      first_hit = -k - 1;                                  // publish the pick to thread 0
     }
+    __syncthreads();
+    if (hit != 0x7fffffff) pick = -first_hit - 1;
+  }
+  if (tid == 0) {
+    int ci, cj;
+    pair_from_index(n, pick, ci, cj);
     if (merges_out) { merges_out[(size_t)b * merges_bstride] = ci; merges_out[(size_t)b * merges_bstride + 1] = cj; }
     if (gap_out) gap_out[(size_t)b * gap_bstride] = np > 1 ? bv - second : 0.f;
     if (forced) {
@@ -945,6 +975,30 @@ __global__ __launch_bounds__(256) void k_assemble_argmax(const float* __restrict
     }
     ij_cur[2 * b] = ci; ij_cur[2 * b + 1] = cj;
   }
+}
+
+// Topology key of a finished rollout for the duplicate filter of the sampling mode (reference utils.py:76 compares
+// `topo_repr`, the rooted topology string whose children are ordered by their smallest leaf): a 64-bit hash of the
+// same equivalence -- leaves hash their index, a join hashes the COMMUTATIVE sum of its children -- so two merge
+// lists get the same key iff they build the same rooted, unordered, leaf-labelled tree (up to 2^-64 collisions).
+__device__ __forceinline__ unsigned long long mix64(unsigned long long x) {    // splitmix64 finaliser
+  x ^= x >> 30; x *= 0xbf58476d1ce4e5b9ull;
+  x ^= x >> 27; x *= 0x94d049bb133111ebull;
+  return x ^ (x >> 31);
+}
+__global__ void k_topology_hash(const int* __restrict__ merges, unsigned long long* __restrict__ keys, int B, int T) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  unsigned long long hsh[256];                              // current rows (positions), T <= 256
+  for (int i = 0; i < T; ++i) hsh[i] = mix64(0x9e3779b97f4a7c15ull * (unsigned long long)(i + 1));
+  const int* m = merges + (size_t)b * (T - 1) * 2;
+  int n = T;
+  for (int s = 0; s < T - 1; ++s, --n) {
+    const int i = min(max(m[2 * s], 0), n - 1), j = min(max(m[2 * s + 1], 0), n - 1);
+    hsh[i] = mix64(hsh[i] + hsh[j] + 0x632be59bd9b4e019ull);
+    for (int p = j; p < n - 1; ++p) hsh[p] = hsh[p + 1];   // position j is deleted (environment.py:764-768)
+  }
+  keys[b] = hsh[0];
 }
 
 // argmax of a given table (finetune_rl_search.py:145,159-160): ij_out [B][2], gap [B] optional

@@ -68,15 +68,21 @@ def sample_rollouts(batch, agent, env, n_rollouts, seed=0, temperature=1.0, devi
     u = torch.from_numpy(np.random.default_rng(seed).random((n_rollouts, T - 1)).astype(np.float32))
     r = agent._context().rollout_sample(codes[:1].to(device), mask[:1], u, temperature=temperature,
                                         replicas=n_rollouts)
+    # duplicate filter on the device (reference utils.py:76 keeps one tree per topo_repr): 64-bit topology keys,
+    # only the first rollout of every distinct key is replayed into a host tree
+    keys = agent._context().topology_hash(r["merges"])
+    uniq, inverse, counts = torch.unique(keys, return_inverse=True, return_counts=True)
+    first = torch.full((uniq.numel(),), n_rollouts, dtype=torch.long, device=keys.device)
+    first.scatter_reduce_(0, inverse, torch.arange(n_rollouts, device=keys.device), reduce="amin")
+    order = torch.argsort(first)                          # distinct trees in order of first appearance
+    first, counts = first[order].cpu().numpy(), counts[order].cpu().numpy()
     merges = r["merges"].cpu().numpy()
     agent._context().check_numeric()
-    env.init_states([batch["seqs"][0]] * n_rollouts, [batch["seq_keys"][0]] * n_rollouts, None)
-    env.apply_merges(merges)
-    trees = {}
-    for st in env.states:
-        t = st.subtrees[0]
-        trees.setdefault(t.topo_repr, [t.utree_op_str, 0])[1] += 1
-    return [(nwk, cnt) for nwk, cnt in trees.values()], merges
+    k = len(first)
+    env.init_states([batch["seqs"][0]] * k, [batch["seq_keys"][0]] * k, None)
+    env.apply_merges(merges[first])
+    trees = [(st.subtrees[0].utree_op_str, int(c)) for st, c in zip(env.states, counts)]
+    return trees, merges
 
 
 def argmax_inference(cfgs, test_dir, write_dir, device="cuda", fast=True):

@@ -46,6 +46,18 @@ def main():
     g.profile_enable(False)
     res["kernel_ms_B1"] = {k: round(v[0], 2) for k, v in prof.items() if v[1]}
     print(res["kernel_ms_B1"], flush=True)
+    # Search mode at the BASELINE shape (infer_opt=Search): 8 sampled rollouts of ONE alignment, encoded once
+    u = torch.rand((8, T - 1), generator=torch.Generator().manual_seed(1))
+    g.rollout_sample(codes, None, u, temperature=1.0, replicas=8)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    rs = g.rollout_sample(codes, None, u, temperature=1.0, replicas=8)
+    keys = g.topology_hash(rs["merges"]).cpu()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    g.check_numeric()
+    res["search_8_rollouts"] = {"s": dt, "rollouts_per_sec": 8 / dt, "distinct_topologies": int(torch.unique(keys).numel())}
+    print("search: 8 sampled rollouts of one 200 x 4096 alignment (encoded once):", res["search_8_rollouts"], flush=True)
     if want_oracle:
         from oracle_lib import Oracle
         m = r["merges"].cpu().numpy()
