@@ -179,6 +179,32 @@ def verify_sample(g, cfgs, packed, codes, merges, T, L, k=8, threads=16, tol=1e-
                      "tables than the fp32 oracle itself")
 
 
+def step_api_path(g, codes, mask, T, merges_ref):
+    """Throughput of a maintainer's binding of the fused step: nnj_encode, nnj_pair_scores_full, nnj_select_pair, then
+    T-2 x nnj_step (one C-ABI call per loop iteration, dense state tensor in and out as the reference's env.step
+    returns it, no host round trip).  Same kernels as the rollout plus one dense gather of the live rows per step."""
+    def run():
+        state = g.encode(codes, mask)
+        logits = g.pair_scores_full(state, mask)
+        ij, _ = g.select_pair(logits, T)
+        ms = [ij]
+        for n in range(T - 1, 1, -1):
+            r = g.step(state, mask, ij, logits)
+            state, logits, ij = r["state"], r["logits"], r["ij"]
+            ms.append(ij)
+        return torch.stack(ms, 1).cpu()
+    run()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    m = run()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    B = codes.shape[0]
+    return dict(workload=f"Batch={B}: nnj_encode + nnj_pair_scores_full + {T - 2} x nnj_step (fused step, dense state in/out)",
+                trees_per_sec=B / dt, ms_per_rollout=1e3 * dt,
+                merges_equal_fused_rollout=bool(torch.equal(m, merges_ref)))
+
+
 def compat_path(cfgs, packed, codes, T, L, dev):
     """Throughput of the API-compatible step-by-step path (neuralnj_amd.rollout.reinforce_rollout_argmax: the
     reference's own call sequence through model.PhyloATTN / environment.PhyInferEnv, one host round trip per
@@ -443,6 +469,10 @@ def main():
             cp, m_api = compat_path(cfgs, packed, codes, T, L, dev)
             cp["merges_equal_fused_path_on_all_trees"] = bool(np.array_equal(m_api, merges.numpy()))
             out["compat_path"] = cp
+            g.set_concurrency(1)                      # the step API works on the whole batch: compare like with like
+            whole = g.rollout_argmax(codes, mask)["merges"].cpu()
+            out["step_api_path"] = step_api_path(g, codes, mask, T, whole)
+            g.set_concurrency(args.streams)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfgs, packed, T, L)
         if verified is not None:

@@ -130,15 +130,21 @@ int nnj_env_step(nnj_handle* h, const float* state_dev, const int32_t* ij_dev,
 int nnj_select_pair(nnj_handle* h, const float* logits_dev, int32_t* ij_out_dev,
                     float* top2_gap_out_dev, int32_t B, int32_t n, void* stream);
 
-/* One iteration of the reference's loop body in its device order -- environment.py:760-835 (merge the pair
- * chosen in the previous iteration: nnj_env_step), then model.py:184-201 + utils.py:213-251 (score the new
- * pairs, assemble the table: nnj_pair_scores_incr), then finetune_rl_search.py:145,159-160 (argmax:
- * nnj_select_pair) -- as ONE call with no host round trip in between.
+/* One iteration of the reference's loop body in its device order -- environment.py:760-835 (merge the pair chosen in
+ * the previous iteration), then model.py:184-201 + utils.py:213-251 (score the n new pairs, assemble the table), then
+ * finetune_rl_search.py:145,159-160 (argmax) -- as ONE fused step with no host round trip: the kernels of
+ * nnj_rollout_argmax's loop body, once each.
  *   state_dev        [B,n+1,C,D]   rows before the merge          ij_dev        int32 [B,2] the pair to merge
  *   logits_prev_dev  [B,P(n+1)]    the table ij_dev was chosen from
  *   forced_next_dev  NULL, or int32 [B,2]: returned in chosen_ij_dev instead of the argmax (teacher forcing)
  *   state_out_dev    [B,n,C,D]     logits_out_dev [B,P(n)]   chosen_ij_dev int32 [B,2]   top2_gap_dev [B] or NULL
- * n = number of rows AFTER the merge, n >= 2. */
+ * n = number of rows AFTER the merge, n >= 2.
+ * A loop of calls is a session: the library keeps the rows in slot layout, with the cached per-row transforms, inside
+ * the caller's workspace, so consecutive steps re-transform nothing.  The session continues when state_dev is the
+ * state_out_dev of the previous call (same workspace pointer, B, L, and n+1 = the previous n); anything else --
+ * another tensor, another workspace, any other entry point called on the same workspace in between -- starts a new
+ * session from the dense state_dev (copy + row transforms).  Iterated from the encoder output it reproduces
+ * nnj_rollout_argmax bit for bit.  state_out_dev is the dense tensor the reference's env.step returns. */
 int nnj_step(nnj_handle* h, const float* state_dev, const uint8_t* mask_dev, const int32_t* ij_dev,
              const float* logits_prev_dev, const int32_t* forced_next_dev, float* state_out_dev,
              float* logits_out_dev, int32_t* chosen_ij_dev, float* top2_gap_dev, int32_t B, int32_t n, int32_t L,

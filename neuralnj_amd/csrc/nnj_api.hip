@@ -66,6 +66,10 @@ struct nnj_handle {
              n_encode == o.n_encode && debug_stop == o.debug_stop && inv_temp == o.inv_temp;
     }
   };
+  // nnj_step keeps the rows of an ongoing loop in slot layout inside the caller's workspace, with their cached
+  // transforms (U, K', beta), exactly like the rollout: consecutive steps re-transform nothing
+  struct StepSession { bool valid = false; const void* ws = nullptr; const float* last_out = nullptr; int B = 0, T0 = 0, L = 0, n = 0; };
+  StepSession sess;
   GraphKey gkey{}, gcand{};      // key of the instantiated graph; key of the previous small-batch call
   hipGraphExec_t gexec = nullptr;
   int use_graph = 1;
@@ -633,6 +637,7 @@ RowSet dense_rowset(nnj_handle* h, const float* state, float* base, const LoopWs
 }
 
 int need_ws(nnj_handle* h, void* ws, size_t ws_bytes, int B, int T, int C) {
+  h->sess.valid = false;                 // every workspace user overwrites the regions a step session lives in
   if (!ws) return fail(h, NNJ_ERR_ARG, "workspace pointer is null");
   const size_t need = ws_floats(B, T, C) * sizeof(float);
   if (ws_bytes < need) return fail(h, NNJ_ERR_WORKSPACE, "workspace too small: %zu < %zu bytes", ws_bytes, need);
@@ -921,13 +926,59 @@ int nnj_step(nnj_handle* h, const float* state, const uint8_t* mask, const int32
   if (int rc = ready(h)) return rc;
   if (!state || !ij || !logits_prev || !state_out || !logits_out || !chosen_ij || n < 2)
     return fail(h, NNJ_ERR_ARG, "nnj_step: bad argument (n = rows after the merge, >= 2)");
-  // the three stages run back to back on the stream; each checks its own shapes against the workspace
-  if (int rc = nnj_env_step(h, state, ij, state_out, B, n + 1, L, ws, ws_bytes, stream)) return rc;
-  if (int rc = nnj_pair_scores_incr(h, state_out, mask, ij, logits_prev, logits_out, B, n, L, ws, ws_bytes, stream)) return rc;
-  if (int rc = nnj_select_pair(h, logits_out, chosen_ij, top2_gap, B, n, stream)) return rc;
-  if (forced_next)
-    HIPCHK(h, hipMemcpyAsync(chosen_ij, forced_next, (size_t)B * 2 * sizeof(int32_t), hipMemcpyDeviceToDevice,
-                             static_cast<hipStream_t>(stream)));
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int C = L;
+  // A loop of nnj_step calls is a SESSION: the rows live in slot layout in the caller's workspace next to their
+  // cached transforms (the rollout's own state), so a step runs the rollout's kernels once -- merged-row aggregate in
+  // place, live-list update, the n new scores, table + argmax -- and re-transforms nothing.  The session continues
+  // when `state` is the tensor the previous call returned (same workspace, batch, sites and row count); any other
+  // input starts a new one from the dense tensor (copy into slots + row transforms).  state_out is the dense
+  // gather of the live rows the reference's env.step hands back (environment.py:833-835).
+  nnj_handle::StepSession& ss = h->sess;
+  const bool cont = ss.valid && ss.ws == ws && ss.last_out == state && ss.B == B && ss.L == L && ss.n == n + 1;
+  const int T0 = cont ? ss.T0 : n + 1;
+  if (int rc = check_shape(h, B, T0, L)) return rc;
+  if (int rc = need_ws(h, ws, ws_bytes, B, T0, L)) return rc;      // (invalidates the session: re-validated below)
+  float* S = static_cast<float*>(ws);
+  float* base = S + align_up((size_t)B * T0 * C * 64, 64);
+  const LoopWs w = loop_ws(B, T0, C);
+  int* live = reinterpret_cast<int*>(base + w.live);
+  int* ijs = reinterpret_cast<int*>(base + w.ij);
+  if (!cont) {
+    HIPCHK(h, hipMemcpyAsync(S, state, (size_t)B * T0 * C * 64 * sizeof(float), hipMemcpyDeviceToDevice, st));
+    {
+      Scope sc(h, st, PK_MISC);
+      hipLaunchKernelGGL(k_init_live, dim3((unsigned)((B * T0 + 255) / 256)), dim3(256), 0, st, live, T0, B, T0);
+    }
+    launch_row_xf(h, S, base + w.U, base + w.Kp, base + w.beta, (long)T0 * C * 64, T0, T0, B, C, st);
+  }
+  RowSet rs;
+  rs.S = S; rs.U = base + w.U; rs.Kp = base + w.Kp; rs.beta_part = base + w.beta;
+  rs.bstride = (long)T0 * C * 64; rs.live = live; rs.live_stride = T0; rs.ntile32 = (C + 31) / 32;
+  HIPCHK(h, hipMemcpyAsync(ijs, ij, (size_t)B * 2 * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+  // env.step (environment.py:760-835): merged row into slot(i), position j leaves the list
+  if (int rc = launch_aggregate(h, rs, ijs, base, w, S, base + w.U, base + w.Kp, base + w.beta, rs.bstride, T0, 1, n + 1,
+                                B, C, st)) return rc;
+  {
+    Scope sc(h, st, PK_MISC);
+    hipLaunchKernelGGL(k_update_live, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, st, live, T0, (const int*)ijs, B, n + 1);
+  }
+  // decode_zxr (model.py:184-201 + utils.py:213-251) and the argmax (finetune_rl_search.py:145,159-160)
+  PairGeom g;
+  if (int rc = launch_pair_scores(h, rs, ijs, mask, base, w, PAIRS_INCR, n, B, C, g, st)) return rc;
+  {
+    Scope sc(h, st, PK_ASSEMBLE);
+    hipLaunchKernelGGL(k_assemble_argmax, dim3((unsigned)B), dim3(256), 0, st, g.score_src, g.nsc, g.ppad, logits_prev,
+                       (const int*)ijs, logits_out, (float*)nullptr, 0L, forced_next, 2L, (int*)nullptr, 0L, top2_gap, 1L,
+                       chosen_ij, (int)PAIRS_INCR, n, (const float*)nullptr, 0L, 1.0f, h->d_flag);
+  }
+  {
+    Scope sc(h, st, PK_MISC);
+    hipLaunchKernelGGL(k_gather_rows, dim3(16, (unsigned)n, (unsigned)B), dim3(256), 0, st, (const float*)S, (const int*)live,
+                       T0, state_out, n, (long)C * 16, (long)T0 * C * 16);
+  }
+  HIPCHK(h, hipGetLastError());
+  ss.valid = true; ss.ws = ws; ss.last_out = state_out; ss.B = B; ss.T0 = T0; ss.L = L; ss.n = n;
   return NNJ_OK;
 }
 

@@ -1086,6 +1086,15 @@ __global__ void k_compact_rows(const float* __restrict__ state, const float* __r
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < row_f4; i += (long)gridDim.x * blockDim.x) d[i] = s[i];
 }
 
+// dense view of the live rows of a slot-layout state: out[b][p] = S[b][live[b][p]]  (environment.py:833-835)
+__global__ void k_gather_rows(const float* __restrict__ S, const int* __restrict__ live, int live_stride,
+                              float* __restrict__ out, int n, long row_f4, long b_f4) {
+  const int p = blockIdx.y, b = blockIdx.z;
+  const f32x4* src = reinterpret_cast<const f32x4*>(S) + (size_t)b * b_f4 + (size_t)live[(size_t)b * live_stride + p] * row_f4;
+  f32x4* d = reinterpret_cast<f32x4*>(out) + ((size_t)b * n + p) * row_f4;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < row_f4; i += (long)gridDim.x * blockDim.x) d[i] = src[i];
+}
+
 // state of batch element 0 copied to elements 1..B-1 (encode once, replicate: the sampling mode runs
 // B rollouts of ONE alignment; the reference re-encodes it for every rollout)
 __global__ void k_replicate(float* __restrict__ buf, long per_b_f4) {
