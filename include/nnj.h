@@ -186,6 +186,41 @@ int nnj_rollout_sample(nnj_handle* h, const uint8_t* codes_dev, const uint8_t* m
 int nnj_topology_hash(nnj_handle* h, const int32_t* merges_dev, int32_t B, int32_t T, uint64_t* keys_out_dev,
                       void* stream);
 
+/* ---- Tree likelihood on the GPU: stands where the reference calls raxmlpy.optimize_brlen
+ * (raxml-ng / libpll on the CPU: environment.py:365-441, 625-672, finetune_rl_search.py:401-411) to score sampled
+ * trees.  That arithmetic lives in un-vendored third-party code with no expected values in the reference's tests:
+ * PARITY UNPINNED.  These entry points follow the published algorithms (Felsenstein pruning; GTR, discrete-gamma rate
+ * heterogeneity with the mean rate per category, proportion of invariant sites; Newton-Raphson branch lengths) and
+ * are checked against closed forms and an independent numpy/scipy evaluation.  Model parameters are inputs: they are
+ * NOT optimised here (the reference passes opt_model=True to raxml-ng). */
+typedef struct nnj_subst_model {
+  double rates[6];   /* GTR exchangeabilities AC AG AT CG CT GT (GT = 1 by convention)  */
+  double freqs[4];   /* base frequencies A C G T (normalised by the library)            */
+  double alpha;      /* gamma shape; <= 0: no rate heterogeneity                        */
+  double pinv;       /* proportion of invariant sites, [0, 1)                           */
+  int32_t ncat;      /* discrete gamma categories, 1..8 (4 = "+G" / "+G4")              */
+} nnj_subst_model;
+
+/* Scratch bytes for the two entry points below (n_align = 1: all B trees are over ONE alignment; B: one each). */
+int nnj_lik_workspace_bytes(int32_t B, int32_t n_align, int32_t T, int32_t L, int32_t ncat, size_t* bytes);
+
+/* log-likelihood of B trees given as merge lists int32 [B,T-1,2] (the output of the rollout entry points).
+ * brlen_dev float [B,T-1,2]: length of the edge from each join to its two children, in merge order (NULL: 0.1
+ * everywhere); the two child edges of the last join form one edge of the unrooted tree.  codes uint8 [n_align,T,L]
+ * (gap / N / padding = every state possible), mask uint8 [n_align,L] or NULL (1 = site ignored).
+ * loglik_out_dev double [B].  fp64 throughout. */
+int nnj_tree_loglik(nnj_handle* h, const uint8_t* codes_dev, int32_t n_align, const uint8_t* mask_dev,
+                    const int32_t* merges_dev, const float* brlen_dev, const nnj_subst_model* model_host,
+                    int32_t B, int32_t T, int32_t L, double* loglik_out_dev, void* ws_dev, size_t ws_bytes, void* stream);
+
+/* Branch-length optimisation, then the log-likelihood: `sweeps` rounds (the reference asks raxml-ng for iters=3) of
+ * one Newton-Raphson solve per edge, all edges of all trees at once from the same partial likelihoods, the step per
+ * tree halved until the likelihood does not drop.  brlen_out_dev float [B,T-1,2] or NULL. */
+int nnj_tree_optimize(nnj_handle* h, const uint8_t* codes_dev, int32_t n_align, const uint8_t* mask_dev,
+                      const int32_t* merges_dev, const float* brlen_in_dev, const nnj_subst_model* model_host,
+                      int32_t sweeps, int32_t B, int32_t T, int32_t L, float* brlen_out_dev, double* loglik_out_dev,
+                      void* ws_dev, size_t ws_bytes, void* stream);
+
 /* Concurrency of the rollout entry points.  The alignments of a batch are independent; with streams = k (1..4,
  * default 2) a rollout of B >= 64 alignments is cut into k contiguous sub-batches that run on k streams owned by the
  * handle, forked from and joined to the caller's `stream` with events: the call is still asynchronous on `stream` and

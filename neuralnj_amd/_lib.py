@@ -22,6 +22,12 @@ class NnjConfig(C.Structure):
                 ("vocab_size", "patch_size", "embed_dim", "num_heads", "num_layers", "device")]
 
 
+class NnjSubstModel(C.Structure):
+    """include/nnj.h nnj_subst_model (GTR+I+G)."""
+    _fields_ = [("rates", C.c_double * 6), ("freqs", C.c_double * 4), ("alpha", C.c_double), ("pinv", C.c_double),
+                ("ncat", C.c_int32)]
+
+
 _SIGS = {
     "nnj_abi_version": ([], C.c_int),
     "nnj_create": ([C.POINTER(NnjConfig), C.POINTER(_vp)], C.c_int),
@@ -48,6 +54,11 @@ _SIGS = {
     "nnj_profile_dropped": ([_vp, C.POINTER(C.c_int64)], C.c_int),
     "nnj_set_concurrency": ([_vp, C.c_int32], C.c_int),
     "nnj_topology_hash": ([_vp, _vp, C.c_int32, C.c_int32, _vp, _vp], C.c_int),
+    "nnj_lik_workspace_bytes": ([C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_size_t)], C.c_int),
+    "nnj_tree_loglik": ([_vp, _vp, C.c_int32, _vp, _vp, _vp, C.POINTER(NnjSubstModel), C.c_int32, C.c_int32, C.c_int32, _vp,
+                         _vp, C.c_size_t, _vp], C.c_int),
+    "nnj_tree_optimize": ([_vp, _vp, C.c_int32, _vp, _vp, _vp, C.POINTER(NnjSubstModel), C.c_int32, C.c_int32, C.c_int32,
+                           C.c_int32, _vp, _vp, _vp, C.c_size_t, _vp], C.c_int),
     "nnj_debug_encoder_stop": ([_vp, C.c_int32], C.c_int),
     "nnj_numeric_status": ([_vp, C.POINTER(C.c_int32), _vp], C.c_int),
     "nnj_step": ([_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int32, C.c_int32, C.c_int32, _vp, C.c_size_t,

@@ -18,6 +18,7 @@
 #include "nnj_scorer.hpp"
 #include "nnj_scorer16.hpp"
 #include "nnj_scorer_wide.hpp"
+#include "nnj_likelihood.hpp"
 
 namespace {
 
@@ -1165,6 +1166,231 @@ int nnj_topology_hash(nnj_handle* h, const int32_t* merges, int32_t B, int32_t T
   return NNJ_OK;
 }
 
+}  // extern "C"
+
+// ---------------------------------------------------------------------------- tree likelihood (nnj_likelihood.hpp)
+namespace {
+
+// regularised lower incomplete gamma P(a, x): series / continued fraction (Numerical Recipes 6.2 forms)
+double gammp(double a, double x) {
+  if (x <= 0.0) return 0.0;
+  const double gln = lgamma(a);
+  if (x < a + 1.0) {
+    double ap = a, sum = 1.0 / a, del = sum;
+    for (int n = 0; n < 1000; ++n) { ap += 1.0; del *= x / ap; sum += del; if (fabs(del) < fabs(sum) * 1e-16) break; }
+    return sum * exp(-x + a * log(x) - gln);
+  }
+  double b = x + 1.0 - a, c = 1.0 / 1e-300, d = 1.0 / b, hh = d;
+  for (int i = 1; i < 1000; ++i) {
+    const double an = -i * (i - a);
+    b += 2.0;
+    d = an * d + b; if (fabs(d) < 1e-300) d = 1e-300;
+    c = b + an / c; if (fabs(c) < 1e-300) c = 1e-300;
+    d = 1.0 / d;
+    const double del = d * c;
+    hh *= del;
+    if (fabs(del - 1.0) < 1e-16) break;
+  }
+  return 1.0 - exp(-x + a * log(x) - gln) * hh;
+}
+// mean rate of each of ncat equiprobable categories of Gamma(alpha, alpha) (Yang 1994)
+void gamma_rates(double alpha, int ncat, double* rates) {
+  if (!(alpha > 0.0) || ncat <= 1) { for (int i = 0; i < ncat; ++i) rates[i] = 1.0; return; }
+  std::vector<double> cut(ncat + 1, 0.0);
+  for (int i = 1; i < ncat; ++i) {                         // quantile by bisection on P(alpha, alpha x) = i / ncat
+    const double p = (double)i / ncat;
+    double lo = 0.0, hi = 1.0;
+    while (gammp(alpha, alpha * hi) < p) hi *= 2.0;
+    for (int it = 0; it < 200; ++it) { const double mid = 0.5 * (lo + hi); (gammp(alpha, alpha * mid) < p ? lo : hi) = mid; }
+    cut[i] = 0.5 * (lo + hi);
+  }
+  double prev = 0.0;
+  for (int i = 0; i < ncat; ++i) {
+    const double cur = i + 1 < ncat ? gammp(alpha + 1.0, alpha * cut[i + 1]) : 1.0;
+    rates[i] = (cur - prev) * ncat;
+    prev = cur;
+  }
+}
+// eigen system of the GTR rate matrix: Q_ij = r_ij pi_j, normalised to one expected substitution per unit time;
+// B = Pi^1/2 Q Pi^-1/2 is symmetric: cyclic Jacobi, then U = Pi^-1/2 V, Uinv = V^T Pi^1/2
+int build_model(const nnj_subst_model* m, LikModel& md, char* err) {
+  static const int pair[4][4] = {{-1, 0, 1, 2}, {0, -1, 3, 4}, {1, 3, -1, 5}, {2, 4, 5, -1}};   // AC AG AT CG CT GT
+  if (m->ncat < 1 || m->ncat > LIK_MAXCAT) { snprintf(err, 512, "substitution model: ncat must be 1..%d", LIK_MAXCAT); return NNJ_ERR_ARG; }
+  if (!(m->pinv >= 0.0 && m->pinv < 1.0)) { snprintf(err, 512, "substitution model: pinv must be in [0, 1)"); return NNJ_ERR_ARG; }
+  double pi[4], fs = 0.0;
+  for (int i = 0; i < 4; ++i) { if (!(m->freqs[i] > 0.0)) { snprintf(err, 512, "substitution model: base frequencies must be positive"); return NNJ_ERR_ARG; } fs += m->freqs[i]; }
+  for (int i = 0; i < 4; ++i) pi[i] = m->freqs[i] / fs;
+  for (int i = 0; i < 6; ++i) if (!(m->rates[i] > 0.0)) { snprintf(err, 512, "substitution model: exchange rates must be positive"); return NNJ_ERR_ARG; }
+  double Q[4][4], mu = 0.0;
+  for (int i = 0; i < 4; ++i) {
+    double row = 0.0;
+    for (int j = 0; j < 4; ++j) if (i != j) { Q[i][j] = m->rates[pair[i][j]] * pi[j]; row += Q[i][j]; }
+    Q[i][i] = -row;
+    mu += pi[i] * row;
+  }
+  double A[4][4], V[4][4];
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 4; ++j) { A[i][j] = sqrt(pi[i]) * Q[i][j] / mu / sqrt(pi[j]); V[i][j] = i == j ? 1.0 : 0.0; }
+  for (int i = 0; i < 4; ++i) for (int j = i + 1; j < 4; ++j) { const double sm = 0.5 * (A[i][j] + A[j][i]); A[i][j] = A[j][i] = sm; }
+  for (int sweep = 0; sweep < 100; ++sweep) {
+    double off = 0.0;
+    for (int p = 0; p < 4; ++p) for (int q = p + 1; q < 4; ++q) off += A[p][q] * A[p][q];
+    if (off < 1e-32) break;
+    for (int p = 0; p < 4; ++p)
+      for (int q = p + 1; q < 4; ++q) {
+        if (fabs(A[p][q]) < 1e-300) continue;
+        const double theta = (A[q][q] - A[p][p]) / (2.0 * A[p][q]);
+        const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+        const double c = 1.0 / sqrt(t * t + 1.0), sn = t * c;
+        for (int k = 0; k < 4; ++k) { const double akp = A[k][p], akq = A[k][q]; A[k][p] = c * akp - sn * akq; A[k][q] = sn * akp + c * akq; }
+        for (int k = 0; k < 4; ++k) { const double apk = A[p][k], aqk = A[q][k]; A[p][k] = c * apk - sn * aqk; A[q][k] = sn * apk + c * aqk; }
+        for (int k = 0; k < 4; ++k) { const double vkp = V[k][p], vkq = V[k][q]; V[k][p] = c * vkp - sn * vkq; V[k][q] = sn * vkp + c * vkq; }
+      }
+  }
+  for (int k = 0; k < 4; ++k) md.lam[k] = A[k][k];
+  for (int i = 0; i < 4; ++i)
+    for (int k = 0; k < 4; ++k) { md.U[i * 4 + k] = V[i][k] / sqrt(pi[i]); md.Uinv[k * 4 + i] = V[i][k] * sqrt(pi[i]); }
+  for (int i = 0; i < 4; ++i) md.freqs[i] = pi[i];
+  md.ncat = m->ncat; md.pinv = m->pinv;
+  for (int i = 0; i < LIK_MAXCAT; ++i) md.rates[i] = 1.0;
+  gamma_rates(m->alpha, m->ncat, md.rates);
+  return NNJ_OK;
+}
+
+struct LikWs { size_t prog, brlen, brlen_new, brlen_try, pmat, inv, down, outer, site, ll, ll_try, step, end; };   // in doubles
+LikWs lik_ws(int B, int nA, int T, int L, int nc) {
+  LikWs w; size_t o = 0;
+  auto take = [&](size_t n) { size_t r = o; o += align_up(n, 32); return r; };
+  const size_t NN = 2 * (size_t)T - 2;
+  w.prog = take(((size_t)B * (T - 1) * 2 + 1) / 2);
+  w.brlen = take(B * NN); w.brlen_new = take(B * NN); w.brlen_try = take(B * NN);
+  w.pmat = take(B * NN * nc * 16);
+  w.inv = take((size_t)nA * L);
+  w.down = take((size_t)B * (T - 1) * nc * 4 * L);
+  w.outer = take(B * NN * nc * 4 * L);
+  w.site = take((size_t)B * L);
+  w.ll = take(B); w.ll_try = take(B); w.step = take(B);
+  w.end = o;
+  return w;
+}
+
+// accept a tried sweep per tree: ll_try >= ll -> take it (step = 0: done); else halve the step
+__global__ void k_lik_accept(double* __restrict__ ll, const double* __restrict__ ll_try, double* __restrict__ step,
+                             double* __restrict__ brlen, const double* __restrict__ brlen_try, int B, int NN) {
+  const int b = blockIdx.x;
+  const bool active = step[b] > 0.0;
+  const bool better = active && ll_try[b] >= ll[b];
+  __syncthreads();
+  if (better) for (int i = threadIdx.x; i < NN; i += blockDim.x) brlen[(size_t)b * NN + i] = brlen_try[(size_t)b * NN + i];
+  if (threadIdx.x == 0 && active) {
+    if (better) { ll[b] = ll_try[b]; step[b] = 0.0; } else step[b] *= 0.5;
+  }
+}
+__global__ void k_fill(double* __restrict__ p, double v, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+
+int lik_eval(nnj_handle* h, const uint8_t* codes, int nA, const LikModel& md, const LikWs& w, double* base,
+             const double* brlen, double* ll_out, int B, int T, int L, hipStream_t st) {
+  const int NN = 2 * T - 2, nc = md.ncat;
+  const int total = B * NN * nc;
+  hipLaunchKernelGGL(k_lik_pmats, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, brlen, md, base + w.pmat, total);
+  hipLaunchKernelGGL(k_lik_down, dim3((unsigned)((L + 127) / 128), (unsigned)B), dim3(128), 0, st, codes, nA,
+                     (const double*)(base + w.inv), reinterpret_cast<const int*>(base + w.prog), (const double*)(base + w.pmat),
+                     md, base + w.down, base + w.site, T, L);
+  hipLaunchKernelGGL(k_lik_sum_sites, dim3((unsigned)B), dim3(256), 0, st, (const double*)(base + w.site), ll_out, L);
+  return NNJ_OK;
+}
+
+int lik_common(nnj_handle* h, const uint8_t* codes, int nA, const uint8_t* mask, const int32_t* merges, const float* brlen_in,
+               const nnj_subst_model* model, int B, int T, int L, void* ws, size_t ws_bytes, LikModel& md, LikWs& w,
+               double*& base, hipStream_t st) {
+  if (!h) return fail(nullptr, NNJ_ERR_ARG, "null handle");
+  HIPCHK(h, hipSetDevice(h->cfg.device));
+  if (!codes || !merges || !model || B <= 0 || T < 2 || T > 256 || L <= 0 || (nA != 1 && nA != B))
+    return fail(h, NNJ_ERR_ARG, "tree likelihood: bad argument (2 <= T <= 256, n_align = 1 or B)");
+  if (int rc = build_model(model, md, h->err)) return rc;
+  w = lik_ws(B, nA, T, L, md.ncat);
+  if (!ws || ws_bytes < w.end * sizeof(double) || (uintptr_t)ws % 256)
+    return fail(h, NNJ_ERR_WORKSPACE, "tree likelihood: workspace too small or misaligned (%zu bytes needed)", w.end * sizeof(double));
+  h->sess.valid = false;
+  base = static_cast<double*>(ws);
+  int* prog = reinterpret_cast<int*>(base + w.prog);
+  hipLaunchKernelGGL(k_lik_program, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, st, merges, prog, B, T);
+  const int ne = B * (T - 1) * 2;
+  hipLaunchKernelGGL(k_lik_brlen_init, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, st, (const int*)prog, brlen_in, 0.1,
+                     base + w.brlen, B, T);
+  hipLaunchKernelGGL(k_lik_invariant, dim3((unsigned)((nA * L + 255) / 256)), dim3(256), 0, st, codes, mask, md, base + w.inv,
+                     nA, T, L);
+  return NNJ_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int nnj_lik_workspace_bytes(int32_t B, int32_t n_align, int32_t T, int32_t L, int32_t ncat, size_t* bytes) {
+  if (!bytes || B <= 0 || T < 2 || L <= 0 || ncat < 1 || ncat > LIK_MAXCAT) return NNJ_ERR_ARG;
+  *bytes = lik_ws(B, n_align, T, L, ncat).end * sizeof(double);
+  return NNJ_OK;
+}
+
+int nnj_tree_loglik(nnj_handle* h, const uint8_t* codes, int32_t n_align, const uint8_t* mask, const int32_t* merges,
+                    const float* brlen, const nnj_subst_model* model, int32_t B, int32_t T, int32_t L, double* loglik_out,
+                    void* ws, size_t ws_bytes, void* stream) {
+  LikModel md; LikWs w; double* base = nullptr;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (!loglik_out) return fail(h, NNJ_ERR_ARG, "nnj_tree_loglik: null output");
+  if (int rc = lik_common(h, codes, n_align, mask, merges, brlen, model, B, T, L, ws, ws_bytes, md, w, base, st)) return rc;
+  lik_eval(h, codes, n_align, md, w, base, base + w.brlen, loglik_out, B, T, L, st);
+  HIPCHK(h, hipGetLastError());
+  return NNJ_OK;
+}
+
+int nnj_tree_optimize(nnj_handle* h, const uint8_t* codes, int32_t n_align, const uint8_t* mask, const int32_t* merges,
+                      const float* brlen_in, const nnj_subst_model* model, int32_t sweeps, int32_t B, int32_t T, int32_t L,
+                      float* brlen_out, double* loglik_out, void* ws, size_t ws_bytes, void* stream) {
+  LikModel md; LikWs w; double* base = nullptr;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (!loglik_out || sweeps < 0) return fail(h, NNJ_ERR_ARG, "nnj_tree_optimize: bad argument");
+  if (int rc = lik_common(h, codes, n_align, mask, merges, brlen_in, model, B, T, L, ws, ws_bytes, md, w, base, st)) return rc;
+  const int NN = 2 * T - 2;
+  const int* prog = reinterpret_cast<const int*>(base + w.prog);
+  lik_eval(h, codes, n_align, md, w, base, base + w.brlen, base + w.ll, B, T, L, st);
+  for (int sw = 0; sw < sweeps; ++sw) {
+    // partials on both sides of every edge from the current lengths (pmat and down are current), then one
+    // Newton-Raphson solve per edge, all edges at once
+    hipLaunchKernelGGL(k_lik_outer, dim3((unsigned)((L + 127) / 128), (unsigned)B), dim3(128), 0, st, codes, n_align, prog,
+                       (const double*)(base + w.pmat), md, (const double*)(base + w.down), base + w.outer, T, L);
+    hipLaunchKernelGGL(k_lik_newton, dim3((unsigned)NN, (unsigned)B), dim3(256), 0, st, codes, n_align,
+                       (const double*)(base + w.inv), (const double*)(base + w.down), (const double*)(base + w.outer), md,
+                       (const double*)(base + w.brlen), base + w.brlen_new, T, L, 12);
+    // a simultaneous update of all edges can overshoot: take the full step if the likelihood does not drop, else
+    // half of it, a quarter, an eighth (per tree, decided on the device)
+    hipLaunchKernelGGL(k_fill, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, st, base + w.step, 1.0, B);
+    for (int tr = 0; tr < 4; ++tr) {
+      hipLaunchKernelGGL(k_lik_blend, dim3((unsigned)((B * NN + 255) / 256)), dim3(256), 0, st, (const double*)(base + w.brlen),
+                         (const double*)(base + w.brlen_new), (const double*)(base + w.step), base + w.brlen_try, B, NN);
+      lik_eval(h, codes, n_align, md, w, base, base + w.brlen_try, base + w.ll_try, B, T, L, st);
+      hipLaunchKernelGGL(k_lik_accept, dim3((unsigned)B), dim3(64), 0, st, base + w.ll, (const double*)(base + w.ll_try),
+                         base + w.step, base + w.brlen, (const double*)(base + w.brlen_try), B, NN);
+    }
+    lik_eval(h, codes, n_align, md, w, base, base + w.brlen, base + w.ll, B, T, L, st);   // pmat / down of the accepted lengths
+  }
+  HIPCHK(h, hipMemcpyAsync(loglik_out, base + w.ll, (size_t)B * sizeof(double), hipMemcpyDeviceToDevice, st));
+  if (brlen_out) {
+    const int ne = B * (T - 1) * 2;
+    hipLaunchKernelGGL(k_lik_brlen_export, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, st, prog,
+                       (const double*)(base + w.brlen), brlen_out, B, T);
+  }
+  HIPCHK(h, hipGetLastError());
+  return NNJ_OK;
+}
+
+}  // extern "C"
+
+extern "C" {
 int nnj_debug_encoder_stop(nnj_handle* h, int32_t stage) {
   if (!h) return NNJ_ERR_ARG;
   h->debug_stop = stage;

@@ -121,16 +121,19 @@ class PhyInferEnv:
         self.init_state_tensor = seq_arrays
         self.state_tensor = None
 
-    def _merge_host(self, b, i, j):
-        """Tree half of one merge for batch element b; returns True when the tree is complete."""
+    def _merge_host(self, b, i, j, lengths=None, log_score=None):
+        """Tree half of one merge for batch element b; returns True when the tree is complete.
+        lengths: (edge to row i, edge to row j) from the GPU branch-length optimiser, or None (dummy lengths)."""
         st = self.states[b]
         unrooted = st.num_trees == 2
-        new_tree = PhyloTree(unrooted, {"tree": st.subtrees[i], "branch_length": None},
-                             {"tree": st.subtrees[j], "branch_length": None})
+        li, lj = (None, None) if lengths is None else (float(lengths[0]), float(lengths[1]))
+        new_tree = PhyloTree(unrooted, {"tree": st.subtrees[i], "branch_length": li},
+                             {"tree": st.subtrees[j], "branch_length": lj})
         if unrooted:
-            # optimize_branch_length_no_br (reference environment.py:674-686): dummy lengths, sentinel score
+            # optimize_branch_length_no_br (reference environment.py:674-686): dummy lengths, sentinel score -- or the
+            # lengths and log-likelihood of the GPU optimiser (the reference's optimize_branch_length_* :625-672)
             keys = self.seq_keys[b]
-            new_tree.log_score = NO_SCORE
+            new_tree.log_score = NO_SCORE if log_score is None else float(log_score)
             ut = UnrootedPhyloTree(new_tree)
             ut.utree_op_str = format_rtree(new_tree, True, None, keys)
             ut.rtree_op_tuple = ut.utree_op_tuple = _newick_tuple(new_tree, keys)
@@ -171,12 +174,14 @@ class PhyInferEnv:
             self.state_tensor = torch.gather(cat, 1, base[:, :, None, None].expand(-1, -1, cat.size(2), cat.size(3)))
         return done
 
-    def apply_merges(self, merges):
-        """Fast path: replay a device-produced merge list [B,T-1,2] on the host trees."""
+    def apply_merges(self, merges, brlen=None, log_scores=None):
+        """Fast path: replay a device-produced merge list [B,T-1,2] on the host trees; brlen [B,T-1,2] and
+        log_scores [B] (neuralnj_amd.likelihood.tree_optimize) give the trees real branch lengths and scores."""
         merges = np.asarray(merges)
         for b in range(merges.shape[0]):
-            for (i, j) in merges[b]:
-                self._merge_host(b, int(i), int(j))
+            for s, (i, j) in enumerate(merges[b]):
+                self._merge_host(b, int(i), int(j), None if brlen is None else brlen[b][s],
+                                 None if log_scores is None else log_scores[b])
 
     def evaluate_loglikelihood(self, get_all_tree=False):
         scores = [s.log_score for s in self.states]

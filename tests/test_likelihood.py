@@ -1,0 +1,127 @@
+"""Tree likelihood.  Parity with the reference is UNPINNED (raxml-ng / libpll are not in the mount and the
+reference's tests at that boundary print without asserting), so these are known-answer tests: closed forms, a
+brute-force sum over internal states, invariances of the likelihood, and the HIP kernels against the independent
+numpy/scipy evaluation of oracle/lik_oracle.py."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import lik_oracle as LO  # noqa: E402
+
+GTR = dict(rates=[1.3, 4.1, 0.7, 1.1, 5.2, 1.0], freqs=[0.31, 0.19, 0.23, 0.27], alpha=0.6, pinv=0.15, ncat=4)
+JC = dict(rates=[1] * 6, freqs=[0.25] * 4, alpha=0.0, pinv=0.0, ncat=1)
+
+
+def _random_tree(T, rng):
+    merges, n = [], T
+    while n > 1:
+        i, j = sorted(rng.choice(n, 2, replace=False))
+        merges.append((int(i), int(j)))
+        n -= 1
+    return np.array(merges, np.int32)
+
+
+def test_oracle_two_taxa_jc69_closed_form():
+    t = 0.37
+    codes = np.array([[0, 1, 2, 3, 0, 2], [0, 1, 3, 3, 1, 2]], np.uint8)
+    same, diff = 0.25 * (0.25 + 0.75 * np.exp(-4 * t / 3)), 0.25 * (0.25 - 0.25 * np.exp(-4 * t / 3))
+    want = 4 * np.log(same) + 2 * np.log(diff)
+    got = LO.tree_loglik(codes, np.array([[0, 1]]), np.array([[0.3 * t, 0.7 * t]]), JC)
+    assert abs(got - want) < 1e-12
+
+
+def test_oracle_pruning_equals_brute_force_and_gamma_rates():
+    rng = np.random.default_rng(1)
+    r = LO.gamma_rates(0.6, 4)
+    assert abs(r.mean() - 1.0) < 1e-12 and (np.diff(r) > 0).all()
+    # Yang (1994) table: alpha = 0.5, four categories, mean rates
+    np.testing.assert_allclose(LO.gamma_rates(0.5, 4), [0.03338775, 0.25191592, 0.82026848, 2.89442785], rtol=1e-6)
+    codes = rng.integers(0, 5, size=(4, 7)).astype(np.uint8)
+    merges = np.array([[1, 3], [0, 2], [0, 1]], np.int32)
+    br = rng.uniform(0.02, 0.6, size=(3, 2))
+    a = LO.tree_loglik(codes, merges, br, GTR)
+    b = LO.brute_force_loglik(codes, merges, br, GTR)
+    assert abs(a - b) < 1e-10
+    # pulley principle: only the SUM of the two root edges matters (time-reversible model)
+    br2 = br.copy()
+    br2[2] = [br[2].sum() * 0.9, br[2].sum() * 0.1]
+    assert abs(LO.tree_loglik(codes, merges, br2, GTR) - a) < 1e-10
+
+
+@pytest.mark.gpu
+def test_hip_loglik_matches_numpy_oracle():
+    import torch
+    from neuralnj_amd import likelihood as lk, utils
+    from neuralnj_amd._lib import Nnj
+    rng = np.random.default_rng(7)
+    g = Nnj(utils.shipped_config(), "cuda:0")
+    for (T, L, model) in ((2, 6, JC), (5, 40, GTR), (12, 65, GTR), (9, 33, dict(GTR, pinv=0.0, alpha=0.0, ncat=1)),
+                          (70, 20, dict(GTR, ncat=6))):
+        B = 3
+        codes = rng.integers(0, 5, size=(B, T, L)).astype(np.uint8)
+        codes[:, :, :4] = codes[:, :1, :4]                     # a few constant columns (the +I component)
+        mask = np.zeros((B, L), bool)
+        mask[:, -3:] = True
+        merges = np.stack([_random_tree(T, rng) for _ in range(B)])
+        br = rng.uniform(0.01, 0.5, size=(B, T - 1, 2)).astype(np.float32)
+        got = lk.tree_loglik(g, codes, merges, br, lk.subst_model(**model), mask=mask).cpu().numpy()
+        want = [LO.tree_loglik(codes[b], merges[b], br[b].astype(np.float64), model, mask[b]) for b in range(B)]
+        np.testing.assert_allclose(got, want, rtol=1e-10, atol=1e-9)
+        # n_align = 1: B trees over ONE alignment
+        got1 = lk.tree_loglik(g, codes[:1], merges, br, lk.subst_model(**model), mask=mask[:1]).cpu().numpy()
+        want1 = [LO.tree_loglik(codes[0], merges[b], br[b].astype(np.float64), model, mask[0]) for b in range(B)]
+        np.testing.assert_allclose(got1, want1, rtol=1e-10, atol=1e-9)
+    g.close()
+
+
+@pytest.mark.gpu
+def test_hip_branch_length_optimisation():
+    """Data simulated down a known tree: the optimiser must (1) never lower the likelihood, (2) reach the value a
+    generic scipy optimiser finds for the same tree, (3) recover branch lengths near the simulated ones, and
+    (4) rank the true topology above a random one."""
+    import torch
+    from scipy.optimize import minimize
+    from neuralnj_amd import likelihood as lk, utils
+    from neuralnj_amd._lib import Nnj
+    rng = np.random.default_rng(11)
+    T, L = 6, 3000
+    merges = np.array([[0, 1], [1, 2], [0, 1], [1, 2], [0, 1]], np.int32)      # ((0,1),((2,3),(4,5)))-like
+    true_br = rng.uniform(0.05, 0.3, size=(T - 1, 2))
+    Q, pi = LO.rate_matrix(JC["rates"], JC["freqs"])
+    from scipy.linalg import expm
+    prog = LO.program(merges, T)
+    seq = {2 * T - 2: rng.choice(4, size=L, p=pi)}
+    for s in range(T - 2, -1, -1):
+        for side, v in enumerate(prog[s]):
+            P = expm(Q * true_br[s][side])
+            cum = P[seq[T + s]].cumsum(1)
+            seq[v] = (rng.random(L)[:, None] > cum).sum(1).clip(0, 3)
+    codes = np.stack([seq[i] for i in range(T)]).astype(np.uint8)[None]
+    g = Nnj(utils.shipped_config(), "cuda:0")
+    m = lk.subst_model(**JC)
+    start = np.full((1, T - 1, 2), 0.1, np.float32)
+    ll0 = lk.tree_loglik(g, codes, merges[None], start, m).item()
+    lls = [ll0]
+    for sw in (1, 2, 3, 6):
+        ll, br = lk.tree_optimize(g, codes, merges[None], start, m, sweeps=sw)
+        lls.append(ll.item())
+    assert all(b >= a - 1e-9 for a, b in zip(lls, lls[1:])), lls
+    br = br.cpu().numpy()[0].astype(np.float64)
+    assert abs(lk.tree_loglik(g, codes, merges[None], br[None].astype(np.float32), m).item() - lls[-1]) < 1e-6 * abs(lls[-1])
+
+    def neg(x):
+        b = np.abs(x).reshape(T - 1, 2)
+        return -LO.tree_loglik(codes[0], merges, b, JC)
+    ref = minimize(neg, np.full(2 * (T - 1), 0.1), method="L-BFGS-B", bounds=[(1e-6, 5)] * (2 * (T - 1)))
+    assert lls[-1] >= -ref.fun - 0.05, (lls[-1], -ref.fun)          # as good as a generic optimiser (log units)
+    est, tru = br.copy(), true_br.copy()
+    est[-1], tru[-1] = est[-1].sum(), tru[-1].sum()                 # the root's two edges are one edge
+    assert np.abs(est - tru).max() < 0.06
+    wrong = np.array([[0, 4], [0, 2], [1, 2], [0, 2], [0, 1]], np.int32)
+    llw, _ = lk.tree_optimize(g, codes, wrong[None], None, m, sweeps=3)
+    assert lls[-1] > llw.item() + 10
+    g.close()
