@@ -17,6 +17,7 @@ reps = int(sys.argv[4]) if len(sys.argv) > 4 else 1
 cfgs = utils.shipped_config()
 g = Nnj(cfgs, "cuda:0")
 g.load_weights(weights.pack(cfgs, weights.seeded_state(cfgs, 0, "sharp")))
+g.set_concurrency(1)      # whole-batch launches on one stream: per-launch byte counts belong to one launch of B alignments
 codes = torch.from_numpy(synth.synth_codes(B, T, L, seed=1, gap_frac=0.2)).cuda()
 for _ in range(reps):
     r = g.rollout_argmax(codes, None)

@@ -47,7 +47,10 @@ if len(sys.argv) > 4:
         e = per.setdefault(kind, dict(hbm=0.0, launches=0))
         e["hbm"] += v["hbm_bytes_per_launch"] * v["launches"]
         e["launches"] += v["launches"]
-    out = dict(source=f"{sys.argv[3]} ({note})",
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from neuralnj_amd import build as nbuild
+    out = dict(source=f"{sys.argv[3]} ({note})", source_hash=nbuild.source_hash(),
                per_kind={k: dict(hbm_bytes_per_launch=e["hbm"] / e["launches"], launches=e["launches"])
                          for k, e in per.items()})
     json.dump(out, open(sys.argv[4], "w"), indent=1)
