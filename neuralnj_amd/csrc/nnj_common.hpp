@@ -266,15 +266,15 @@ __device__ __forceinline__ void split8(Frag3& o, const f32x16& x) {
     o.h[p] = h; o.m[p] = m;
   }
 }
-__device__ __forceinline__ f32x16 mfma_bf16(u32x4 a, u32x4 b, f32x16 c) {
+__device__ __forceinline__ f32x16 mfma_f16(u32x4 a, u32x4 b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c,
                                                  0, 0, 0);
 }
-// c += A*B from the six leading piece products, smallest first
+// c += A*B from the three leading piece products (m.h, h.m, h.h), smallest first
 __device__ __forceinline__ f32x16 mfma_b6(const Frag3& a, const Frag3& b, f32x16 c) {
-  c = mfma_bf16(a.m, b.h, c);
-  c = mfma_bf16(a.h, b.m, c);
-  c = mfma_bf16(a.h, b.h, c);
+  c = mfma_f16(a.m, b.h, c);
+  c = mfma_f16(a.h, b.m, c);
+  c = mfma_f16(a.h, b.h, c);
   return c;
 }
 
@@ -468,14 +468,14 @@ __device__ __forceinline__ void linear6_T_acc(f32x16 (&out)[NT][MT], const f32x1
 // k-slot 8*kq + 4*u + r = feature 32*ks + 16*u + 4*kq + r; weight images store their columns in that order.
 struct V64 { f32x4 t[4]; };
 
-__device__ __forceinline__ f32x4 mfma16_bf16(u32x4 a, u32x4 b, f32x4 c) {
+__device__ __forceinline__ f32x4 mfma16_f16(u32x4 a, u32x4 b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0,
                                                  0);
 }
 __device__ __forceinline__ f32x4 mfma16_b6(const Frag3& a, const Frag3& b, f32x4 c) {
-  c = mfma16_bf16(a.m, b.h, c);
-  c = mfma16_bf16(a.h, b.m, c);
-  c = mfma16_bf16(a.h, b.h, c);
+  c = mfma16_f16(a.m, b.h, c);
+  c = mfma16_f16(a.h, b.m, c);
+  c = mfma16_f16(a.h, b.h, c);
   return c;
 }
 // eight values -> one k-step fragment (k-slot order: a[0..3], b[0..3])

@@ -601,3 +601,26 @@ def test_search_round_samples_scores_and_ranks():
     assert len({utils.rf_distance(t[0], best)[0] for t in trees}) > 1          # really different topologies
     _, ll_more, _ = search_rollouts(batch, agent, PhyInferEnv(cfgs, "cuda:0"), 256, seed=1, temperature=6.0)
     assert ll_more >= best_ll - 1e-6                    # the first 64 uniforms are a prefix of the 256
+
+
+def test_small_magnitude_weights(ctx_cache):
+    """the f16x3 operand split keeps 22 significand bits only while the low piece of an operand stays a
+    NORMAL fp16 number; weights of magnitude 1e-3..1e-2 push it into the fp16 denormal range.  Every weight matrix of
+    the reference-scale ("plain") initialisation is scaled by 0.05 here (weights of 6e-3 and below): the score
+    tables must still hold the 1e-4 tolerance against the oracle, and the trees must be the oracle's."""
+    cfgs = utils.shipped_config()
+    st = weights.seeded_state(cfgs, 31, "plain")
+    st = {k: (v * np.float32(0.05) if v.ndim == 2 else v) for k, v in st.items()}
+    packed = weights.pack(cfgs, st)
+    g = ctx_cache(cfgs, packed)
+    o = _oracle(cfgs, packed)
+    for (B, T, L, seed) in ((2, 12, 96, 1), (1, 40, 256, 2), (1, 80, 64, 3)):
+        codes = synth.synth_codes_tree(B, T, L, seed)
+        r = g.rollout_argmax(torch.from_numpy(codes), None, want_trace=True, want_state=True)
+        merges = r["merges"].cpu().numpy()
+        ref = o.rollout_argmax(onehot_f32(codes), None, forced_merges=merges, want_state=True)
+        np.testing.assert_allclose(r["state"].cpu().numpy(), ref["state"], atol=RTOL * np.abs(ref["state"]).max())
+        assert_logits_close(r["logits"].cpu().numpy(), ref["logits"], RTOL, f"small weights {B}x{T}x{L}")
+        scale = np.abs(ref["logits"]).max()
+        decisive = ref["top2_gap"] > 4 * RTOL * max(scale, 1.0)
+        assert (ref["merges"][decisive] == merges[decisive]).all()
