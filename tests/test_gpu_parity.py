@@ -290,10 +290,12 @@ def test_mask_none_equals_all_false(ctx_cache):
     assert torch.equal(a["logits"], b["logits"]) and torch.equal(a["merges"], b["merges"])
 
 
-def test_fused_step_reproduces_the_rollout(ctx_cache):
+@pytest.mark.parametrize("name", ["synth_b2_t8_l128_s1", "synth_b2_t70_l64_s12"])
+def test_fused_step_reproduces_the_rollout(name, ctx_cache):
     """nnj_step (merge + new scores + table + argmax in one call) iterated from the encoder output gives the
-    tables and merges of nnj_rollout_argmax bit for bit -- both run the same kernels in the same order."""
-    z, cfgs, packed = load_golden("synth_b2_t8_l128_s1")
+    tables and merges of nnj_rollout_argmax bit for bit -- both run the same kernels in the same order (70 rows:
+    through the star kernels above 64 live rows, then the 64-row kernels)."""
+    z, cfgs, packed = load_golden(name)
     g = ctx_cache(cfgs, packed)
     codes, mask = torch.from_numpy(z["codes"]), torch.from_numpy(z["mask"])
     B, T, L = z["codes"].shape
