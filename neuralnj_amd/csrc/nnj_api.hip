@@ -411,7 +411,7 @@ int launch_encoder(nnj_handle* h, const uint8_t* codes, const float* onehot, con
       // NT waves per column (32 rows each), 8 / NT columns in flight per workgroup; persistent
       constexpr int NSLOT = 8 / NT;
       const unsigned grid1 = (unsigned)std::min<long>((long)(((size_t)B * C + NSLOT - 1) / NSLOT), (long)h->num_cu);
-      const size_t lds = (size_t)(5 * 4096 + NSLOT * (32 * NT * 36 + 32 * NT * 32) + 16) * sizeof(float);
+      const size_t lds = (size_t)(5 * 4096 + NSLOT * (32 * NT * 32 + 32 * NT * 32) + 16) * sizeof(float);
       if (int rc = set_lds(h, k_tok1p<NT>, lds)) return rc;
       hipLaunchKernelGGL(k_tok1p<NT>, dim3(grid1), dim3(512), lds, st, ctx, mask, x, attn_ptrs(h, h->lo[l].row),
                          attn_ptrs(h, h->lo[l].col), B, T, C, d.Epad, dbg, h->d_flag);

@@ -113,13 +113,19 @@ __global__ __launch_bounds__(512) void k_tok1p(const float* __restrict__ ctx, co
   // (NWC = 1: every wave owns a column, no barrier at all.)
   constexpr int NSLOT = 8 / NWC;                        // columns in flight per workgroup
   constexpr int KR = 32 * NWC;                          // rows (= keys) of the column images
-  constexpr int SLOTF = KR * 36 + KR * 32;              // floats of a slot: K image [KR][36] + V^T image
+  constexpr int SLOTF = KR * 32 + KR * 32;              // floats of a slot: K image (two fp16 planes) + V^T image
+  constexpr int KPL = KR * 64;                          // bytes of a K plane: [KR keys][4 heads x 2 halves][4 fp16]
   constexpr int VCH = 4 * NWC;                          // 16-byte chunks of a V^T image row (8 keys each)
   constexpr int VPL = 32 * KR * 2;                      // bytes of a V^T plane
   const int slot = wave / NWC, rt = wave % NWC;
-  float* kimg = smem + 20480 + slot * SLOTF;            // K image [KR][36]
+  // K image: two fp16 planes of [KR keys][8 chunks of 8 B]; chunk 2g + hh = the four k values d = 4hh..4hh+3 of
+  // head g -- the k-slots 8hh..8hh+3 of ONE 32x32x16 MFMA per (key tile, head, piece product); slots 8hh+4..8hh+7 are
+  // zero on both operands (the head dimension is 8).  Chunks are XOR-swizzled by (key >> 2) & 7: the ds_read_b64 of 32
+  // keys at one logical chunk is conflict free.  (QK^T used to be four v_mfma_f32_32x32x2_f32 of 64 cycles each per
+  // key tile and head: 4096 of the 11000 matrix-pipe cycles of a column; as three f16 piece products it is 1536.)
+  uint8_t* kimg = reinterpret_cast<uint8_t*>(smem + 20480 + slot * SLOTF);
   // V^T image: two fp16 planes of [32 (head, d)][KR keys], keys in fragment order (see the P.V loop)
-  uint8_t* vimg = reinterpret_cast<uint8_t*>(kimg + KR * 36);
+  uint8_t* vimg = kimg + 2 * KPL;
   int* cnt = reinterpret_cast<int*>(smem + 20480 + NSLOT * SLOTF) + slot;
   // f16x3 operand images (4 B per element: the same 16 KiB per matrix as an fp32 image)
   stage_weight_b6<64>(W0, wr.Wo, 64, tid, 512);
@@ -221,8 +227,14 @@ __global__ __launch_bounds__(512) void k_tok1p(const float* __restrict__ ctx, co
       if constexpr (NWC >= 2) pair_barrier<NWC>(cnt, epoch, status);  // the partners have finished reading the previous images
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const f32x4 k4 = {kh[4 * g], kh[4 * g + 1], kh[4 * g + 2], kh[4 * g + 3]};
-        *reinterpret_cast<f32x4*>(kimg + r * 36 + 8 * g + 4 * hh) = k4;
+        {
+          unsigned kh01, km01, kh23, km23;
+          split2(kh[4 * g], kh[4 * g + 1], kh01, km01);
+          split2(kh[4 * g + 2], kh[4 * g + 3], kh23, km23);
+          uint8_t* kd = kimg + r * 64 + 8 * ((2 * g + hh) ^ ((r >> 2) & 7));
+          *reinterpret_cast<uint2*>(kd) = make_uint2(kh01, kh23);
+          *reinterpret_cast<uint2*>(kd + KPL) = make_uint2(km01, km23);
+        }
         // vT registers 4g..4g+3: rows 32rt + 8g + 4hh + 0..3 of feature `tok`.  Key 32jt + 16u + 8v + 4hh + w sits at
         // position 32jt + 16u + 8hh + 4v + w of the image row: the 8 keys a lane multiplies in one k-step (16 keys)
         // are one 16-byte chunk, chunk index 4jt + 2u + hh, in the order the probability registers have
@@ -240,13 +252,25 @@ __global__ __launch_bounds__(512) void k_tok1p(const float* __restrict__ ctx, co
       for (int g = 0; g < 4; ++g) {
         // S^T[key j x query i]: A = K image rows (lane = key), B = this wave's q registers (lane = query)
         f32x16 sc_[NWC];
+        Frag3 qf;                                          // this lane's four q values of head g, scaled, as pieces
+        {
+          unsigned h01, m01, h23, m23;
+          split2(qh[4 * g] * qscale, qh[4 * g + 1] * qscale, h01, m01);
+          split2(qh[4 * g + 2] * qscale, qh[4 * g + 3] * qscale, h23, m23);
+          qf.h = (u32x4){h01, h23, 0u, 0u};
+          qf.m = (u32x4){m01, m23, 0u, 0u};
+        }
 #pragma unroll
         for (int jt = 0; jt < NWC; ++jt) {
-          const f32x4 ka = *reinterpret_cast<const f32x4*>(kimg + (32 * jt + tok) * 36 + 8 * g + 4 * hh);
+          const int kr = 32 * jt + tok;
+          const uint8_t* ks_ = kimg + kr * 64 + 8 * ((2 * g + hh) ^ ((kr >> 2) & 7));
+          const uint2 ah = *reinterpret_cast<const uint2*>(ks_), am = *reinterpret_cast<const uint2*>(ks_ + KPL);
+          Frag3 kf;
+          kf.h = (u32x4){ah.x, ah.y, 0u, 0u};
+          kf.m = (u32x4){am.x, am.y, 0u, 0u};
 #pragma unroll
           for (int k = 0; k < 16; ++k) sc_[jt][k] = 0.f;
-#pragma unroll
-          for (int t = 0; t < 4; ++t) sc_[jt] = mfma32(ka[t], qh[4 * g + t] * qscale, sc_[jt]);
+          sc_[jt] = mfma_b6(kf, qf, sc_[jt]);
         }
         // element k of tile jt is key j = 32*jt + (k&3) + 8*(k>>2) + 4*hh.  A padded column gets the same score
         // for every key (axial_attention.py:220-224: -10000 everywhere): its q is scaled by 0 instead, the
@@ -305,14 +329,26 @@ __global__ __launch_bounds__(512) void k_tok1p(const float* __restrict__ ctx, co
           f32x16 o;
 #pragma unroll
           for (int k = 0; k < 16; ++k) o[k] = 0.f;
+          Frag3 qf;
+          {
+            unsigned h01, m01, h23, m23;
+            split2(qh[4 * g] * qscale, qh[4 * g + 1] * qscale, h01, m01);
+            split2(qh[4 * g + 2] * qscale, qh[4 * g + 3] * qscale, h23, m23);
+            qf.h = (u32x4){h01, h23, 0u, 0u};
+            qf.m = (u32x4){m01, m23, 0u, 0u};
+          }
 #pragma unroll 1
           for (int jt = 0; jt < NWC; ++jt) {
-            const f32x4 ka = *reinterpret_cast<const f32x4*>(kimg + (32 * jt + tok) * 36 + 8 * g + 4 * hh);
+            const int kr = 32 * jt + tok;
+            const uint8_t* ks_ = kimg + kr * 64 + 8 * ((2 * g + hh) ^ ((kr >> 2) & 7));
+            const uint2 ah = *reinterpret_cast<const uint2*>(ks_), am = *reinterpret_cast<const uint2*>(ks_ + KPL);
+            Frag3 kf;
+            kf.h = (u32x4){ah.x, ah.y, 0u, 0u};
+            kf.m = (u32x4){am.x, am.y, 0u, 0u};
             f32x16 sc;
 #pragma unroll
             for (int k = 0; k < 16; ++k) sc[k] = 0.f;
-#pragma unroll
-            for (int t = 0; t < 4; ++t) sc = mfma32(ka[t], qh[4 * g + t] * qscale, sc);
+            sc = mfma_b6(kf, qf, sc);
             float mt = -INFINITY;
 #pragma unroll
             for (int k = 0; k < 16; ++k) {
