@@ -463,8 +463,8 @@ int launch_pair_scores_wide(nnj_handle* h, const RowSet& rs, const int* ij_prev,
   const WideGeom wg = wide_geom(n, B, C, full);
   const ScorerW sw = scorer_ptrs(h);
   const int* ijp = full ? nullptr : ij_prev;
-  const size_t lds_a = (size_t)(2 * IMG64 + 64 * wg.RP) * sizeof(float);
-  const size_t lds_s = (size_t)(3 * IMG64 + 64 * wg.RP) * sizeof(float);
+  const size_t lds_a = (size_t)(2 * IMG64 + 64 * wg.RP + SCORER_CONSTS) * sizeof(float);
+  const size_t lds_s = (size_t)(3 * IMG64 + 64 * wg.RP + SCORER_CONSTS) * sizeof(float);
   for (int m0 = 0; m0 < wg.M; m0 += wg.MB) {
     const int mc = std::min(wg.MB, wg.M - m0);
     const dim3 grid((unsigned)wg.nsc, (unsigned)mc, (unsigned)B);
@@ -524,7 +524,7 @@ int launch_pair_scores(nnj_handle* h, const RowSet& rs, const int* ij_prev, cons
     if (has_ctx) {
       {
         Scope sc(h, st, PK_PAIR_ALPHA_INCR);
-        const size_t lds = (size_t)(2 * IMG64 + T16_WAVES * 512 * NPL + 16) * sizeof(float);
+        const size_t lds = (size_t)(2 * IMG64 + T16_WAVES * 512 * NPL + 16 + SCORER_CONSTS) * sizeof(float);
 #define NNJ_IA(NG)                                                                                          \
   case NG:                                                                                                  \
     if (int rc = set_lds(h, k_inc_alpha16<NG>, lds)) return rc;                                             \
@@ -544,7 +544,7 @@ int launch_pair_scores(nnj_handle* h, const RowSet& rs, const int* ij_prev, cons
       if (n <= 16) {
         // 16-pair tiles: half the padding of the 32-pair kernels (measured 2x faster here); above 16 rows the
         // group barriers of the shared image cost more than the padding saves
-        const size_t lds = (size_t)(3 * IMG64 + T16_WAVES * 512 * NPL + 16) * sizeof(float);
+        const size_t lds = (size_t)(3 * IMG64 + T16_WAVES * 512 * NPL + 16 + SCORER_CONSTS) * sizeof(float);
         if (has_ctx) {
           if (int rc = set_lds(h, k_inc_score16<1, true>, lds)) return rc;
           hipLaunchKernelGGL((k_inc_score16<1, true>), grid, blk16, lds, st, rs, sw, ij_prev, base + w.alpha, mask,
@@ -555,17 +555,17 @@ int launch_pair_scores(nnj_handle* h, const RowSet& rs, const int* ij_prev, cons
                              base + w.score_part, n, C, g.cs);
         }
       } else if (n > 32 && n <= 48) {                      // three 16-row tiles: 48 instead of 64 padded pairs,
-        const size_t lds = (size_t)(3 * IMG64 + 8 * (64 * 48 * NPL / 2)) * sizeof(float);   // one wave per site
+        const size_t lds = (size_t)(3 * IMG64 + 8 * (64 * 48 * NPL / 2) + SCORER_CONSTS) * sizeof(float);   // one wave per site
         if (int rc = set_lds(h, k_inc_score_w<3, true>, lds)) return rc;
         hipLaunchKernelGGL((k_inc_score_w<3, true>), grid, dim3(512), lds, st, rs, sw, ij_prev, base + w.alpha, mask,
                            base + w.score_part, n, C, g.cs);
       } else if (n > 32) {
-        const size_t lds = (size_t)(3 * IMG64 + 4 * b6_floats(64, 64) + 16) * sizeof(float);
+        const size_t lds = (size_t)(3 * IMG64 + 4 * b6_floats(64, 64) + 16 + SCORER_CONSTS) * sizeof(float);
         if (int rc = set_lds(h, k_inc_score<2, true>, lds)) return rc;
         hipLaunchKernelGGL((k_inc_score<2, true>), grid, dim3(512), lds, st, rs, sw, ij_prev, base + w.alpha, mask,
                            base + w.score_part, n, C, g.cs, h->d_flag);
       } else {                                             // 17..32: the 32-pair kernel (k_inc_score_w<2> measured equal)
-        const size_t lds = (size_t)(3 * IMG64 + 8 * b6_floats(64, 32) + 16) * sizeof(float);
+        const size_t lds = (size_t)(3 * IMG64 + 8 * b6_floats(64, 32) + 16 + SCORER_CONSTS) * sizeof(float);
         if (int rc = set_lds(h, k_inc_score<1, true>, lds)) return rc;
         hipLaunchKernelGGL((k_inc_score<1, true>), grid, dim3(512), lds, st, rs, sw, ij_prev, base + w.alpha, mask,
                            base + w.score_part, n, C, g.cs, h->d_flag);
@@ -577,7 +577,7 @@ int launch_pair_scores(nnj_handle* h, const RowSet& rs, const int* ij_prev, cons
   if (has_ctx) {
     {
       Scope sc(h, st, PK_PAIR_ALPHA);
-      const size_t lds = 2 * (IMG64 + 8192) * sizeof(float);
+      const size_t lds = (2 * (IMG64 + 8192) + SCORER_CONSTS) * sizeof(float);
       if (int rc = set_lds(h, k_pair_alpha<1, 8>, lds)) return rc;
       hipLaunchKernelGGL((k_pair_alpha<1, 8>), grid, dim3(512), lds, st, rs, sw, ij_prev, base + w.alpha_part, mode, n, C,
                          g.npairs, g.ppad, g.cs, g.nsc, g.pg, B);
@@ -590,7 +590,7 @@ int launch_pair_scores(nnj_handle* h, const RowSet& rs, const int* ij_prev, cons
   }
   {
     Scope sc(h, st, PK_PAIR_SCORE);
-    const size_t lds = (size_t)(2 * IMG64 + 2 * (IMG64 + 8192)) * sizeof(float);
+    const size_t lds = (size_t)(2 * IMG64 + 2 * (IMG64 + 8192) + SCORER_CONSTS) * sizeof(float);
     if (int rc = set_lds(h, k_pair_score<1, 8>, lds)) return rc;
     hipLaunchKernelGGL((k_pair_score<1, 8>), grid, dim3(512), lds, st, rs, sw, ij_prev, base + w.alpha, mask,
                        base + w.score_part, mode, n, C, g.npairs, g.ppad, g.cs, has_ctx, g.nsc, g.pg, B);

@@ -515,15 +515,17 @@ __device__ __forceinline__ void stage_weight_t16(float* lds, const float* __rest
   }
 }
 // out (MT tiles of 16 rows) = bias + W*in or += W*in; W = a [16*MT][64] image of the layout above
-template <int MT, bool ACC>
+// BIAS is a compile-time switch: a run-time `if (bias)` puts every bias load into a basic block of its own and
+// serialises their latency.  Callers keep small per-feature vectors (biases, s_out.2 weights) in LDS (scorer_consts).
+template <int MT, bool ACC, bool BIAS = true>
 __device__ __forceinline__ void linear_t16(f32x4 (&out)[MT], const V64& in, const float* W, const float* bias,
                                            int lane) {
   const int l15 = lane & 15, kq = lane >> 4;
   if constexpr (!ACC) {
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-      out[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      if (bias) out[mt] = *reinterpret_cast<const f32x4*>(bias + 16 * mt + 4 * kq);
+      if constexpr (BIAS) out[mt] = *reinterpret_cast<const f32x4*>(bias + 16 * mt + 4 * kq);
+      else out[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
   }
   const u32x4* img = reinterpret_cast<const u32x4*>(W);

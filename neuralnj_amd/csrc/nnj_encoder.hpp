@@ -446,7 +446,7 @@ __global__ __launch_bounds__(1024) void k_ffn16(float* __restrict__ x, FfnW wf, 
       for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
         for (int e = 0; e < 4; ++e) hdn.t[mt][e] = gelu_erf(hdn.t[mt][e]);
-      linear_t16<4, true>(out.t, hdn, W2l + q * IMG64, nullptr, lane);
+      linear_t16<4, true, false>(out.t, hdn, W2l + q * IMG64, nullptr, lane);
     }
     if (!valid) continue;
 #pragma unroll

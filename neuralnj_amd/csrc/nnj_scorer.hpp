@@ -40,6 +40,16 @@ __device__ __forceinline__ int slot_of(const RowSet& rs, int b, int pos) {
   return rs.live ? rs.live[b * rs.live_stride + pos] : pos;
 }
 
+// The per-feature vectors of the scorer (b_h, b_g, s_out.0 bias, s_out.2 weight: 4 x 64 floats) live in LDS for the
+// lifetime of a workgroup: read from global memory inside the site loop they were one L2 round trip each, several of
+// them serialised by the scheduling fences that bound the live ranges (k_inc_score16: four `s_waitcnt vmcnt(0)` per
+// site on the s_out.2 weights alone), and their 64-bit addresses cost registers (k_inc_score_w<3>: 256 registers + 92
+// bytes of scratch -> 247 and none; incremental scores 72.5 -> 63.6 ms, alpha 34.6 -> 31.7 ms per rollout).
+constexpr int SCORER_CONSTS = 256;
+__device__ __forceinline__ void stage_scorer_consts(float* cv, const ScorerW& w, int tid) {
+  if (tid < 64) { cv[tid] = w.bh[tid]; cv[64 + tid] = w.bg[tid]; cv[128 + tid] = w.s0[tid]; cv[192 + tid] = w.s2w[tid]; }
+}
+
 enum { PAIRS_FULL = 0, PAIRS_INCR = 1 };
 
 // pair -> (position i, position j); returns false for padding lanes / the self pair
@@ -167,6 +177,8 @@ __global__ __launch_bounds__(64 * NW) void k_pair_alpha(RowSet rs, ScorerW w, co
   int sc, pg, b;
   if (!pair_block(nsc, npg, B, sc, pg, b)) return;
   const int c0 = sc * cs, c1 = min(C, c0 + cs);
+  float* cv = smem + 2 * (IMG64 + 8192);
+  stage_scorer_consts(cv, w, tid);
   int pi[TPW], pj[TPW];
   bool any = false;
 #pragma unroll
@@ -197,7 +209,7 @@ __global__ __launch_bounds__(64 * NW) void k_pair_alpha(RowSet rs, ScorerW w, co
 #pragma unroll
       for (int tt = 0; tt < TPW; ++tt) {
         f32x16 x[1][2];
-        gate_tile(x[0], cur + IMG64, cur + IMG64 + 4096, w.bh, pi[tt], pj[tt], hh);
+        gate_tile(x[0], cur + IMG64, cur + IMG64 + 4096, cv, pi[tt], pj[tt], hh);
         linear6_T_acc<2, 2, 1, true>(acc[tt], x, cur, lane);
       }
     }
@@ -276,6 +288,8 @@ __global__ __launch_bounds__(64 * NW) void k_pair_score(RowSet rs, ScorerW w, co
   const int c0 = sc * cs, c1 = min(C, c0 + cs);
   stage_weight_b6<64>(Wg_l, w.Wg, 64, tid, 64 * NW);
   stage_weight_b6<64>(S0_l, w.S0, 64, tid, 64 * NW);
+  float* cv = smem + 2 * IMG64 + 2 * (IMG64 + 8192);
+  stage_scorer_consts(cv, w, tid);
   int pi[TPW], pj[TPW];
   bool any = false;
   f32x16 al[TPW][1][2];
@@ -309,11 +323,11 @@ __global__ __launch_bounds__(64 * NW) void k_pair_score(RowSet rs, ScorerW w, co
 #pragma unroll
       for (int tt = 0; tt < TPW; ++tt) {
         f32x16 x[1][2];
-        gate_tile(x[0], img_s, img_u, w.bh, pi[tt], pj[tt], hh);
+        gate_tile(x[0], img_s, img_u, cv, pi[tt], pj[tt], hh);
         if (has_ctx) {
           f32x16 xg[1][2], g[1][2];
           linear6_T_nb<2, 2, 1, true>(xg, al[tt], img_t, lane);
-          linear6_T<2, 2, 1, true>(g, xg, Wg_l, w.bg, lane);
+          linear6_T<2, 2, 1, true>(g, xg, Wg_l, cv + 64, lane);
 #pragma unroll
           for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -323,13 +337,13 @@ __global__ __launch_bounds__(64 * NW) void k_pair_score(RowSet rs, ScorerW w, co
             }
         }
         f32x16 s1[1][2];
-        linear6_T<2, 2, 1, true>(s1, x, S0_l, w.s0, lane);
+        linear6_T<2, 2, 1, true>(s1, x, S0_l, cv + 128, lane);
         float s = 0.f;
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
           for (int g4 = 0; g4 < 4; ++g4) {
-            const f32x4 w4 = *reinterpret_cast<const f32x4*>(w.s2w + 32 * mt + 8 * g4 + 4 * hh);
+            const f32x4 w4 = *reinterpret_cast<const f32x4*>(cv + 192 + 32 * mt + 8 * g4 + 4 * hh);
 #pragma unroll
             for (int t = 0; t < 4; ++t) s += gelu_erf(s1[0][mt][4 * g4 + t]) * w4[t];
           }
@@ -468,6 +482,8 @@ __global__ __launch_bounds__(512) void k_inc_score(RowSet rs, ScorerW w, const i
   stage_weight_b6<64>(Wg_l, w.Wg, 64, tid, 512);
   stage_weight_b6<64>(S0_l, w.S0, 64, tid, 512);
   stage_weight_b6<64>(Wh_l, w.Wh, 64, tid, 512);
+  float* cv = smem + 3 * IMG64 + NSLOT * IMG + 16;
+  stage_scorer_consts(cv, w, tid);
   if (tid < NSLOT) reinterpret_cast<int*>(smem + 3 * IMG64 + NSLOT * IMG)[tid] = 0;
   __syncthreads();
   int epoch = 0;
@@ -544,7 +560,7 @@ __global__ __launch_bounds__(512) void k_inc_score(RowSet rs, ScorerW w, const i
     {
       IncShared sh;
       inc_load_shared(sh, rs, L, bo, C, c, hh);
-      inc_gate<1>(x, raw, sh, L, w.bh, hh);
+      inc_gate<1>(x, raw, sh, L, cv, hh);
     }
     if constexpr (CTX && KT == 2) pair_barrier_lds(cnt, epoch, status);   // all 64 columns are in the image
     const float mc = (mask && mask[(size_t)b * C + c]) ? 0.f : 1.f;     // seq_mask (model.py:96)
@@ -553,7 +569,7 @@ __global__ __launch_bounds__(512) void k_inc_score(RowSet rs, ScorerW w, const i
     if constexpr (CTX) {
       f32x16 xg[1][2], g[1][2];
       linear6_T_nb<2, KT, 1, true>(xg, at, img_t, lane);
-      linear6_T<2, 2, 1, true>(g, xg, Wg_l, w.bg, lane);
+      linear6_T<2, 2, 1, true>(g, xg, Wg_l, cv + 64, lane);
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -563,13 +579,13 @@ __global__ __launch_bounds__(512) void k_inc_score(RowSet rs, ScorerW w, const i
         }
     }
     f32x16 s1[1][2];
-    linear6_T<2, 2, 1, true>(s1, x, S0_l, w.s0, lane);
+    linear6_T<2, 2, 1, true>(s1, x, S0_l, cv + 128, lane);
     float s = 0.f;
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const f32x4 w4 = *reinterpret_cast<const f32x4*>(w.s2w + 32 * mt + 8 * g + 4 * hh);
+        const f32x4 w4 = *reinterpret_cast<const f32x4*>(cv + 192 + 32 * mt + 8 * g + 4 * hh);
 #pragma unroll
         for (int t = 0; t < 4; ++t) s += gelu_erf(s1[0][mt][4 * g + t]) * w4[t];
       }

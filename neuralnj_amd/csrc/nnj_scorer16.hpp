@@ -80,6 +80,8 @@ __global__ __launch_bounds__(64 * T16_WAVES) void k_inc_alpha16(RowSet rs, Score
   const int c0 = sc * cs, c1 = min(C, c0 + cs);
   stage_weight_t16(At_l, w.A, 64, tid, 64 * T16_WAVES, true);
   stage_weight_t16(Wh_l, w.Wh, 64, tid, 64 * T16_WAVES);
+  float* cv = smem + 2 * IMG64 + NSLOT * IMG + 16;
+  stage_scorer_consts(cv, w, tid);
   if (tid < NSLOT) cnt0[tid] = 0;
   __syncthreads();
   int* cnt = cnt0 + slot;
@@ -125,7 +127,7 @@ __global__ __launch_bounds__(64 * T16_WAVES) void k_inc_alpha16(RowSet rs, Score
         }
         __builtin_amdgcn_sched_barrier(0);
       }
-      gate16(x, sr, ur, sm, um, w.bh, L.sgn, kq);
+      gate16(x, sr, ur, sm, um, cv, L.sgn, kq);
     }
     if constexpr (NG > 1) group_barrier_lds<NG>(cnt, epoch, status);     // everyone is done with the previous image
     // row r of the image: chunk 4*ks + kq = this lane's tiles 2ks, 2ks+1
@@ -138,8 +140,8 @@ __global__ __launch_bounds__(64 * T16_WAVES) void k_inc_alpha16(RowSet rs, Score
     const int cn = c + NSLOT < c1 ? c + NSLOT : c;               // prefetch behind the MFMAs (last: harmless reload)
     load_v64(sr, Sr + (size_t)cn * 64, kq);
     V64 xp;
-    linear_t16<4, false>(xp.t, x, At_l, nullptr, lane);          // x' = A^T x
-    linear_t16<NG, true>(acc, xp, img, nullptr, lane);           // acc[r'][pair] += S_r' . x'
+    linear_t16<4, false, false>(xp.t, x, At_l, nullptr, lane);          // x' = A^T x
+    linear_t16<NG, true, false>(acc, xp, img, nullptr, lane);           // acc[r'][pair] += S_r' . x'
   }
   // one partial set per WORKGROUP: the slots add their tiles into one LDS tile [64 pairs][64 r'] in slot order
   // (fixed order: bitwise reproducible), the images are dead by then
@@ -193,6 +195,8 @@ __global__ __launch_bounds__(64 * T16_WAVES) void k_inc_score16(RowSet rs, Score
   stage_weight_t16(Wg_l, w.Wg, 64, tid, 64 * T16_WAVES);
   stage_weight_t16(S0_l, w.S0, 64, tid, 64 * T16_WAVES);
   stage_weight_t16(Wh_l, w.Wh, 64, tid, 64 * T16_WAVES);
+  float* cv = smem + 3 * IMG64 + NSLOT * IMG + 16;
+  stage_scorer_consts(cv, w, tid);
   if constexpr (NG == 3) {                                 // columns 48..63 are never written: they meet alpha = 0 but must be finite
     for (int i = tid; i < NSLOT * IMG; i += 64 * T16_WAVES) smem[3 * IMG64 + i] = 0.f;
   }
@@ -257,7 +261,7 @@ __global__ __launch_bounds__(64 * T16_WAVES) void k_inc_score16(RowSet rs, Score
         }
         __builtin_amdgcn_sched_barrier(0);
       }
-      gate16(x, sr, ur, sm, um, w.bh, L.sgn, kq);
+      gate16(x, sr, ur, sm, um, cv, L.sgn, kq);
     }
     if constexpr (CTX) {
       if constexpr (NG > 1) __syncthreads();                     // everyone is done with the previous image
@@ -296,7 +300,7 @@ __global__ __launch_bounds__(64 * T16_WAVES) void k_inc_score16(RowSet rs, Score
         }
         __builtin_amdgcn_sched_barrier(0);
       });
-      linear_t16<4, false>(g.t, xg, Wg_l, w.bg, lane);
+      linear_t16<4, false>(g.t, xg, Wg_l, cv + 64, lane);
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
@@ -307,11 +311,11 @@ __global__ __launch_bounds__(64 * T16_WAVES) void k_inc_score16(RowSet rs, Score
         }
     }
     V64 s1;
-    linear_t16<4, false>(s1.t, x, S0_l, w.s0, lane);
+    linear_t16<4, false>(s1.t, x, S0_l, cv + 128, lane);
     float s = 0.f;
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
-      const f32x4 w4 = *reinterpret_cast<const f32x4*>(w.s2w + 16 * mt + 4 * kq);
+      const f32x4 w4 = *reinterpret_cast<const f32x4*>(cv + 192 + 16 * mt + 4 * kq);
 #pragma unroll
       for (int e = 0; e < 4; ++e) s += gelu_erf(s1.t[mt][e]) * w4[e];
       __builtin_amdgcn_sched_barrier(0);
@@ -366,6 +370,8 @@ __global__ __launch_bounds__(512) void k_inc_score_w(RowSet rs, ScorerW w, const
   stage_weight_t16(Wg_l, w.Wg, 64, tid, 64 * NW);
   stage_weight_t16(S0_l, w.S0, 64, tid, 64 * NW);
   stage_weight_t16(Wh_l, w.Wh, 64, tid, 64 * NW);
+  float* cv = smem + 3 * IMG64 + NW * IMG;
+  stage_scorer_consts(cv, w, tid);
   __syncthreads();
   const size_t bo = (size_t)b * rs.bstride;
   const float* Sr[NT];
@@ -420,7 +426,7 @@ __global__ __launch_bounds__(512) void k_inc_score_w(RowSet rs, ScorerW w, const
             a.h = wh4[o]; a.m = wh4[64 * 8 + o];
             ur.t[mt] = mfma16_b6(a, sf[ks], ur.t[mt]);
           }
-        gate16(x[t], sr[t], ur, sm, um, w.bh, sgn[t], kq);
+        gate16(x[t], sr[t], ur, sm, um, cv, sgn[t], kq);
         if constexpr (CTX) {
           const int wchunk = 2 * t + (l15 >> 3), we = l15 & 7;
 #pragma unroll
@@ -467,7 +473,7 @@ __global__ __launch_bounds__(512) void k_inc_score_w(RowSet rs, ScorerW w, const
             xg.t[mt] = mfma16_b6(a, bfr, xg.t[mt]);
           }
         }
-        linear_t16<4, false>(g.t, xg, Wg_l, w.bg, lane);
+        linear_t16<4, false>(g.t, xg, Wg_l, cv + 64, lane);
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
@@ -477,11 +483,11 @@ __global__ __launch_bounds__(512) void k_inc_score_w(RowSet rs, ScorerW w, const
           }
       }
       V64 s1;
-      linear_t16<4, false>(s1.t, x[t], S0_l, w.s0, lane);
+      linear_t16<4, false>(s1.t, x[t], S0_l, cv + 128, lane);
       float s = 0.f;
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt) {
-        const f32x4 w4 = *reinterpret_cast<const f32x4*>(w.s2w + 16 * mt + 4 * kq);
+        const f32x4 w4 = *reinterpret_cast<const f32x4*>(cv + 192 + 16 * mt + 4 * kq);
 #pragma unroll
         for (int e = 0; e < 4; ++e) s += gelu_erf(s1.t[mt][e]) * w4[e];
       }

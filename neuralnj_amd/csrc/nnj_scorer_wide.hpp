@@ -59,6 +59,8 @@ __global__ __launch_bounds__(512) void k_wide_alpha(RowSet rs, ScorerW w, const 
   const int c0 = sc * cs, c1 = min(C, c0 + cs);
   stage_weight_t16(At_l, w.A, 64, tid, 512, true);
   stage_weight_t16(Wh_l, w.Wh, 64, tid, 512);
+  float* cv = smem + 2 * IMG64 + 64 * RP;
+  stage_scorer_consts(cv, w, tid);
   const size_t bo = (size_t)b * rs.bstride;
   const float* Sm = rs.S + bo + (size_t)st.slot_m * C * 64;
   const float* Um = rs.U + bo + (size_t)st.slot_m * C * 64;
@@ -115,15 +117,15 @@ __global__ __launch_bounds__(512) void k_wide_alpha(RowSet rs, ScorerW w, const 
         }
         __builtin_amdgcn_sched_barrier(0);
       }
-      gate16(x[pt], sr, ur, sm, um, w.bh, sgn[pt], kq);
+      gate16(x[pt], sr, ur, sm, um, cv, sgn[pt], kq);
     }
     __syncthreads();                                       // all RP rows are in the image
 #pragma unroll
     for (int pt = 0; pt < PT; ++pt) {
       if (pt != pth || !act[pt]) continue;                 // wave-uniform
       V64 xp;
-      linear_t16<4, false>(xp.t, x[pt], At_l, nullptr, lane);          // x' = A^T x
-      linear_t16<NGT, true>(acc, xp, img, nullptr, lane);              // acc[r'][pair] += S_r' . x'
+      linear_t16<4, false, false>(xp.t, x[pt], At_l, nullptr, lane);          // x' = A^T x
+      linear_t16<NGT, true, false>(acc, xp, img, nullptr, lane);              // acc[r'][pair] += S_r' . x'
     }
   }
   // partial sums of this site chunk: [pair r][r'], the lane's four r' of tile mt at 16mt + 4kq
@@ -211,6 +213,8 @@ __global__ __launch_bounds__(512) void k_wide_score(RowSet rs, ScorerW w, const 
   stage_weight_t16(Wg_l, w.Wg, 64, tid, 512);
   stage_weight_t16(S0_l, w.S0, 64, tid, 512);
   stage_weight_t16(Wh_l, w.Wh, 64, tid, 512);
+  float* cv = smem + 3 * IMG64 + 64 * RP;
+  stage_scorer_consts(cv, w, tid);
   const size_t bo = (size_t)b * rs.bstride;
   const float* Sm = rs.S + bo + (size_t)st.slot_m * C * 64;
   const float* Um = rs.U + bo + (size_t)st.slot_m * C * 64;
@@ -274,7 +278,7 @@ __global__ __launch_bounds__(512) void k_wide_score(RowSet rs, ScorerW w, const 
         }
         __builtin_amdgcn_sched_barrier(0);
       }
-      gate16(x[pt], sr, ur, sm, um, w.bh, sgn[pt], kq);
+      gate16(x[pt], sr, ur, sm, um, cv, sgn[pt], kq);
     }
     __syncthreads();                                       // all RP columns are in the image
     const float mc = (mask && mask[(size_t)b * C + c]) ? 0.f : 1.f;      // seq_mask (model.py:96)
@@ -300,7 +304,7 @@ __global__ __launch_bounds__(512) void k_wide_score(RowSet rs, ScorerW w, const 
           xg.t[mt] = mfma16_b6(a, bfr, xg.t[mt]);
         }
       }
-      linear_t16<4, false>(g.t, xg, Wg_l, w.bg, lane);
+      linear_t16<4, false>(g.t, xg, Wg_l, cv + 64, lane);
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
@@ -309,11 +313,11 @@ __global__ __launch_bounds__(512) void k_wide_score(RowSet rs, ScorerW w, const 
           x[pt].t[mt][e] += wg * (xg.t[mt][e] - x[pt].t[mt][e]);       // (1-w)*x + w*x_g
         }
       V64 s1;
-      linear_t16<4, false>(s1.t, x[pt], S0_l, w.s0, lane);
+      linear_t16<4, false>(s1.t, x[pt], S0_l, cv + 128, lane);
       float s = 0.f;
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt) {
-        const f32x4 w4 = *reinterpret_cast<const f32x4*>(w.s2w + 16 * mt + 4 * kq);
+        const f32x4 w4 = *reinterpret_cast<const f32x4*>(cv + 192 + 16 * mt + 4 * kq);
 #pragma unroll
         for (int e = 0; e < 4; ++e) s += gelu_erf(s1.t[mt][e]) * w4[e];
       }
