@@ -361,7 +361,7 @@ int launch_encoder(nnj_handle* h, const uint8_t* codes, const float* onehot, con
   for (int l = 0; l < nl; ++l) {
     {
       Scope sc(h, st, PK_ROW_QKV);
-      const size_t lds_qkv = (size_t)b6_floats(192, 64) * sizeof(float);
+      const size_t lds_qkv = (size_t)(b6_floats(192, 64) + 320) * sizeof(float);
       if (int rc = set_lds(h, k_qkv6, lds_qkv)) return rc;
       const long tiles = (long)((T + 1) / 2) * ((C + 15) / 16);
       const long ngroups = ((tiles + 7) / 8) * B;
@@ -411,7 +411,7 @@ int launch_encoder(nnj_handle* h, const uint8_t* codes, const float* onehot, con
       // NT waves per column (32 rows each), 8 / NT columns in flight per workgroup; persistent
       constexpr int NSLOT = 8 / NT;
       const unsigned grid1 = (unsigned)std::min<long>((long)(((size_t)B * C + NSLOT - 1) / NSLOT), (long)h->num_cu);
-      const size_t lds = (size_t)(5 * 4096 + NSLOT * (32 * NT * 32 + 32 * NT * 32) + 16) * sizeof(float);
+      const size_t lds = (size_t)(5 * 4096 + NSLOT * (32 * NT * 32 + 32 * NT * 32) + 16 + 448) * sizeof(float);
       if (int rc = set_lds(h, k_tok1p<NT>, lds)) return rc;
       hipLaunchKernelGGL(k_tok1p<NT>, dim3(grid1), dim3(512), lds, st, ctx, mask, x, attn_ptrs(h, h->lo[l].row),
                          attn_ptrs(h, h->lo[l].col), B, T, C, d.Epad, dbg, h->d_flag);
@@ -424,7 +424,7 @@ int launch_encoder(nnj_handle* h, const uint8_t* codes, const float* onehot, con
         const int groups_per_b = (T * C + 255) / 256;
         const long ngroups = (long)groups_per_b * B;
         const unsigned grid = (unsigned)std::min<long>(ngroups, h->num_cu);
-        const size_t lds_ffn = (size_t)8 * IMG64 * sizeof(float);   // W1 and W2 whole (8 images of 64x64)
+        const size_t lds_ffn = (size_t)(8 * IMG64 + 448) * sizeof(float);   // W1 and W2 whole (8 images of 64x64) + LN / bias vectors
         if (int rc = set_lds(h, k_ffn16, lds_ffn)) return rc;
         hipLaunchKernelGGL(k_ffn16, dim3(grid), dim3(1024), lds_ffn, st, x, ffn_ptrs(h, h->lo[l]), B, T, C, groups_per_b);
       }

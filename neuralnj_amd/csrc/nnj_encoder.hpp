@@ -137,6 +137,11 @@ __global__ __launch_bounds__(512) void k_tok1p(const float* __restrict__ ctx, co
     stage_weight_b6<64>(Wqkv_l + hf * QKV, wc.Wv + hf * 32 * 64, 32, tid, 512, 64, 96);
   }
   if (tid < NSLOT) reinterpret_cast<int*>(smem + 20480 + NSLOT * SLOTF)[tid] = 0;
+  // bias and LayerNorm vectors in LDS (persistent workgroup; see k_ffn16): row out_proj bias | column ln_w | ln_b |
+  // bq | bk | bv | column out_proj bias, 64 floats each
+  float* ct = smem + 20480 + NSLOT * SLOTF + 16;
+  if (tid < 64) { ct[tid] = wr.bo[tid]; ct[64 + tid] = wc.ln_w[tid]; ct[128 + tid] = wc.ln_b[tid]; ct[192 + tid] = wc.bq[tid];
+                  ct[256 + tid] = wc.bk[tid]; ct[320 + tid] = wc.bv[tid]; ct[384 + tid] = wc.bo[tid]; }
   __syncthreads();
   int epoch = 0;
   const int tok = lane & 31, hh = lane >> 5;
@@ -178,7 +183,7 @@ __global__ __launch_bounds__(512) void k_tok1p(const float* __restrict__ ctx, co
       f32x16 cx[1][2], o[1][2];
       xr[0][0] = xn[0]; xr[0][1] = xn[1];
       cx[0][0] = cn[0]; cx[0][1] = cn[1];
-      linear6_T<2, 2, 1, true>(o, cx, W0, wr.bo, lane);
+      linear6_T<2, 2, 1, true>(o, cx, W0, ct, lane);
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt) xr[0][mt] += o[0][mt];
     }
@@ -197,12 +202,12 @@ __global__ __launch_bounds__(512) void k_tok1p(const float* __restrict__ ctx, co
       f32x16 qh, kh, vT;
       {
         f32x16 y[2];
-        layer_norm64(y, xr[0], wc.ln_w, wc.ln_b, hh);
-        const float bvl = wc.bv[32 * hf + tok];
+        layer_norm64(y, xr[0], ct + 64, ct + 128, hh);
+        const float bvl = ct[320 + 32 * hf + tok];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-          const f32x4 q4 = *reinterpret_cast<const f32x4*>(wc.bq + 32 * hf + 8 * g + 4 * hh);
-          const f32x4 k4 = *reinterpret_cast<const f32x4*>(wc.bk + 32 * hf + 8 * g + 4 * hh);
+          const f32x4 q4 = *reinterpret_cast<const f32x4*>(ct + 192 + 32 * hf + 8 * g + 4 * hh);
+          const f32x4 k4 = *reinterpret_cast<const f32x4*>(ct + 256 + 32 * hf + 8 * g + 4 * hh);
 #pragma unroll
           for (int t = 0; t < 4; ++t) { qh[4 * g + t] = q4[t]; kh[4 * g + t] = k4[t]; vT[4 * g + t] = bvl; }
         }
@@ -393,7 +398,7 @@ __global__ __launch_bounds__(512) void k_tok1p(const float* __restrict__ ctx, co
     }
     load_col(col + cstride < ncols ? col + cstride : col, xn, cn);      // (last column: harmless reload; unconditional, so
     f32x16 o[1][2];                                                      //  the old values are dead across the iteration)
-    linear6_T<2, 2, 1, true>(o, cx, Wo_l, wc.bo, lane);
+    linear6_T<2, 2, 1, true>(o, cx, Wo_l, ct + 384, lane);
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) xr[0][mt] += o[0][mt];
     store_token64(xr[0], xp, valid, hh);
@@ -426,6 +431,11 @@ __global__ __launch_bounds__(1024) void k_ffn16(float* __restrict__ x, FfnW wf, 
     stage_weight_t16(W1l + q * IMG64, wf.W1 + (size_t)(q * 64) * 64, 64, tid, 1024);
     stage_weight_t16(W2l + q * IMG64, wf.W2, 64, tid, 1024, false, 256, 64 * q);
   }
+  // LayerNorm scale / shift and the two bias vectors stay in LDS for the lifetime of the (persistent) workgroup: read
+  // from global memory inside the loop they are 28 small L2 round trips per 16-token tile
+  float* cf = smem + 8 * IMG64;              // ln_w[64] | ln_b[64] | b2[64] | b1[256]
+  if (tid < 64) { cf[tid] = wf.ln_w[tid]; cf[64 + tid] = wf.ln_b[tid]; cf[128 + tid] = wf.b2[tid]; }
+  if (tid < 256) cf[192 + tid] = wf.b1[tid];
   __syncthreads();
   for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
     const int b = grp / groups_per_b;
@@ -435,13 +445,13 @@ __global__ __launch_bounds__(1024) void k_ffn16(float* __restrict__ x, FfnW wf, 
     asm volatile("" ::: "memory");          // keep the parameter loads inside the loop (hoisted, they would occupy ~200 VGPRs)
     V64 xr, y, out;
     load_v64(xr, xp, kq);
-    layer_norm_v64(y, xr, wf.ln_w, wf.ln_b, kq);
+    layer_norm_v64(y, xr, cf, cf + 64, kq);
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) out.t[mt] = *reinterpret_cast<const f32x4*>(wf.b2 + 16 * mt + 4 * kq);
+    for (int mt = 0; mt < 4; ++mt) out.t[mt] = *reinterpret_cast<const f32x4*>(cf + 128 + 16 * mt + 4 * kq);
 #pragma unroll 1
     for (int q = 0; q < 4; ++q) {              // 64 hidden units at a time
       V64 hdn;
-      linear_t16<4, false>(hdn.t, y, W1l + q * IMG64, wf.b1 + q * 64, lane);
+      linear_t16<4, false>(hdn.t, y, W1l + q * IMG64, cf + 192 + q * 64, lane);
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt)
 #pragma unroll

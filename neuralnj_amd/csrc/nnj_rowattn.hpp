@@ -94,6 +94,10 @@ __global__ __launch_bounds__(512) void k_qkv6(const float* __restrict__ x, const
   stage_weight_b6<64>(Wl, wn.Wq, 64, tid, 512, 0, 192);
   stage_weight_b6<64>(Wl, wn.Wk, 64, tid, 512, 64, 192);
   stage_weight_b6<64>(Wl, wn.Wv, 64, tid, 512, 128, 192);
+  // LayerNorm scale / shift and the three bias vectors in LDS (persistent workgroup): see k_ffn16
+  float* cq = smem + b6_floats(192, 64);     // ln_w | ln_b | bq | bk | bv, 64 floats each
+  if (tid < 64) { cq[tid] = wn.ln_w[tid]; cq[64 + tid] = wn.ln_b[tid]; cq[128 + tid] = wn.bq[tid];
+                  cq[192 + tid] = wn.bk[tid]; cq[256 + tid] = wn.bv[tid]; }
   __syncthreads();
   const int R = g.T, C = g.C;
   const int RP = (R + 1) / 2, CB = (C + 15) / 16;
@@ -121,7 +125,7 @@ __global__ __launch_bounds__(512) void k_qkv6(const float* __restrict__ x, const
     const bool valid = tile_ok && r < R && c < C;
     asm volatile("" ::: "memory");      // keep the parameter loads inside the loop (hoisted, they would occupy ~200 VGPRs)
     f32x16 y[1][2], o[1][6];
-    layer_norm64(y[0], xr, wn.ln_w, wn.ln_b, hh);
+    layer_norm64(y[0], xr, cq, cq + 64, hh);
     // the next group's tokens go into the registers LayerNorm has just consumed: their HBM latency runs
     // behind the GEMM and the stores
     if (grp + (int)gridDim.x < ngroups) load_token64(xr, tok_addr(grp + gridDim.x), true, hh);
@@ -145,7 +149,7 @@ __global__ __launch_bounds__(512) void k_qkv6(const float* __restrict__ x, const
         // ---- q and k: 8 bytes (d = 4hh..4hh+3) of the 16-byte half (row r) of column c's tile row
 #pragma unroll
         for (int ten = 0; ten < 2; ++ten) {
-          const float* bias = ten ? wn.bk : wn.bq;
+          const float* bias = ten ? cq + 192 : cq + 128;
           const float scale = ten ? 1.0f : qscale;
           const f32x4 b4 = *reinterpret_cast<const f32x4*>(bias + 32 * mt + 8 * gq + 4 * hh);
           float v[4];
@@ -161,7 +165,7 @@ __global__ __launch_bounds__(512) void k_qkv6(const float* __restrict__ x, const
         // ---- v: transposed.  The lane holds four rows e (t = 0..3) of ONE key; a 4x4 transpose over the
         // quad (four consecutive keys) gives it one row e = 8r + 4hh + (lane&3) of FOUR keys = 8 bytes.
         {
-          const f32x4 b4 = *reinterpret_cast<const f32x4*>(wn.bv + 32 * mt + 8 * gq + 4 * hh);
+          const f32x4 b4 = *reinterpret_cast<const f32x4*>(cq + 256 + 32 * mt + 8 * gq + 4 * hh);
           float v[4];
 #pragma unroll
           for (int t = 0; t < 4; ++t) v[t] = valid ? b4[t] + o[0][4 + mt][4 * gq + t] : 0.f;
