@@ -461,6 +461,57 @@ __device__ __forceinline__ void linear6_T_acc(f32x16 (&out)[NT][MT], const f32x1
   linear_core_b6<MT, KT, NT, true, false, LEAN>(out, in, W, nullptr, lane);
 }
 
+// out = W * in for an input that is ALREADY split into k-step fragments (the softmax kernels write the context
+// weights alpha as fp16 pieces: the consumers' site loops carry no split of them).  W = image of [32*MT][16*KS2].
+template <int MT, int KS2>
+__device__ __forceinline__ void linear6_pre(f32x16 (&out)[1][MT], const Frag3 (&b)[KS2], const float* W, int lane) {
+  const int row = lane & 31, hh = lane >> 5;
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) out[0][mt][r] = 0.f;
+  constexpr int CH = 2 * KS2;
+  constexpr int PLANE = 32 * MT * CH;
+  const u32x4* img = reinterpret_cast<const u32x4*>(W);
+  static_for<0, KS2>([&](auto ki) {
+    constexpr int ks = decltype(ki)::value;
+    static_for<0, MT>([&](auto mi) {
+      constexpr int mt = decltype(mi)::value;
+      const int wrow = 32 * mt + row;
+      const int o = wrow * CH + wswz6<CH>(wrow, 2 * ks + hh);
+      Frag3 a;
+      a.h = img[o]; a.m = img[PLANE + o];
+      out[0][mt] = mfma_b6(a, b[ks], out[0][mt]);
+    });
+    __builtin_amdgcn_sched_barrier(0);
+  });
+}
+// alpha planes: the two fp16 pieces of a softmax weight, `plane` fp16 elements apart
+__device__ __forceinline__ void alpha_store(float* alpha, long plane, size_t idx, float a) {
+  _Float16* ah = reinterpret_cast<_Float16*>(alpha);
+  const _Float16 h = (_Float16)a;
+  ah[idx] = h;
+  ah[plane + idx] = (_Float16)(a - (float)h);
+}
+// fragment of k-step ks for a 16-token-tile consumer: 8 consecutive r' (natural order)
+__device__ __forceinline__ void alpha_frag16(Frag3& f, const float* alpha, long plane, size_t idx) {
+  const unsigned short* ah = reinterpret_cast<const unsigned short*>(alpha);
+  f.h = *reinterpret_cast<const u32x4*>(ah + idx);
+  f.m = *reinterpret_cast<const u32x4*>(ah + plane + idx);
+}
+// ... for a 32-token-tile consumer: k-step ks of row `row_idx` (element offset of the row): r' = 16ks + 8j + 4hh + t
+__device__ __forceinline__ void alpha_frag32(Frag3& f, const float* alpha, long plane, size_t row_idx, int ks, int hh,
+                                             bool ok) {
+  const unsigned short* ah = reinterpret_cast<const unsigned short*>(alpha) + row_idx + 16 * ks + 4 * hh;
+  uint2 h0 = make_uint2(0u, 0u), h1 = h0, m0 = h0, m1 = h0;
+  if (ok) {
+    h0 = *reinterpret_cast<const uint2*>(ah); h1 = *reinterpret_cast<const uint2*>(ah + 8);
+    m0 = *reinterpret_cast<const uint2*>(ah + plane); m1 = *reinterpret_cast<const uint2*>(ah + plane + 8);
+  }
+  f.h = (u32x4){h0.x, h0.y, h1.x, h1.y};
+  f.m = (u32x4){m0.x, m0.y, m1.x, m1.y};
+}
+
 // ---- 16-token tiles.  lane = (token l&15, feature quarter kq = l>>4); a 64-feature vector is four f32x4 tiles,
 // element r of tile mt = feature 16*mt + 4*kq + r -- the C/D layout of v_mfma_f32_16x16x32_f16 -- so a tensor
 // costs 16 registers per lane (32 with the 32-token tiles): kernels whose dependency chains are latency bound

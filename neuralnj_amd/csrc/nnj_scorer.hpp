@@ -265,7 +265,8 @@ __global__ __launch_bounds__(256) void k_alpha_softmax(RowSet rs, ScorerW w, con
   float s = e;
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o);
-  alpha[((size_t)b * ppad + p) * 64 + lane] = (s > 0.f) ? e / s : 0.f;
+  // written as its two fp16 pieces (planes): the B operand of x_g = S^T alpha^T as the consumers load it
+  alpha_store(alpha, (long)gridDim.y * ppad * 64, ((size_t)b * ppad + p) * 64 + lane, (s > 0.f) ? e / s : 0.f);
 }
 
 // ------------------------------------------------------------------ k_pair_score
@@ -292,7 +293,7 @@ __global__ __launch_bounds__(64 * NW) void k_pair_score(RowSet rs, ScorerW w, co
   stage_scorer_consts(cv, w, tid);
   int pi[TPW], pj[TPW];
   bool any = false;
-  f32x16 al[TPW][1][2];
+  Frag3 af[TPW][4];                                        // alpha of the lane's pair, as k-step fragments (pre-split)
   float score[TPW];
 #pragma unroll
   for (int tt = 0; tt < TPW; ++tt) {
@@ -302,7 +303,9 @@ __global__ __launch_bounds__(64 * NW) void k_pair_score(RowSet rs, ScorerW w, co
     any = any || (tile * 32 < npairs);
     score[tt] = 0.f;
     const bool ld = has_ctx && p < ppad;
-    load_token64(al[tt][0], alpha + ((size_t)b * ppad + p) * 64, ld, hh);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+      alpha_frag32(af[tt][ks], alpha, (long)B * ppad * 64, ((size_t)b * ppad + (ld ? p : 0)) * 64, ks, hh, ld);
   }
   SiteRegs<64 * NW> R;
   if (c0 < c1) {
@@ -326,7 +329,7 @@ __global__ __launch_bounds__(64 * NW) void k_pair_score(RowSet rs, ScorerW w, co
         gate_tile(x[0], img_s, img_u, cv, pi[tt], pj[tt], hh);
         if (has_ctx) {
           f32x16 xg[1][2], g[1][2];
-          linear6_T_nb<2, 2, 1, true>(xg, al[tt], img_t, lane);
+          linear6_pre<2, 4>(xg, af[tt], img_t, lane);
           linear6_T<2, 2, 1, true>(g, xg, Wg_l, cv + 64, lane);
 #pragma unroll
           for (int mt = 0; mt < 2; ++mt)
@@ -500,16 +503,11 @@ __global__ __launch_bounds__(512) void k_inc_score(RowSet rs, ScorerW w, const i
     asm volatile("" ::: "memory");
     // alpha[pair][r'] (only r' < 32*KT can be non-zero) is re-read per site from L2 (keeping it in registers
     // next to the prefetched rows would spill); issued first, it lands behind the gate and the image
-    f32x16 at[1][KT];
+    Frag3 at[2 * KT];                                      // pre-split k-step fragments (see k_alpha_softmax)
     if constexpr (CTX) {
-      const float* ap = alpha + ((size_t)b * 64 + r) * 64;
 #pragma unroll
-      for (int kt = 0; kt < KT; ++kt)
-#pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) {
-          const f32x4 v = *reinterpret_cast<const f32x4*>(ap + 32 * kt + 8 * g4 + 4 * hh);
-          at[0][kt][4 * g4] = v[0]; at[0][kt][4 * g4 + 1] = v[1]; at[0][kt][4 * g4 + 2] = v[2]; at[0][kt][4 * g4 + 3] = v[3];
-        }
+      for (int ks = 0; ks < 2 * KT; ++ks)
+        alpha_frag32(at[ks], alpha, (long)gridDim.y * 4096, ((size_t)b * 64 + r) * 64, ks, hh, true);
     }
     f32x16 x[1][2];
     {
@@ -568,7 +566,7 @@ __global__ __launch_bounds__(512) void k_inc_score(RowSet rs, ScorerW w, const i
     inc_load<1>(raw, rs, L, bo, n, C, cn < c1 ? cn : c, hh);           // prefetch behind the MFMAs (last: harmless reload)
     if constexpr (CTX) {
       f32x16 xg[1][2], g[1][2];
-      linear6_T_nb<2, KT, 1, true>(xg, at, img_t, lane);
+      linear6_pre<2, 2 * KT>(xg, at, img_t, lane);
       linear6_T<2, 2, 1, true>(g, xg, Wg_l, cv + 64, lane);
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt)

@@ -206,7 +206,8 @@ __global__ __launch_bounds__(64 * T16_WAVES) void k_inc_score16(RowSet rs, Score
   const float* Sr = rs.S + bo + (size_t)L.slot_r * C * 64;
   const float* Sm = rs.S + bo + (size_t)L.slot_m * C * 64;
   const float* Um = rs.U + bo + (size_t)L.slot_m * C * 64;
-  const float* ap = alpha + ((size_t)b * 64 + L.r) * 64 + 8 * kq;
+  const size_t ap = ((size_t)b * 64 + L.r) * 64 + 8 * kq;       // element offset into the alpha planes
+  const long apl = (long)gridDim.y * 4096;
   // column r of the image: chunk r>>3, element r&7
   unsigned short* t16 = reinterpret_cast<unsigned short*>(img);
   constexpr int RL = 16 * NC;                              // fp16 per image row
@@ -228,13 +229,10 @@ __global__ __launch_bounds__(64 * T16_WAVES) void k_inc_score16(RowSet rs, Score
     load_v64(sr, Sr + (size_t)c * 64, kq);
     // alpha[pair][r'] of this lane's pair, k-slot 8kq + j of k-step ks = r' = 32ks + 8kq + j (exactly 0 beyond
     // the live rows): issued first, it lands behind the gate and the image
-    f32x4 al[KSX][2];
+    Frag3 al[KSX];                                               // pre-split by k_alpha_softmax
     if constexpr (CTX) {
 #pragma unroll
-      for (int ks = 0; ks < KSX; ++ks) {
-        al[ks][0] = *reinterpret_cast<const f32x4*>(ap + 32 * ks);
-        al[ks][1] = *reinterpret_cast<const f32x4*>(ap + 32 * ks + 4);
-      }
+      for (int ks = 0; ks < KSX; ++ks) alpha_frag16(al[ks], alpha, apl, ap + 32 * ks);
     }
     V64 x;
     // fp16 pieces of S_r: B operand of U_r = W_h S_r (recomputed: the cached U rows were half of the kernel's HBM
@@ -285,8 +283,7 @@ __global__ __launch_bounds__(64 * T16_WAVES) void k_inc_score16(RowSet rs, Score
       for (int mt = 0; mt < 4; ++mt) xg.t[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
       static_for<0, KSX>([&](auto ki) {
         constexpr int ks = decltype(ki)::value;
-        Frag3 bfr;
-        split_8(bfr, al[ks][0], al[ks][1]);
+        const Frag3& bfr = al[ks];
         // lanes whose chunk lies beyond a short row read the row's last chunk instead: finite data against
         // alpha values that are exactly 0
         const int lc = min(4 * ks + kq, CH - 1);
@@ -375,7 +372,8 @@ __global__ __launch_bounds__(512) void k_inc_score_w(RowSet rs, ScorerW w, const
   __syncthreads();
   const size_t bo = (size_t)b * rs.bstride;
   const float* Sr[NT];
-  const float* ap[NT];
+  size_t ap[NT];                                           // element offsets into the alpha planes
+  const long apl = (long)gridDim.y * 4096;
   float sgn[NT], score[NT];
   int rr[NT];
   const float *Sm, *Um;
@@ -383,7 +381,7 @@ __global__ __launch_bounds__(512) void k_inc_score_w(RowSet rs, ScorerW w, const
   for (int t = 0; t < NT; ++t) {
     const Inc16 L = inc16(rs, ij_prev, b, n, 16 * t + l15);
     Sr[t] = rs.S + bo + (size_t)L.slot_r * C * 64;
-    ap[t] = alpha + ((size_t)b * 64 + L.r) * 64 + 8 * kq;
+    ap[t] = ((size_t)b * 64 + L.r) * 64 + 8 * kq;
     sgn[t] = L.sgn;
     rr[t] = L.r;
     score[t] = 0.f;
@@ -459,10 +457,8 @@ __global__ __launch_bounds__(512) void k_inc_score_w(RowSet rs, ScorerW w, const
         for (int mt = 0; mt < 4; ++mt) xg.t[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ks = 0; ks < KSX; ++ks) {
-          const f32x4 a0 = *reinterpret_cast<const f32x4*>(ap[t] + 32 * ks);
-          const f32x4 a1 = *reinterpret_cast<const f32x4*>(ap[t] + 32 * ks + 4);
           Frag3 bfr;
-          split_8(bfr, a0, a1);
+          alpha_frag16(bfr, alpha, apl, ap[t] + 32 * ks);
           const int lc = min(4 * ks + kq, CH - 1);
 #pragma unroll
           for (int mt = 0; mt < 4; ++mt) {

@@ -151,11 +151,12 @@ __global__ __launch_bounds__(256) void k_wide_softmax(RowSet rs, ScorerW w, cons
   const bool full = ij_prev == nullptr;
   const WideStar st = wide_star(rs, ij_prev, m0, b, n);
   const size_t star = (size_t)b * gridDim.y + st.mi;
-  float* out = alpha + (star * RP + r) * RP;
+  const size_t orow = (star * RP + r) * RP;                 // alpha is written as two fp16 planes (pre-split)
+  const long apl = (long)gridDim.z * gridDim.y * RP * RP;
   const bool wanted = r < n && r != st.m && (!full || r > st.m);
   const int nk = RP / 64;
   if (!wanted) {
-    for (int k = 0; k < nk; ++k) out[64 * k + lane] = 0.f;
+    for (int k = 0; k < nk; ++k) alpha_store(alpha, apl, orow + 64 * k + lane, 0.f);
     return;
   }
   const float inv = 1.0f / sqrtf(64.0f * (float)C);
@@ -186,7 +187,7 @@ __global__ __launch_bounds__(256) void k_wide_softmax(RowSet rs, ScorerW w, cons
   }
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) sum += __shfl_xor(sum, o);
-  for (int k = 0; k < nk; ++k) out[64 * k + lane] = sum > 0.f ? a[k] / sum : 0.f;
+  for (int k = 0; k < nk; ++k) alpha_store(alpha, apl, orow + 64 * k + lane, sum > 0.f ? a[k] / sum : 0.f);
 }
 
 // ------------------------------------------------------------------ k_wide_score
@@ -220,7 +221,8 @@ __global__ __launch_bounds__(512) void k_wide_score(RowSet rs, ScorerW w, const 
   const float* Um = rs.U + bo + (size_t)st.slot_m * C * 64;
   const size_t star = (size_t)b * gridDim.y + st.mi;
   const float* Sr[PT];
-  const float* ap[PT];
+  size_t ap[PT];                                           // element offsets into the alpha planes
+  const long apl = (long)gridDim.z * gridDim.y * RP * RP;
   int rr[PT];
   float sgn[PT], score[PT];
   bool act[PT];
@@ -229,7 +231,7 @@ __global__ __launch_bounds__(512) void k_wide_score(RowSet rs, ScorerW w, const 
     const int t = wave + 8 * pt;
     rr[pt] = 16 * t + l15;
     Sr[pt] = rs.S + bo + (size_t)slot_of(rs, b, rr[pt] < n ? rr[pt] : 0) * C * 64;
-    ap[pt] = alpha + (star * RP + rr[pt]) * RP + 8 * kq;
+    ap[pt] = (star * RP + rr[pt]) * RP + 8 * kq;
     sgn[pt] = rr[pt] < st.m ? 1.0f : -1.0f;
     act[pt] = wide_tile_active(t, st.m, n, full);
     score[pt] = 0.f;
@@ -291,10 +293,8 @@ __global__ __launch_bounds__(512) void k_wide_score(RowSet rs, ScorerW w, const 
       // x_g^T = S^T alpha^T: k-slot 8kq + j of k-step ks = r' = 32ks + 8kq + j (alpha is exactly 0 beyond the rows)
 #pragma unroll 2
       for (int ks = 0; ks < KSX; ++ks) {
-        const f32x4 a0 = *reinterpret_cast<const f32x4*>(ap[pt] + 32 * ks);
-        const f32x4 a1 = *reinterpret_cast<const f32x4*>(ap[pt] + 32 * ks + 4);
         Frag3 bfr;
-        split_8(bfr, a0, a1);
+        alpha_frag16(bfr, alpha, apl, ap[pt] + 32 * ks);
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
           const int d = 16 * mt + l15;
