@@ -524,13 +524,16 @@ int launch_pair_scores(nnj_handle* h, const RowSet& rs, const int* ij_prev, cons
     if (has_ctx) {
       {
         Scope sc(h, st, PK_PAIR_ALPHA_INCR);
-        const size_t lds = (size_t)(2 * IMG64 + T16_WAVES * 512 * NPL + 16 + SCORER_CONSTS) * sizeof(float);
-#define NNJ_IA(NG)                                                                                          \
-  case NG:                                                                                                  \
-    if (int rc = set_lds(h, k_inc_alpha16<NG>, lds)) return rc;                                             \
-    hipLaunchKernelGGL((k_inc_alpha16<NG>), grid, blk16, lds, st, rs, sw, ij_prev, base + w.alpha_part, n, C, g.cs, h->d_flag); \
-    break;
-        switch (ng) { NNJ_IA(1) NNJ_IA(2) NNJ_IA(3) NNJ_IA(4) }
+        // 16 waves per workgroup (four per SIMD) for one and two tiles per site: 0.330 -> 0.290 and 0.656 -> 0.633 ms per
+        // launch; with three / four tiles the 128-register limit spills (1.06 -> 1.13, 1.33 -> 1.72 ms): 12 waves there
+#define NNJ_IA(NG, NW)                                                                                          \
+  case NG: {                                                                                                    \
+    const size_t lds = (size_t)(2 * IMG64 + NW * 512 * NPL + 16 + SCORER_CONSTS) * sizeof(float);              \
+    if (int rc = set_lds(h, (k_inc_alpha16<NG, NW>), lds)) return rc;                                           \
+    hipLaunchKernelGGL((k_inc_alpha16<NG, NW>), grid, dim3(64 * NW), lds, st, rs, sw, ij_prev, base + w.alpha_part, n, C, \
+                       g.cs, h->d_flag);                                                                        \
+  } break;
+        switch (ng) { NNJ_IA(1, 16) NNJ_IA(2, 16) NNJ_IA(3, 12) NNJ_IA(4, 12) }
 #undef NNJ_IA
       }
       {

@@ -62,12 +62,13 @@ constexpr int T16_WAVES = 12;
 // share a site: together they write its 16*NG S rows as a weight-like image [2 planes][16*NG r][64 d] (each
 // lane one 16-byte chunk per k-step and plane) and each multiplies its x' with all rows.
 // part[b][sc*NSLOT+slot][pair r][r'].
-template <int NG>
-__global__ __launch_bounds__(64 * T16_WAVES) void k_inc_alpha16(RowSet rs, ScorerW w, const int* __restrict__ ij_prev,
+// NW waves per workgroup: 12 (three per SIMD) or, where the registers allow it, 16 / 15 (four per SIMD).
+template <int NG, int NW = T16_WAVES>
+__global__ __launch_bounds__(64 * NW) void k_inc_alpha16(RowSet rs, ScorerW w, const int* __restrict__ ij_prev,
                                                                 float* __restrict__ alpha_part, int n, int C, int cs,
                                                                 int* __restrict__ status) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  constexpr int NSLOT = T16_WAVES / NG;
+  constexpr int NSLOT = NW / NG;
   constexpr int IMG = 16 * NG * 64 * NPL / 2;              // floats of an image
   float* At_l = smem;                                      // A^T, IMG64 floats
   float* Wh_l = smem + IMG64;                              // W_h
@@ -78,8 +79,8 @@ __global__ __launch_bounds__(64 * T16_WAVES) void k_inc_alpha16(RowSet rs, Score
   int* cnt0 = reinterpret_cast<int*>(smem + 2 * IMG64 + NSLOT * IMG);
   const int sc = blockIdx.x, b = blockIdx.y;
   const int c0 = sc * cs, c1 = min(C, c0 + cs);
-  stage_weight_t16(At_l, w.A, 64, tid, 64 * T16_WAVES, true);
-  stage_weight_t16(Wh_l, w.Wh, 64, tid, 64 * T16_WAVES);
+  stage_weight_t16(At_l, w.A, 64, tid, 64 * NW, true);
+  stage_weight_t16(Wh_l, w.Wh, 64, tid, 64 * NW);
   float* cv = smem + 2 * IMG64 + NSLOT * IMG + 16;
   stage_scorer_consts(cv, w, tid);
   if (tid < NSLOT) cnt0[tid] = 0;
@@ -147,7 +148,7 @@ __global__ __launch_bounds__(64 * T16_WAVES) void k_inc_alpha16(RowSet rs, Score
   // (fixed order: bitwise reproducible), the images are dead by then
   __syncthreads();
   float* red = smem + 2 * IMG64;                           // 4096 floats (NSLOT * IMG >= 12288)
-  for (int i = tid; i < 4096; i += 64 * T16_WAVES) red[i] = 0.f;
+  for (int i = tid; i < 4096; i += 64 * NW) red[i] = 0.f;
   __syncthreads();
   for (int s_ = 0; s_ < NSLOT; ++s_) {
     if (slot == s_) {
@@ -160,7 +161,7 @@ __global__ __launch_bounds__(64 * T16_WAVES) void k_inc_alpha16(RowSet rs, Score
     __syncthreads();
   }
   float* dst = alpha_part + ((size_t)b * gridDim.x + sc) * 4096;
-  for (int i = tid; i < 1024; i += 64 * T16_WAVES)
+  for (int i = tid; i < 1024; i += 64 * NW)
     reinterpret_cast<f32x4*>(dst)[i] = reinterpret_cast<const f32x4*>(red)[i];
 }
 
