@@ -12,7 +12,7 @@ import torch
 from . import weights as _weights
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libnnj_hip.so")
+LIB_PATH = os.environ.get("NNJ_LIB_PATH") or os.path.join(_HERE, "libnnj_hip.so")   # (override: A/B timing of two builds)
 
 _vp = C.c_void_p
 

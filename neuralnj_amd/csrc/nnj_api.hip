@@ -243,7 +243,7 @@ PairGeom pair_geom(int mode, int n, int B, int C) {
 
 // workspace regions of the NJ loop (after the state/slots buffer), in floats
 struct LoopWs {
-  size_t U, Kp, beta, alpha_part, alpha, score_part, full, agg_part, logits0, logits1, merged, live, ij, end;
+  size_t U, Kp, beta, alpha_part, alpha, score_part, full, agg_part, logits0, logits1, merged, live, ij, zmask, end;
 };
 LoopWs loop_ws(int B, int T, int C) {
   LoopWs w;
@@ -284,8 +284,20 @@ LoopWs loop_ws(int B, int T, int C) {
   w.merged = take((size_t)B * C * 64);
   w.live = take((size_t)B * T);
   w.ij = take((size_t)B * 2 + 2);
+  w.zmask = take(((size_t)B * C + 3) / 4);       // all-false site mask for callers that pass none (bytes)
   w.end = o;
   return w;
+}
+
+// the scorer kernels read the site mask unconditionally (no branch in their site loops): a caller without a mask
+// gets a zero-filled one from the workspace
+int scorer_mask(nnj_handle* h, const uint8_t* mask, float* base, const LoopWs& w, int B, int C, hipStream_t st,
+                const uint8_t** out) {
+  if (mask) { *out = mask; return NNJ_OK; }
+  uint8_t* z = reinterpret_cast<uint8_t*>(base + w.zmask);
+  HIPCHK(h, hipMemsetAsync(z, 0, (size_t)B * C, st));
+  *out = z;
+  return NNJ_OK;
 }
 
 // encoder scratch (floats, after the state): ctx | Q6 | K6 | V6 | S | M | key classes
@@ -558,7 +570,7 @@ int launch_pair_scores(nnj_handle* h, const RowSet& rs, const int* ij_prev, cons
                              base + w.score_part, n, C, g.cs);
         }
       } else if (n > 32 && n <= 48) {                      // three 16-row tiles: 48 instead of 64 padded pairs,
-        const size_t lds = (size_t)(3 * IMG64 + 8 * (64 * 48 * NPL / 2) + SCORER_CONSTS) * sizeof(float);   // one wave per site
+        const size_t lds = (size_t)(3 * IMG64 + 8 * (64 * 48 * NPL / 2) + SCORER_CONSTS + 3 * 1024) * sizeof(float);   // one wave per site; + alpha pieces
         if (int rc = set_lds(h, k_inc_score_w<3, true>, lds)) return rc;
         hipLaunchKernelGGL((k_inc_score_w<3, true>), grid, dim3(512), lds, st, rs, sw, ij_prev, base + w.alpha, mask,
                            base + w.score_part, n, C, g.cs);
@@ -828,6 +840,7 @@ int nnj_pair_scores_full(nnj_handle* h, const float* state, const uint8_t* mask,
   RowSet rs = dense_rowset(h, state, base, w, B, n, L, st);
   PairGeom g;
   int* ij = reinterpret_cast<int*>(base + w.ij);
+  if (int rc = scorer_mask(h, mask, base, w, B, L, st, &mask)) return rc;
   if (int rc = launch_pair_scores(h, rs, ij, mask, base, w, PAIRS_FULL, n, B, L, g, st)) return rc;
   {
     Scope sc(h, st, PK_ASSEMBLE);
@@ -853,6 +866,7 @@ int nnj_pair_scores_incr(nnj_handle* h, const float* state, const uint8_t* mask,
   RowSet rs = dense_rowset(h, state, base, w, B, n, L, st);
   PairGeom g;
   int* ij = reinterpret_cast<int*>(base + w.ij);
+  if (int rc = scorer_mask(h, mask, base, w, B, L, st, &mask)) return rc;
   if (int rc = launch_pair_scores(h, rs, ij_prev, mask, base, w, PAIRS_INCR, n, B, L, g, st)) return rc;
   {
     Scope sc(h, st, PK_ASSEMBLE);
@@ -969,6 +983,7 @@ int nnj_step(nnj_handle* h, const float* state, const uint8_t* mask, const int32
   }
   // decode_zxr (model.py:184-201 + utils.py:213-251) and the argmax (finetune_rl_search.py:145,159-160)
   PairGeom g;
+  if (int rc = scorer_mask(h, mask, base, w, B, C, st, &mask)) return rc;
   if (int rc = launch_pair_scores(h, rs, ijs, mask, base, w, PAIRS_INCR, n, B, C, g, st)) return rc;
   {
     Scope sc(h, st, PK_ASSEMBLE);
@@ -1006,6 +1021,7 @@ static int rollout_core(nnj_handle* h, const uint8_t* codes, const uint8_t* mask
     }
   }
   if (state_out) HIPCHK(h, hipMemcpyAsync(state_out, S, (size_t)B * T * C * 64 * sizeof(float), hipMemcpyDeviceToDevice, st));
+  if (int rc = scorer_mask(h, mask, base, w, B, C, st, &mask)) return rc;      // (after the encoder: the region is its scratch)
   int* live = reinterpret_cast<int*>(base + w.live);
   int* ij = reinterpret_cast<int*>(base + w.ij);
   {

@@ -224,6 +224,7 @@ __global__ __launch_bounds__(64 * T16_WAVES) void k_inc_score16(RowSet rs, Score
     asm volatile("" ::: "memory");
     const bool act = c_ < c1;
     const int c = act ? c_ : c1 - 1;
+    const float mc = (!act || mask[(size_t)b * C + c]) ? 0.f : 1.f;      // seq_mask (model.py:96); first load of the iteration
     // no register prefetch of the next site: three waves per SIMD hide the row loads, and the 32 registers
     // would push the kernel over the 168 of that occupancy
     V64 sr;
@@ -277,7 +278,6 @@ __global__ __launch_bounds__(64 * T16_WAVES) void k_inc_score16(RowSet rs, Score
         }
       if constexpr (NG > 1) __syncthreads();                     // all columns are in the image
     }
-    const float mc = (!act || (mask && mask[(size_t)b * C + c])) ? 0.f : 1.f;      // seq_mask (model.py:96)
     if constexpr (CTX) {
       V64 xg, g;
 #pragma unroll
@@ -370,11 +370,23 @@ __global__ __launch_bounds__(512) void k_inc_score_w(RowSet rs, ScorerW w, const
   stage_weight_t16(Wh_l, w.Wh, 64, tid, 64 * NW);
   float* cv = smem + 3 * IMG64 + NW * IMG;
   stage_scorer_consts(cv, w, tid);
+  // the alpha pieces of this alignment's pairs sit in LDS for the lifetime of the workgroup (two planes of
+  // [16 NT pairs][64 r'] fp16, 16-byte chunks XOR-swizzled by the pair): read from L2 per tile and site they were
+  // one exposed round trip in front of every tile's chain
+  const long apl = (long)gridDim.y * 4096;
+  constexpr int APL = 16 * NT * 64;                        // fp16 elements of a plane in LDS
+  unsigned short* alds = reinterpret_cast<unsigned short*>(cv + SCORER_CONSTS);
+  if constexpr (CTX) {
+    const unsigned short* ag = reinterpret_cast<const unsigned short*>(alpha) + (size_t)b * 4096;
+    for (int i = tid; i < 2 * 16 * NT * 8; i += 64 * NW) {             // 16-byte chunks of both planes
+      const int pl = i / (16 * NT * 8), rc = i % (16 * NT * 8), r = rc >> 3, ch = rc & 7;
+      *reinterpret_cast<u32x4*>(alds + pl * APL + r * 64 + 8 * (ch ^ (r & 7))) =
+          *reinterpret_cast<const u32x4*>(ag + pl * apl + r * 64 + 8 * ch);
+    }
+  }
   __syncthreads();
   const size_t bo = (size_t)b * rs.bstride;
   const float* Sr[NT];
-  size_t ap[NT];                                           // element offsets into the alpha planes
-  const long apl = (long)gridDim.y * 4096;
   float sgn[NT], score[NT];
   int rr[NT];
   const float *Sm, *Um;
@@ -382,7 +394,7 @@ __global__ __launch_bounds__(512) void k_inc_score_w(RowSet rs, ScorerW w, const
   for (int t = 0; t < NT; ++t) {
     const Inc16 L = inc16(rs, ij_prev, b, n, 16 * t + l15);
     Sr[t] = rs.S + bo + (size_t)L.slot_r * C * 64;
-    ap[t] = ((size_t)b * 64 + L.r) * 64 + 8 * kq;
+
     sgn[t] = L.sgn;
     rr[t] = L.r;
     score[t] = 0.f;
@@ -398,6 +410,7 @@ __global__ __launch_bounds__(512) void k_inc_score_w(RowSet rs, ScorerW w, const
   const u32x4* wh4 = reinterpret_cast<const u32x4*>(Wh_l);
   for (int c = c0 + wave; c < c1; c += NW) {
     asm volatile("" ::: "memory");
+    const float mc = mask[(size_t)b * C + c] ? 0.f : 1.f;               // seq_mask (model.py:96); first load of the iteration
     V64 x[NT];
     {
       V64 sr[NT], sm, um;
@@ -445,7 +458,6 @@ __global__ __launch_bounds__(512) void k_inc_score_w(RowSet rs, ScorerW w, const
         __builtin_amdgcn_sched_barrier(0);
       }
     }
-    const float mc = (mask && mask[(size_t)b * C + c]) ? 0.f : 1.f;      // seq_mask (model.py:96)
     // x_g^T = S^T alpha^T, W_g, mix, s_out per tile.  Image rows are 16*NT fp16 (96 bytes at NT = 3: rows d and
     // d+8 share banks, the 16 lanes of a read group hold 8 distinct d per chunk parity -- conflict free without
     // a swizzle).  Lanes whose chunk lies beyond a short row read the row's last chunk: finite data against
@@ -459,7 +471,12 @@ __global__ __launch_bounds__(512) void k_inc_score_w(RowSet rs, ScorerW w, const
 #pragma unroll
         for (int ks = 0; ks < KSX; ++ks) {
           Frag3 bfr;
-          alpha_frag16(bfr, alpha, apl, ap[t] + 32 * ks);
+          {
+            const int ar = 16 * t + l15;
+            const unsigned short* ap_ = alds + ar * 64 + 8 * ((4 * ks + kq) ^ (ar & 7));
+            bfr.h = *reinterpret_cast<const u32x4*>(ap_);
+            bfr.m = *reinterpret_cast<const u32x4*>(ap_ + APL);
+          }
           const int lc = min(4 * ks + kq, CH - 1);
 #pragma unroll
           for (int mt = 0; mt < 4; ++mt) {

@@ -242,6 +242,7 @@ __global__ __launch_bounds__(512) void k_wide_score(RowSet rs, ScorerW w, const 
   __syncthreads();
   for (int c = c0; c < c1; ++c) {
     asm volatile("" ::: "memory");
+    const float mc = mask[(size_t)b * C + c] ? 0.f : 1.f;                // seq_mask (model.py:96); first load of the iteration
     V64 x[PT];
     V64 sm, um;
     load_v64(sm, Sm + (size_t)c * 64, kq);
@@ -283,7 +284,6 @@ __global__ __launch_bounds__(512) void k_wide_score(RowSet rs, ScorerW w, const 
       gate16(x[pt], sr, ur, sm, um, cv, sgn[pt], kq);
     }
     __syncthreads();                                       // all RP columns are in the image
-    const float mc = (mask && mask[(size_t)b * C + c]) ? 0.f : 1.f;      // seq_mask (model.py:96)
 #pragma unroll
     for (int pt = 0; pt < PT; ++pt) {
       if (!act[pt]) continue;                              // wave-uniform
