@@ -88,38 +88,39 @@ __device__ __forceinline__ void site_offsets(SiteOff<NTHR>& O, const RowSet& rs,
 template <bool WITH_A, int NTHR>
 __device__ __forceinline__ void site_load(SiteRegs<NTHR>& R, const SiteOff<NTHR>& O, const RowSet& rs, int n, int c,
                                           const float* srcA, int tid) {
+  // loads only: the values are not touched here (rows >= n read row 0, always there; they are zeroed in site_store).
+  // A select on the loaded value at this point is a USE: the compiler then waits for the loads right here and the
+  // next site's rows are not in flight behind the MFMAs of the current one at all (it did: `s_waitcnt vmcnt(0)`
+  // straight after the loads in the ISA of both step-0 kernels).
 #pragma unroll
   for (int k = 0; k < 1024 / NTHR; ++k) {
-    const int i = tid + NTHR * k;
-    const int r = i >> 4;
-    const bool live = r < n;                  // rows >= n: load row 0 (always there) and zero by select
     const size_t off = O.base[k] + (size_t)c * 64;
-    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-    const f32x4 vs = *reinterpret_cast<const f32x4*>(rs.S + off);
-    const f32x4 vu = *reinterpret_cast<const f32x4*>(rs.U + off);
-    R.s[k] = live ? vs : z;
-    R.u[k] = live ? vu : z;
-    R.a[k] = z;
-    if (WITH_A) { const f32x4 va = *reinterpret_cast<const f32x4*>(srcA + off); R.a[k] = live ? va : z; }
+    R.s[k] = *reinterpret_cast<const f32x4*>(rs.S + off);
+    R.u[k] = *reinterpret_cast<const f32x4*>(rs.U + off);
+    if (WITH_A) R.a[k] = *reinterpret_cast<const f32x4*>(srcA + off);
   }
 }
 template <bool WITH_A, bool WITH_T, int NTHR>
 __device__ __forceinline__ void site_store(const SiteRegs<NTHR>& R, float* img_a, float* img_s, float* img_u,
-                                           float* img_t, int tid) {
+                                           float* img_t, int tid, int n) {
 #pragma unroll
   for (int k = 0; k < 1024 / NTHR; ++k) {
     const int i = tid + NTHR * k;
     const int r = i >> 4, ch = i & 15;
     const int sw = 4 * wswz(r, ch);
-    *reinterpret_cast<f32x4*>(img_s + r * 64 + sw) = R.s[k];
-    *reinterpret_cast<f32x4*>(img_u + r * 64 + sw) = R.u[k];
+    const bool live = r < n;
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    const f32x4 vs = live ? R.s[k] : z, vu = live ? R.u[k] : z;
+    *reinterpret_cast<f32x4*>(img_s + r * 64 + sw) = vs;
+    *reinterpret_cast<f32x4*>(img_u + r * 64 + sw) = vu;
     if (WITH_A) {
+      const f32x4 va = live ? R.a[k] : z;
       // K' as an f16x3 A image [2 planes][64 rows r][64 d] (the layout of stage_weight_b6): this thread's four
       // features d = 4ch..4ch+3 are one half of chunk q = 4*kt + 2*G + hh  (d = 32kt + 16G + 8j + 4hh + t)
       const int q = 4 * (ch >> 3) + 2 * ((ch >> 2) & 1) + (ch & 1), j = (ch >> 1) & 1;
       unsigned h01, m01, h23, m23;
-      split2(R.a[k][0], R.a[k][1], h01, m01);
-      split2(R.a[k][2], R.a[k][3], h23, m23);
+      split2(va[0], va[1], h01, m01);
+      split2(va[2], va[3], h23, m23);
       uint2* img = reinterpret_cast<uint2*>(img_a) + (r * 8 + wswz6<8>(r, q)) * 2 + j;   // 8-byte units
       img[0] = make_uint2(h01, h23);
       img[64 * 8 * 2] = make_uint2(m01, m23);
@@ -131,7 +132,7 @@ __device__ __forceinline__ void site_store(const SiteRegs<NTHR>& R, float* img_a
 #pragma unroll
       for (int pr = 0; pr < 2; ++pr) {
         unsigned h, m;
-        split2(R.s[k][2 * pr], R.s[k][2 * pr + 1], h, m);
+        split2(vs[2 * pr], vs[2 * pr + 1], h, m);
         const int d0 = 4 * ch + 2 * pr, d1 = d0 + 1;
         const int o0 = d0 * 64 + 8 * wswz6<8>(d0, q) + e, o1 = d1 * 64 + 8 * wswz6<8>(d1, q) + e;
         t16[o0] = (unsigned short)h; t16[o1] = (unsigned short)(h >> 16);
@@ -212,7 +213,7 @@ __global__ __launch_bounds__(64 * NW) void k_pair_alpha(RowSet rs, ScorerW w, co
   site_offsets<64 * NW>(RO, rs, b, n, C, tid);
   if (c0 < c1) {
     site_load<true, 64 * NW>(R, RO, rs, n, c0, rs.Kp, tid);
-    site_store<true, false, 64 * NW>(R, smem, smem + IMG64, smem + IMG64 + 4096, nullptr, tid);
+    site_store<true, false, 64 * NW>(R, smem, smem + IMG64, smem + IMG64 + 4096, nullptr, tid, n);
   }
   __syncthreads();
   for (int c = c0; c < c1; ++c) {
@@ -228,7 +229,7 @@ __global__ __launch_bounds__(64 * NW) void k_pair_alpha(RowSet rs, ScorerW w, co
         linear6_T_acc<2, 2, 1, true>(acc[tt], x, cur, lane);
       }
     }
-    if (more) site_store<true, false, 64 * NW>(R, nxt, nxt + IMG64, nxt + IMG64 + 4096, nullptr, tid);
+    if (more) site_store<true, false, 64 * NW>(R, nxt, nxt + IMG64, nxt + IMG64 + 4096, nullptr, tid, n);
     __syncthreads();
   }
 #pragma unroll
@@ -327,7 +328,7 @@ __global__ __launch_bounds__(64 * NW) void k_pair_score(RowSet rs, ScorerW w, co
   site_offsets<64 * NW>(RO, rs, b, n, C, tid);
   if (c0 < c1) {
     site_load<false, 64 * NW>(R, RO, rs, n, c0, nullptr, tid);
-    site_store<false, true, 64 * NW>(R, nullptr, ring + IMG64, ring + IMG64 + 4096, ring, tid);
+    site_store<false, true, 64 * NW>(R, nullptr, ring + IMG64, ring + IMG64 + 4096, ring, tid, n);
   }
   __syncthreads();
   for (int c = c0; c < c1; ++c) {
@@ -374,7 +375,7 @@ __global__ __launch_bounds__(64 * NW) void k_pair_score(RowSet rs, ScorerW w, co
         score[tt] += (s + w.s2b) * mc;
       }
     }
-    if (more) site_store<false, true, 64 * NW>(R, nullptr, nxt + IMG64, nxt + IMG64 + 4096, nxt, tid);
+    if (more) site_store<false, true, 64 * NW>(R, nullptr, nxt + IMG64, nxt + IMG64 + 4096, nxt, tid, n);
     __syncthreads();
   }
   if (hh == 0) {
