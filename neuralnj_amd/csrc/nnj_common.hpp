@@ -57,21 +57,25 @@ __device__ __forceinline__ float sigmoidf_(float x) {
 // sigmoid of t given xs = -log2(e) * t (the scorer's W_h, b_h, W_g, b_g are stored pre-scaled): one
 // multiplication less per element in kernels that are bound by vector issue
 __device__ __forceinline__ float sigmoid_l2(float xs) { return nnj_rcp(1.0f + __builtin_amdgcn_exp2f(xs)); }
-// nn.GELU() default (exact erf form), select free:  x Phi(x) = max(x, 0) - |x| h(|x|),
+// nn.GELU() default (exact erf form), select free:  x Phi(x) = x/2 + |x| (1/2 - h(|x|)),
 // h(a) = erfc(a / sqrt2) / 2 by Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7 on erfc, a few fp32 ulps of the
-// result) with the polynomial coefficients halved: 17 vector instructions.
+// result) with the polynomial coefficients halved: 11 vector + 2 transcendental instructions (|x| is a source
+// modifier).  The earlier form max(x, 0) - |x| h cost four more: fmaxf on a matrix-pipe result gets a
+// canonicalising v_max in front of it, and its explicit z = |x| / sqrt2 one multiplication.  Measured with GELU
+// knocked out (results wrong, time only): k_ffn16 24.4 -> 16.4 ms, k_pair_score 35.4 -> 28.0, incremental scores
+// 59.1 -> 49.3 per rollout of 256 -- these kernels are bound by vector issue, every instruction here counts.
 __device__ __forceinline__ float gelu_erf(float x) {
   const float ax = fabsf(x);
-  const float z = ax * 0.70710678118654752440f;
-  const float t = nnj_rcp(1.0f + 0.3275911f * z);
+  const float t = nnj_rcp(ax * (0.3275911f * 0.70710678118654752440f) + 1.0f);
   float p = 0.5f * 1.061405429f;
   p = p * t - 0.5f * 1.453152027f;
   p = p * t + 0.5f * 1.421413741f;
   p = p * t - 0.5f * 0.284496736f;
   p = p * t + 0.5f * 0.254829592f;
-  const float e = __builtin_amdgcn_exp2f((z * z) * -1.4426950408889634f);
-  const float h = (p * t) * e;                              // erfc(|x|/sqrt2) / 2
-  return fmaxf(x, 0.f) - ax * h;
+  const float y = ax * 0.84932180028801904272f;             // sqrt(log2(e) / 2): exp(-x^2 / 2) = exp2(-y^2)
+  const float e = __builtin_amdgcn_exp2f(-(y * y));
+  const float q = 0.5f - (p * t) * e;                       // 1/2 - erfc(|x|/sqrt2) / 2
+  return ax * q + 0.5f * x;
 }
 
 // ---- LDS-DMA: 16 bytes per lane HBM -> LDS with no register staging (global_load_lds_dwordx4).
@@ -594,6 +598,62 @@ __device__ __forceinline__ void linear_t16(f32x4 (&out)[MT], const V64& in, cons
       out[mt] = mfma16_b6(a, b, out[mt]);
     }
     __builtin_amdgcn_sched_barrier(0);
+  });
+}
+
+// The same product with the weight fragments READ BY HAND, PF (k-step, row tile) steps (2: measured against 3 and 4, which cost registers) ahead of the MFMAs that use
+// them.  The compiler's own schedule issues each ds_read_b128 pair right in front of its three MFMAs and waits for
+// it at once (lgkmcnt(0) some 40 times per tile and site in the pair-scorer chains): with two or three waves per
+// SIMD that LDS latency is the largest single stall of those kernels.  Here the reads of step s + PF are issued
+// behind the MFMAs of step s and the wait in front of step s is counted.  `bfr[ks]` = the B fragments (the caller
+// splits; fragments that exist already -- the S rows of the scorer -- are passed as they are).
+// Only for images that are complete before the call and are not written while it runs (weights staged once per
+// workgroup): the compiler does not order its own LDS stores against these asm reads.
+template <int MT, int PF = 2, typename PRE>
+__device__ __forceinline__ void linear_t16p_core(f32x4 (&out)[MT], const Frag3 (&bfr)[2], const float* W, int lane,
+                                                 PRE&& pre) {
+  const int l15 = lane & 15, kq = lane >> 4;
+  constexpr int NS = 2 * MT;
+  constexpr int PLANE = 16 * MT * 8 * 16;                  // bytes
+  const int sw = (l15 >> 1) & 7;                           // wswz6<8>(16 mt + l15, q) = q ^ ((l15 >> 1) & 7) for every mt
+  const unsigned ad[2] = {lds_addr(W) + (unsigned)(l15 * 8 + (kq ^ sw)) * 16u,
+                          lds_addr(W) + (unsigned)(l15 * 8 + ((4 + kq) ^ sw)) * 16u};
+  Frag3 a[PF];
+  auto issue = [&](auto si) {
+    constexpr int s = decltype(si)::value;
+    if constexpr (s < NS) {
+      constexpr int ks = s / MT, mt = s % MT;
+      lds_read_frag<mt * 2048>(a[s % PF].h, ad[ks]);
+      lds_read_frag<mt * 2048 + PLANE>(a[s % PF].m, ad[ks]);
+    }
+  };
+  static_for<0, PF>([&](auto si) { issue(si); });
+  pre();                                                   // the caller's work that hides the first reads' latency (operand split)
+  static_for<0, NS>([&](auto si) {
+    constexpr int s = decltype(si)::value;
+    constexpr int ks = s / MT, mt = s % MT;
+    constexpr int ahead = (s + PF - 1 < NS - 1 ? s + PF - 1 : NS - 1) - s;      // steps whose reads are younger than step s
+    lds_wait_le<2 * ahead>();
+    pin_frag(a[s % PF]);
+    out[mt] = mfma16_b6(a[s % PF], bfr[ks], out[mt]);
+    issue(std::integral_constant<int, s + PF>{});
+  });
+}
+template <int MT, bool ACC, bool BIAS = true, int PF = 2>
+__device__ __forceinline__ void linear_t16p(f32x4 (&out)[MT], const V64& in, const float* W, const float* bias,
+                                            int lane) {
+  const int kq = lane >> 4;
+  if constexpr (!ACC) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      if constexpr (BIAS) out[mt] = *reinterpret_cast<const f32x4*>(bias + 16 * mt + 4 * kq);
+      else out[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+  }
+  Frag3 b[2];
+  linear_t16p_core<MT, PF>(out, b, W, lane, [&] {
+    split_8(b[0], in.t[0], in.t[1]);
+    split_8(b[1], in.t[2], in.t[3]);
   });
 }
 

@@ -115,19 +115,7 @@ __global__ __launch_bounds__(64 * NW) void k_inc_alpha16(RowSet rs, ScorerW w, c
       load_v64(um, Um + (size_t)c * 64, kq);
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt) ur.t[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      const u32x4* wh4 = reinterpret_cast<const u32x4*>(Wh_l);
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
-          const int row = 16 * mt + l15;
-          const int o = row * 8 + wswz6<8>(row, 4 * ks + kq);
-          Frag3 a;
-          a.h = wh4[o]; a.m = wh4[64 * 8 + o];
-          ur.t[mt] = mfma16_b6(a, sf[ks], ur.t[mt]);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      }
+      linear_t16p_core<4>(ur.t, sf, Wh_l, lane, [] {});
       gate16(x, sr, ur, sm, um, cv, L.sgn, kq);
     }
     if constexpr (NG > 1) group_barrier_lds<NG>(cnt, epoch, status);     // everyone is done with the previous image
@@ -141,7 +129,7 @@ __global__ __launch_bounds__(64 * NW) void k_inc_alpha16(RowSet rs, ScorerW w, c
     const int cn = c + NSLOT < c1 ? c + NSLOT : c;               // prefetch behind the MFMAs (last: harmless reload)
     load_v64(sr, Sr + (size_t)cn * 64, kq);
     V64 xp;
-    linear_t16<4, false, false>(xp.t, x, At_l, nullptr, lane);          // x' = A^T x
+    linear_t16p<4, false, false>(xp.t, x, At_l, nullptr, lane);          // x' = A^T x
     linear_t16<NG, true, false>(acc, xp, img, nullptr, lane);           // acc[r'][pair] += S_r' . x'
   }
   // one partial set per WORKGROUP: the slots add their tiles into one LDS tile [64 pairs][64 r'] in slot order
@@ -248,19 +236,7 @@ __global__ __launch_bounds__(64 * T16_WAVES) void k_inc_score16(RowSet rs, Score
       load_v64(um, Um + (size_t)c * 64, kq);
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt) ur.t[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      const u32x4* wh4 = reinterpret_cast<const u32x4*>(Wh_l);
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
-          const int row = 16 * mt + l15;
-          const int o = row * 8 + wswz6<8>(row, 4 * ks + kq);
-          Frag3 a;
-          a.h = wh4[o]; a.m = wh4[64 * 8 + o];
-          ur.t[mt] = mfma16_b6(a, sf[ks], ur.t[mt]);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      }
+      linear_t16p_core<4>(ur.t, sf, Wh_l, lane, [] {});
       gate16(x, sr, ur, sm, um, cv, L.sgn, kq);
     }
     if constexpr (CTX) {
@@ -298,7 +274,7 @@ __global__ __launch_bounds__(64 * T16_WAVES) void k_inc_score16(RowSet rs, Score
         }
         __builtin_amdgcn_sched_barrier(0);
       });
-      linear_t16<4, false>(g.t, xg, Wg_l, cv + 64, lane);
+      linear_t16p<4, false>(g.t, xg, Wg_l, cv + 64, lane);
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
@@ -309,7 +285,7 @@ __global__ __launch_bounds__(64 * T16_WAVES) void k_inc_score16(RowSet rs, Score
         }
     }
     V64 s1;
-    linear_t16<4, false>(s1.t, x, S0_l, cv + 128, lane);
+    linear_t16p<4, false>(s1.t, x, S0_l, cv + 128, lane);
     float s = 0.f;
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
@@ -407,7 +383,6 @@ __global__ __launch_bounds__(512) void k_inc_score_w(RowSet rs, ScorerW w, const
   auto wsw = [](int d, int chunk) { if constexpr (NT == 3) return chunk; else return tswz<NT>(d, chunk); };
   unsigned short* t16 = reinterpret_cast<unsigned short*>(img);
   const u32x4* im4 = reinterpret_cast<const u32x4*>(img);
-  const u32x4* wh4 = reinterpret_cast<const u32x4*>(Wh_l);
   for (int c = c0 + wave; c < c1; c += NW) {
     asm volatile("" ::: "memory");
     const float mc = mask[(size_t)b * C + c] ? 0.f : 1.f;               // seq_mask (model.py:96); first load of the iteration
@@ -428,16 +403,7 @@ __global__ __launch_bounds__(512) void k_inc_score_w(RowSet rs, ScorerW w, const
         V64 ur;
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) ur.t[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-          for (int mt = 0; mt < 4; ++mt) {
-            const int row = 16 * mt + l15;
-            const int o = row * 8 + wswz6<8>(row, 4 * ks + kq);
-            Frag3 a;
-            a.h = wh4[o]; a.m = wh4[64 * 8 + o];
-            ur.t[mt] = mfma16_b6(a, sf[ks], ur.t[mt]);
-          }
+        linear_t16p_core<4>(ur.t, sf, Wh_l, lane, [] {});
         gate16(x[t], sr[t], ur, sm, um, cv, sgn[t], kq);
         if constexpr (CTX) {
           const int wchunk = 2 * t + (l15 >> 3), we = l15 & 7;
@@ -487,7 +453,7 @@ __global__ __launch_bounds__(512) void k_inc_score_w(RowSet rs, ScorerW w, const
             xg.t[mt] = mfma16_b6(a, bfr, xg.t[mt]);
           }
         }
-        linear_t16<4, false>(g.t, xg, Wg_l, cv + 64, lane);
+        linear_t16p<4, false>(g.t, xg, Wg_l, cv + 64, lane);
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
@@ -497,7 +463,7 @@ __global__ __launch_bounds__(512) void k_inc_score_w(RowSet rs, ScorerW w, const
           }
       }
       V64 s1;
-      linear_t16<4, false>(s1.t, x[t], S0_l, cv + 128, lane);
+      linear_t16p<4, false>(s1.t, x[t], S0_l, cv + 128, lane);
       float s = 0.f;
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt) {
