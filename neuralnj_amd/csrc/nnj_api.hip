@@ -282,7 +282,7 @@ LoopWs loop_ws(int B, int T, int C) {
   w.logits0 = take((size_t)B * T * (T - 1) / 2 + 1);
   w.logits1 = take((size_t)B * T * (T - 1) / 2 + 1);
   w.merged = take((size_t)B * C * 64);
-  w.live = take((size_t)B * T);
+  w.live = take((size_t)2 * B * T);            // two lists (current / next step)
   w.ij = take((size_t)B * 2 + 2);
   w.zmask = take(((size_t)B * C + 3) / 4);       // all-false site mask for callers that pass none (bytes)
   w.end = o;
@@ -661,6 +661,14 @@ int need_ws(nnj_handle* h, void* ws, size_t ws_bytes, int B, int T, int C) {
   return NNJ_OK;
 }
 
+// Every entry point selects the handle's device; the caller's current device (torch's, in a single process that drives
+// several GPUs) is put back when the call returns.
+struct DevGuard {
+  int prev = -1;
+  DevGuard() { if (hipGetDevice(&prev) != hipSuccess) prev = -1; }
+  ~DevGuard() { int cur = -1; if (prev >= 0 && hipGetDevice(&cur) == hipSuccess && cur != prev) (void)hipSetDevice(prev); }
+};
+
 int ready(nnj_handle* h) {
   if (!h) return fail(nullptr, NNJ_ERR_ARG, "null handle");
   if (!h->have_w) return fail(h, NNJ_ERR_NO_WEIGHTS, "weights not loaded");
@@ -730,6 +738,7 @@ int nnj_load_weights(nnj_handle* h, const float* p, size_t n) {
   if (!h || !p) return fail(h, NNJ_ERR_ARG, "nnj_load_weights: null argument");
   const size_t need = count_params(h->cfg);
   if (n != need) return fail(h, NNJ_ERR_ARG, "nnj_load_weights: got %zu floats, config needs %zu", n, need);
+  DevGuard dev_guard;
   HIPCHK(h, hipSetDevice(h->cfg.device));
   const size_t D = NNJ_D, F = NNJ_F;
   size_t o = 0;
@@ -818,6 +827,7 @@ int nnj_workspace_bytes(const nnj_handle* h, int32_t B, int32_t T, int32_t L, si
 
 int nnj_encode(nnj_handle* h, const uint8_t* codes, const float* onehot, const uint8_t* mask, float* state_out,
                int32_t B, int32_t T, int32_t L, void* ws, size_t ws_bytes, void* stream) {
+  DevGuard dev_guard;
   if (int rc = ready(h)) return rc;
   if ((!codes && !onehot) || (codes && onehot) || !state_out)
     return fail(h, NNJ_ERR_ARG, "nnj_encode: exactly one of codes / onehot, and an output buffer, are required");
@@ -830,6 +840,7 @@ int nnj_encode(nnj_handle* h, const uint8_t* codes, const float* onehot, const u
 
 int nnj_pair_scores_full(nnj_handle* h, const float* state, const uint8_t* mask, float* logits_out, int32_t B,
                          int32_t n, int32_t L, void* ws, size_t ws_bytes, void* stream) {
+  DevGuard dev_guard;
   if (int rc = ready(h)) return rc;
   if (!state || !logits_out || n < 2) return fail(h, NNJ_ERR_ARG, "nnj_pair_scores_full: bad argument");
   if (int rc = check_shape(h, B, n, L)) return rc;
@@ -847,7 +858,7 @@ int nnj_pair_scores_full(nnj_handle* h, const float* state, const uint8_t* mask,
     hipLaunchKernelGGL(k_assemble_argmax, dim3((unsigned)B), dim3(256), 0, st, g.score_src, g.nsc, g.ppad,
                        (const float*)nullptr, (const int*)nullptr, logits_out, (float*)nullptr, 0L, (const int*)nullptr,
                        0L, (int*)nullptr, 0L, (float*)nullptr, 0L, ij, (int)PAIRS_FULL, n, (const float*)nullptr, 0L, 1.0f,
-                       h->d_flag);
+                       h->d_flag, (const int*)nullptr, (int*)nullptr, 0);
   }
   HIPCHK(h, hipGetLastError());
   return NNJ_OK;
@@ -856,6 +867,7 @@ int nnj_pair_scores_full(nnj_handle* h, const float* state, const uint8_t* mask,
 int nnj_pair_scores_incr(nnj_handle* h, const float* state, const uint8_t* mask, const int32_t* ij_prev,
                          const float* logits_prev, float* logits_out, int32_t B, int32_t n, int32_t L, void* ws,
                          size_t ws_bytes, void* stream) {
+  DevGuard dev_guard;
   if (int rc = ready(h)) return rc;
   if (!state || !ij_prev || !logits_prev || !logits_out || n < 2) return fail(h, NNJ_ERR_ARG, "nnj_pair_scores_incr: bad argument");
   if (int rc = check_shape(h, B, n + 1, L)) return rc;
@@ -872,7 +884,8 @@ int nnj_pair_scores_incr(nnj_handle* h, const float* state, const uint8_t* mask,
     Scope sc(h, st, PK_ASSEMBLE);
     hipLaunchKernelGGL(k_assemble_argmax, dim3((unsigned)B), dim3(256), 0, st, g.score_src, g.nsc, g.ppad,
                        logits_prev, ij_prev, logits_out, (float*)nullptr, 0L, (const int*)nullptr, 0L, (int*)nullptr, 0L,
-                       (float*)nullptr, 0L, ij, (int)PAIRS_INCR, n, (const float*)nullptr, 0L, 1.0f, h->d_flag);
+                       (float*)nullptr, 0L, ij, (int)PAIRS_INCR, n, (const float*)nullptr, 0L, 1.0f, h->d_flag,
+                       (const int*)nullptr, (int*)nullptr, 0);
   }
   HIPCHK(h, hipGetLastError());
   return NNJ_OK;
@@ -880,6 +893,7 @@ int nnj_pair_scores_incr(nnj_handle* h, const float* state, const uint8_t* mask,
 
 int nnj_score_index_map(nnj_handle* h, const int32_t* ij_prev, int64_t* idx_out, int32_t B, int32_t n, void* stream) {
   if (!h) return fail(nullptr, NNJ_ERR_ARG, "null handle");
+  DevGuard dev_guard;
   HIPCHK(h, hipSetDevice(h->cfg.device));
   if (!ij_prev || !idx_out || B <= 0 || n < 2) return fail(h, NNJ_ERR_ARG, "nnj_score_index_map: bad argument");
   const long total = (long)B * (n * (n - 1) / 2);
@@ -891,6 +905,7 @@ int nnj_score_index_map(nnj_handle* h, const int32_t* ij_prev, int64_t* idx_out,
 
 int nnj_aggregate(nnj_handle* h, const float* state, const int32_t* ij, float* out_row, int32_t B, int32_t n,
                   int32_t L, void* ws, size_t ws_bytes, void* stream) {
+  DevGuard dev_guard;
   if (int rc = ready(h)) return rc;
   if (!state || !ij || !out_row || n < 2) return fail(h, NNJ_ERR_ARG, "nnj_aggregate: bad argument");
   if (int rc = check_shape(h, B, n, L)) return rc;
@@ -906,6 +921,7 @@ int nnj_aggregate(nnj_handle* h, const float* state, const int32_t* ij, float* o
 
 int nnj_env_step(nnj_handle* h, const float* state, const int32_t* ij, float* state_out, int32_t B, int32_t n,
                  int32_t L, void* ws, size_t ws_bytes, void* stream) {
+  DevGuard dev_guard;
   if (int rc = ready(h)) return rc;
   if (!state || !ij || !state_out || n < 3) return fail(h, NNJ_ERR_ARG, "nnj_env_step: bad argument (n must be >= 3)");
   if (int rc = check_shape(h, B, n, L)) return rc;
@@ -929,6 +945,7 @@ int nnj_env_step(nnj_handle* h, const float* state, const int32_t* ij, float* st
 int nnj_select_pair(nnj_handle* h, const float* logits, int32_t* ij_out, float* top2_gap, int32_t B, int32_t n,
                     void* stream) {
   if (!h) return fail(nullptr, NNJ_ERR_ARG, "null handle");
+  DevGuard dev_guard;
   HIPCHK(h, hipSetDevice(h->cfg.device));
   if (!logits || !ij_out || B <= 0 || n < 2) return fail(h, NNJ_ERR_ARG, "nnj_select_pair: bad argument");
   hipStream_t st = static_cast<hipStream_t>(stream);
@@ -941,6 +958,7 @@ int nnj_select_pair(nnj_handle* h, const float* logits, int32_t* ij_out, float* 
 int nnj_step(nnj_handle* h, const float* state, const uint8_t* mask, const int32_t* ij, const float* logits_prev,
              const int32_t* forced_next, float* state_out, float* logits_out, int32_t* chosen_ij, float* top2_gap,
              int32_t B, int32_t n, int32_t L, void* ws, size_t ws_bytes, void* stream) {
+  DevGuard dev_guard;
   if (int rc = ready(h)) return rc;
   if (!state || !ij || !logits_prev || !state_out || !logits_out || !chosen_ij || n < 2)
     return fail(h, NNJ_ERR_ARG, "nnj_step: bad argument (n = rows after the merge, >= 2)");
@@ -989,7 +1007,8 @@ int nnj_step(nnj_handle* h, const float* state, const uint8_t* mask, const int32
     Scope sc(h, st, PK_ASSEMBLE);
     hipLaunchKernelGGL(k_assemble_argmax, dim3((unsigned)B), dim3(256), 0, st, g.score_src, g.nsc, g.ppad, logits_prev,
                        (const int*)ijs, logits_out, (float*)nullptr, 0L, forced_next, 2L, (int*)nullptr, 0L, top2_gap, 1L,
-                       chosen_ij, (int)PAIRS_INCR, n, (const float*)nullptr, 0L, 1.0f, h->d_flag);
+                       chosen_ij, (int)PAIRS_INCR, n, (const float*)nullptr, 0L, 1.0f, h->d_flag, (const int*)nullptr,
+                       (int*)nullptr, 0);
   }
   {
     Scope sc(h, st, PK_MISC);
@@ -1022,16 +1041,18 @@ static int rollout_core(nnj_handle* h, const uint8_t* codes, const uint8_t* mask
   }
   if (state_out) HIPCHK(h, hipMemcpyAsync(state_out, S, (size_t)B * T * C * 64 * sizeof(float), hipMemcpyDeviceToDevice, st));
   if (int rc = scorer_mask(h, mask, base, w, B, C, st, &mask)) return rc;      // (after the encoder: the region is its scratch)
-  int* live = reinterpret_cast<int*>(base + w.live);
+  // two live lists: k_assemble_argmax writes the next step's list (without position j) beside the one the merged-row
+  // kernels of this step still read
+  int* livebuf[2] = {reinterpret_cast<int*>(base + w.live), reinterpret_cast<int*>(base + w.live) + (size_t)B * T};
   int* ij = reinterpret_cast<int*>(base + w.ij);
   {
     Scope sc(h, st, PK_MISC);
-    hipLaunchKernelGGL(k_init_live, dim3((unsigned)((B * T + 255) / 256)), dim3(256), 0, st, live, T, B, T);
+    hipLaunchKernelGGL(k_init_live, dim3((unsigned)((B * T + 255) / 256)), dim3(256), 0, st, livebuf[0], T, B, T);
   }
   launch_row_xf(h, S, base + w.U, base + w.Kp, base + w.beta, (long)T * C * 64, T, T, B, C, st);
   RowSet rs;
   rs.S = S; rs.U = base + w.U; rs.Kp = base + w.Kp; rs.beta_part = base + w.beta;
-  rs.bstride = (long)T * C * 64; rs.live = live; rs.live_stride = T; rs.ntile32 = (C + 31) / 32;
+  rs.bstride = (long)T * C * 64; rs.live = livebuf[0]; rs.live_stride = T; rs.ntile32 = (C + 31) / 32;
   size_t total = 0;
   for (int n = T; n >= 2; --n) total += (size_t)n * (n - 1) / 2;
   float* lg[2] = {base + w.logits0, base + w.logits1};
@@ -1039,6 +1060,7 @@ static int rollout_core(nnj_handle* h, const uint8_t* codes, const uint8_t* mask
   for (int step = 0, n = T; n >= 2; ++step, --n) {
     const int mode = step == 0 ? PAIRS_FULL : PAIRS_INCR;
     PairGeom g;
+    rs.live = livebuf[step & 1];
     if (int rc = launch_pair_scores(h, rs, ij, mask, base, w, mode, n, B, C, g, st)) return rc;   // :121-126
     {
       Scope sc(h, st, PK_ASSEMBLE);                                                                 // :140-160
@@ -1046,14 +1068,13 @@ static int rollout_core(nnj_handle* h, const uint8_t* codes, const uint8_t* mask
                          (const float*)lg[(step + 1) & 1], (const int*)ij, lg[step & 1], trace ? trace + off : nullptr,
                          (long)total, forced ? forced + 2 * step : nullptr, (long)(T - 1) * 2, merges_out + 2 * step,
                          (long)(T - 1) * 2, gap ? gap + step : nullptr, (long)(T - 1), ij, mode, n,
-                         uniforms ? uniforms + step : nullptr, (long)(T - 1), inv_temp, h->d_flag);
+                         uniforms ? uniforms + step : nullptr, (long)(T - 1), inv_temp, h->d_flag,
+                         (const int*)livebuf[step & 1], n > 2 ? livebuf[(step + 1) & 1] : (int*)nullptr, T);
     }
     off += (size_t)n * (n - 1) / 2;
     if (n > 2) {                                                                                    // env.step :164
       if (int rc = launch_aggregate(h, rs, ij, base, w, S, base + w.U, base + w.Kp, base + w.beta, rs.bstride, T, 1, n,
                                     B, C, st)) return rc;
-      Scope sc(h, st, PK_MISC);
-      hipLaunchKernelGGL(k_update_live, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, st, live, T, (const int*)ij, B, n);
     }
   }
   HIPCHK(h, hipGetLastError());
@@ -1069,6 +1090,7 @@ static int rollout_impl(nnj_handle* h, const uint8_t* codes, const uint8_t* mask
                         int32_t n_encode, const int32_t* forced, const float* uniforms, float inv_temp,
                         int32_t* merges_out, float* trace, float* gap, float* state_out, void* ws, size_t ws_bytes,
                         void* stream) {
+  DevGuard dev_guard;
   if (int rc = ready(h)) return rc;
   if (!codes || !merges_out || T < 2) return fail(h, NNJ_ERR_ARG, "rollout: bad argument");
   if (n_encode != B && n_encode != 1) return fail(h, NNJ_ERR_ARG, "rollout: n_encode must be 1 or B");
@@ -1177,6 +1199,7 @@ int nnj_rollout_sample(nnj_handle* h, const uint8_t* codes, const uint8_t* mask,
 
 int nnj_topology_hash(nnj_handle* h, const int32_t* merges, int32_t B, int32_t T, uint64_t* keys_out, void* stream) {
   if (!h) return fail(nullptr, NNJ_ERR_ARG, "null handle");
+  DevGuard dev_guard;
   HIPCHK(h, hipSetDevice(h->cfg.device));
   if (!merges || !keys_out || B <= 0 || T < 2 || T > 256) return fail(h, NNJ_ERR_ARG, "nnj_topology_hash: bad argument");
   hipLaunchKernelGGL(k_topology_hash, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, static_cast<hipStream_t>(stream), merges,
@@ -1326,6 +1349,7 @@ int lik_common(nnj_handle* h, const uint8_t* codes, int nA, const uint8_t* mask,
                const nnj_subst_model* model, int B, int T, int L, void* ws, size_t ws_bytes, LikModel& md, LikWs& w,
                double*& base, hipStream_t st) {
   if (!h) return fail(nullptr, NNJ_ERR_ARG, "null handle");
+  DevGuard dev_guard;
   HIPCHK(h, hipSetDevice(h->cfg.device));
   if (!codes || !merges || !model || B <= 0 || T < 2 || T > 256 || L <= 0 || (nA != 1 && nA != B))
     return fail(h, NNJ_ERR_ARG, "tree likelihood: bad argument (2 <= T <= 256, n_align = 1 or B)");
@@ -1418,6 +1442,7 @@ int nnj_debug_encoder_stop(nnj_handle* h, int32_t stage) {
 
 int nnj_profile_enable(nnj_handle* h, int32_t on) {
   if (!h) return fail(nullptr, NNJ_ERR_ARG, "null handle");
+  DevGuard dev_guard;
   HIPCHK(h, hipSetDevice(h->cfg.device));
   h->prof = on != 0;
   h->ev_used = 0;
@@ -1428,6 +1453,7 @@ int nnj_profile_enable(nnj_handle* h, int32_t on) {
 
 int nnj_numeric_status(nnj_handle* h, int32_t* nonfinite_out, void* stream) {
   if (!h || !nonfinite_out) return fail(h, NNJ_ERR_ARG, "nnj_numeric_status: null argument");
+  DevGuard dev_guard;
   HIPCHK(h, hipSetDevice(h->cfg.device));
   hipStream_t st = static_cast<hipStream_t>(stream);
   int v = 0;
@@ -1449,6 +1475,7 @@ const char* nnj_profile_kind_name(int32_t k) { return (k >= 0 && k < PK_COUNT) ?
 
 int nnj_profile_read(nnj_handle* h, double* ms_out, int64_t* launches_out, int32_t cap) {
   if (!h || !ms_out || !launches_out || cap < PK_COUNT) return fail(h, NNJ_ERR_ARG, "nnj_profile_read: bad argument");
+  DevGuard dev_guard;
   HIPCHK(h, hipSetDevice(h->cfg.device));
   for (size_t i = 0; i + 1 < h->ev_used; i += 2) {
     HIPCHK(h, hipEventSynchronize(h->ev[i + 1]));

@@ -703,24 +703,43 @@ __global__ __launch_bounds__(256) void k_agg_alpha(RowSet rs, ScorerW w, const i
     }
   }
   *reinterpret_cast<f32x4*>(xl + e) = x;
+  // the live-list lookups of all rows at once (in front of every row's loads they were a dependent round trip each)
+  __shared__ int slots[256];
+  if (tid < n) slots[tid] = slot_of(rs, b, tid);
   __syncthreads();
   const int nch = gridDim.x;
-  for (int r = wave; r < n; r += 4) {
-    const size_t orow = bo + (size_t)slot_of(rs, b, r) * C * 64 + (size_t)chunk * 16 * 64;
-    float acc = 0.f;
+  // this lane's part of x in registers; two rows per iteration: eight 16-byte loads of a wave in flight
+  f32x4 xv[4];
+  bool ok[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int ee = (k * 64 + lane) * 4;
+    ok[k] = chunk * 16 + (ee >> 6) < C;
+    xv[k] = *reinterpret_cast<const f32x4*>(xl + ee);
+  }
+  const size_t coff = (size_t)chunk * 16 * 64 + (size_t)lane * 4;
+  for (int r = wave; r < n; r += 8) {
+    const int r2 = r + 4 < n ? r + 4 : r;                    // (last odd row: loaded twice, stored once)
+    const float* k0 = rs.Kp + bo + (size_t)slots[r] * C * 64 + coff;
+    const float* k1 = rs.Kp + bo + (size_t)slots[r2] * C * 64 + coff;
+    f32x4 kv0[4], kv1[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      const int ee = (k * 64 + lane) * 4;
-      const int cc = chunk * 16 + (ee >> 6);
-      if (cc < C) {
-        const f32x4 kv = *reinterpret_cast<const f32x4*>(rs.Kp + orow + ee);
-        const f32x4 xv = *reinterpret_cast<const f32x4*>(xl + ee);
-        acc += xv[0] * kv[0] + xv[1] * kv[1] + xv[2] * kv[2] + xv[3] * kv[3];
-      }
+      kv0[k] = ok[k] ? *reinterpret_cast<const f32x4*>(k0 + k * 256) : (f32x4){0.f, 0.f, 0.f, 0.f};
+      kv1[k] = ok[k] ? *reinterpret_cast<const f32x4*>(k1 + k * 256) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    float acc0 = 0.f, acc1 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {                             // same order of the sums as one row at a time
+      acc0 += xv[k][0] * kv0[k][0] + xv[k][1] * kv0[k][1] + xv[k][2] * kv0[k][2] + xv[k][3] * kv0[k][3];
+      acc1 += xv[k][0] * kv1[k][0] + xv[k][1] * kv1[k][1] + xv[k][2] * kv1[k][2] + xv[k][3] * kv1[k][3];
     }
 #pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) acc += __shfl_xor(acc, o);
-    if (lane == 0) part[((size_t)b * nch + chunk) * rp + r] = acc;
+    for (int o = 32; o >= 1; o >>= 1) { acc0 += __shfl_xor(acc0, o); acc1 += __shfl_xor(acc1, o); }
+    if (lane == 0) {
+      part[((size_t)b * nch + chunk) * rp + r] = acc0;
+      if (r2 != r) part[((size_t)b * nch + chunk) * rp + r2] = acc1;
+    }
   }
 }
 
@@ -894,8 +913,19 @@ __global__ __launch_bounds__(256) void k_assemble_argmax(const float* __restrict
                                                          float* __restrict__ gap_out, long gap_bstride,
                                                          int* ij_cur, int mode, int n,
                                                          const float* __restrict__ uniforms, long u_bstride,
-                                                         float inv_temp, int* __restrict__ nonfinite) {
+                                                         float inv_temp, int* __restrict__ nonfinite,
+                                                         const int* __restrict__ live_cur, int* __restrict__ live_next,
+                                                         int live_stride) {
   __shared__ float newsc[256];
+  __shared__ int picked_j;
+  // the rollout keeps two live lists: this kernel also writes the NEXT one (the current list without position j:
+  // environment.py:764-768), which used to be a launch of its own per step (k_update_live; 5 us of the 100 us of a
+  // step at batch 1).  The current entries are loaded here, their latency hides behind the table pass.
+  int lv0 = 0, lv1 = 0;
+  if (live_next && threadIdx.x < n - 1) {
+    lv0 = live_cur[(size_t)blockIdx.x * live_stride + threadIdx.x];
+    lv1 = live_cur[(size_t)blockIdx.x * live_stride + threadIdx.x + 1];
+  }
   __shared__ float red_v[8];
   __shared__ int red_i[4];
   const int tid = threadIdx.x, b = blockIdx.x;
@@ -1009,6 +1039,11 @@ __global__ __launch_bounds__(256) void k_assemble_argmax(const float* __restrict
       if (fi >= 0 && fi < fj && fj < n) { ci = fi; cj = fj; }       // out-of-range forcing is ignored
     }
     ij_cur[2 * b] = ci; ij_cur[2 * b + 1] = cj;
+    picked_j = min(max(cj, 1), n - 1);
+  }
+  if (live_next) {
+    __syncthreads();
+    if (tid < n - 1) live_next[(size_t)b * live_stride + tid] = tid >= picked_j ? lv1 : lv0;
   }
 }
 
