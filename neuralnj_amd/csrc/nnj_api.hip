@@ -369,7 +369,10 @@ int launch_encoder(nnj_handle* h, const uint8_t* codes, const float* onehot, con
   // reference no-grad chunking: one masked_fill(-10000) per row chunk, summed (axial_attention.py:35-64)
   int nchunks = 1;
   if ((long)T * C > 1024) { int max_rows = 1024 / C; if (max_rows < 1) max_rows = 1; nchunks = (T + max_rows - 1) / max_rows; }
-  const float fill = -10000.0f * (float)nchunks;
+  // k_row_s writes the logits (and their tile maxima) times log2(e): the probabilities of k_row_pv are one v_exp_f32
+  // (2^x) each, without the multiplication exp(x) costs per key and query
+  const float LOG2E = 1.4426950408889634f;
+  const float fill = -10000.0f * (float)nchunks * LOG2E;
   for (int l = 0; l < nl; ++l) {
     {
       Scope sc(h, st, PK_ROW_QKV);
@@ -383,7 +386,7 @@ int launch_encoder(nnj_handle* h, const uint8_t* codes, const float* onehot, con
     }
     {
       Scope sc(h, st, PK_ROW_S);
-      const float qs = 1.0f / (sqrtf((float)NNJ_DH) * sqrtf((float)T));
+      const float qs = LOG2E / (sqrtf((float)NNJ_DH) * sqrtf((float)T));
       if (T <= 64) {
         constexpr int QW = 128;
         const size_t lds = (size_t)RsShape<QW>::NST * RsShape<QW>::STAGE;
@@ -579,7 +582,7 @@ int launch_pair_scores(nnj_handle* h, const RowSet& rs, const int* ij_prev, cons
         if (int rc = set_lds(h, k_inc_score<2, true>, lds)) return rc;
         hipLaunchKernelGGL((k_inc_score<2, true>), grid, dim3(512), lds, st, rs, sw, ij_prev, base + w.alpha, mask,
                            base + w.score_part, n, C, g.cs, h->d_flag);
-      } else {                                             // 17..32: the 32-pair kernel (k_inc_score_w<2> measured equal)
+      } else {                                             // 17..32: the 32-pair kernel (k_inc_score_w<2> with 8 or 12 waves measured 2-3 ms per rollout slower)
         const size_t lds = (size_t)(3 * IMG64 + 8 * b6_floats(64, 32) + 16 + SCORER_CONSTS) * sizeof(float);
         if (int rc = set_lds(h, k_inc_score<1, true>, lds)) return rc;
         hipLaunchKernelGGL((k_inc_score<1, true>), grid, dim3(512), lds, st, rs, sw, ij_prev, base + w.alpha, mask,

@@ -253,20 +253,53 @@ __device__ __forceinline__ void opaque(unsigned& x) {
   asm("" : "+v"(x));
 #endif
 }
-// two fp32 -> two packed fp16 pairs (h, m)
+// -1.0f the optimiser cannot see through (no instruction; identical calls are merged and hoisted out of loops)
+__device__ __forceinline__ float opaque_neg_one() {
+  float k = -1.0f;
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm("" : "+s"(k));
+#endif
+  return k;
+}
+// two fp32 -> two packed fp16 pairs (h, m): THREE instructions -- v_cvt_pk_f16_f32 for h, then the residuals
+// a - h.lo, b - h.hi computed in fp32 and rounded to fp16 by v_fma_mixlo_f16 / v_fma_mixhi_f16, which take the fp16
+// halves of h as they stand and write the halves of m.  Written as `a - (float)h` the compiler emits two
+// v_cvt_f32_f16, a v_pk_add_f32 (plus the wait state its packed result needs) and a second v_cvt_pk: six issue
+// slots per pair, and the operand splits were a fifth of the vector work of the token kernels (knocked out, time
+// only: k_tok1p 36.4 -> 29.9 ms per rollout, incremental alpha 31.7 -> 28.4, k_row_pv 36.0 -> 33.3).  The mixed-
+// precision FMA is selected only for fma(fpext(h), k, a) with a multiplier the optimiser cannot fold -- hence the
+// opaque -1 -- and only while the two residuals are not paired by the SLP vectoriser: the low half passes through an
+// empty asm, so the high one is a lone fpround(fma) next to a finished low half (the v_fma_mixhi pattern).  The
+// compiler schedules these like any other VALU instruction (hazard wait states included); results are bit-identical
+// to the subtraction (the fma is exact).
+// MIX = false: the residuals as plain subtractions (two v_cvt_f32_f16, one v_pk_add_f32, a second v_cvt_pk).  The
+// mixed-precision instructions issue at half rate, so the gain is the removed wait states and registers rather than
+// the instruction count, and it depends on the kernel: measured per rollout of 256, k_tok1p 35.4 -> 34.0 ms and the
+// incremental alpha kernels 32.5 -> 30.4, but the incremental SCORE kernels 56.9 -> 58.8 -- those keep this form.
+template <bool MIX = true>
 __device__ __forceinline__ void split2(float a, float b, unsigned& h, unsigned& m) {
   h = cvt_pk_f16(a, b);
   opaque(h);
   const f16x2 hv = __builtin_bit_cast(f16x2, h);
-  m = cvt_pk_f16(a - (float)hv[0], b - (float)hv[1]);
+  if constexpr (!MIX) {
+    m = cvt_pk_f16(a - (float)hv[0], b - (float)hv[1]);
+    return;
+  }
+  const float k = opaque_neg_one();
+  _Float16 m0 = (_Float16)__builtin_fmaf((float)hv[0], k, a);
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm("" : "+v"(m0));
+#endif
+  const f16x2 mv = {m0, (_Float16)__builtin_fmaf((float)hv[1], k, b)};
+  m = __builtin_bit_cast(unsigned, mv);
 }
 // registers base..base+7 of a feature-major tile -> the fragment of one k-step
-template <int BASE>
+template <int BASE, bool MIX = true>
 __device__ __forceinline__ void split8(Frag3& o, const f32x16& x) {
 #pragma unroll
   for (int p = 0; p < 4; ++p) {
     unsigned h, m;
-    split2(x[BASE + 2 * p], x[BASE + 2 * p + 1], h, m);
+    split2<MIX>(x[BASE + 2 * p], x[BASE + 2 * p + 1], h, m);
     o.h[p] = h; o.m[p] = m;
   }
 }
@@ -378,7 +411,7 @@ __host__ __device__ constexpr int b6_floats(int rows, int in) { return rows * in
 constexpr int IMG64 = b6_floats(64, 64);                   // floats of a [64][64] operand image
 
 // out[nt][mt] = bias + W*in (or += W*in), W = a stage_weight_b6 image of [32*MT][32*KT].
-template <int MT, int KT, int NT, bool ACC, bool BIAS, bool LEAN = false>
+template <int MT, int KT, int NT, bool ACC, bool BIAS, bool LEAN = false, bool MIX = true>
 __device__ __forceinline__ void linear_core_b6(f32x16 (&out)[NT][MT], const f32x16 (&in)[NT][KT],
                                                const float* W, const float* bias, int lane) {
   const int row = lane & 31, hh = lane >> 5;
@@ -413,7 +446,7 @@ __device__ __forceinline__ void linear_core_b6(f32x16 (&out)[NT][MT], const f32x
       constexpr int ks = decltype(ki)::value;
       Frag3 b[NT];
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) split8<8 * (ks & 1)>(b[nt], in[nt][ks >> 1]);
+      for (int nt = 0; nt < NT; ++nt) split8<8 * (ks & 1), MIX>(b[nt], in[nt][ks >> 1]);
       static_for<0, MT>([&](auto mi) {
         constexpr int mt = decltype(mi)::value;
         Frag3 a;
@@ -431,7 +464,7 @@ __device__ __forceinline__ void linear_core_b6(f32x16 (&out)[NT][MT], const f32x
   Frag3 b[2][NT];
   frag(0, a[0]);
 #pragma unroll
-  for (int nt = 0; nt < NT; ++nt) split8<0>(b[0][nt], in[nt][0]);
+  for (int nt = 0; nt < NT; ++nt) split8<0, MIX>(b[0][nt], in[nt][0]);
   static_for<0, 2 * KT>([&](auto ki) {
     constexpr int ks = decltype(ki)::value;
     static_for<0, MT>([&](auto mi) {
@@ -443,16 +476,16 @@ __device__ __forceinline__ void linear_core_b6(f32x16 (&out)[NT][MT], const f32x
     });
     if constexpr (ks + 1 < 2 * KT) {
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) split8<8 * ((ks + 1) & 1)>(b[(ks + 1) & 1][nt], in[nt][(ks + 1) >> 1]);
+      for (int nt = 0; nt < NT; ++nt) split8<8 * ((ks + 1) & 1), MIX>(b[(ks + 1) & 1][nt], in[nt][(ks + 1) >> 1]);
     }
     __builtin_amdgcn_sched_barrier(0);
   });
   }
 }
-template <int MT, int KT, int NT, bool LEAN = false>
+template <int MT, int KT, int NT, bool LEAN = false, bool MIX = true>
 __device__ __forceinline__ void linear6_T(f32x16 (&out)[NT][MT], const f32x16 (&in)[NT][KT], const float* W,
                                           const float* bias, int lane) {
-  linear_core_b6<MT, KT, NT, false, true, LEAN>(out, in, W, bias, lane);
+  linear_core_b6<MT, KT, NT, false, true, LEAN, MIX>(out, in, W, bias, lane);
 }
 template <int MT, int KT, int NT, bool LEAN = false>
 __device__ __forceinline__ void linear6_T_nb(f32x16 (&out)[NT][MT], const f32x16 (&in)[NT][KT], const float* W,
@@ -534,12 +567,13 @@ __device__ __forceinline__ f32x4 mfma16_b6(const Frag3& a, const Frag3& b, f32x4
   return c;
 }
 // eight values -> one k-step fragment (k-slot order: a[0..3], b[0..3])
+template <bool MIX = true>
 __device__ __forceinline__ void split_8(Frag3& o, const f32x4& a, const f32x4& b) {
   unsigned h, m;
-  split2(a[0], a[1], h, m); o.h[0] = h; o.m[0] = m;
-  split2(a[2], a[3], h, m); o.h[1] = h; o.m[1] = m;
-  split2(b[0], b[1], h, m); o.h[2] = h; o.m[2] = m;
-  split2(b[2], b[3], h, m); o.h[3] = h; o.m[3] = m;
+  split2<MIX>(a[0], a[1], h, m); o.h[0] = h; o.m[0] = m;
+  split2<MIX>(a[2], a[3], h, m); o.h[1] = h; o.m[1] = m;
+  split2<MIX>(b[0], b[1], h, m); o.h[2] = h; o.m[2] = m;
+  split2<MIX>(b[2], b[3], h, m); o.h[3] = h; o.m[3] = m;
 }
 __device__ __forceinline__ void load_v64(V64& v, const float* p, int kq) {
 #pragma unroll
@@ -639,7 +673,7 @@ __device__ __forceinline__ void linear_t16p_core(f32x4 (&out)[MT], const Frag3 (
     issue(std::integral_constant<int, s + PF>{});
   });
 }
-template <int MT, bool ACC, bool BIAS = true, int PF = 2>
+template <int MT, bool ACC, bool BIAS = true, int PF = 2, bool MIX = true>
 __device__ __forceinline__ void linear_t16p(f32x4 (&out)[MT], const V64& in, const float* W, const float* bias,
                                             int lane) {
   const int kq = lane >> 4;
@@ -652,8 +686,8 @@ __device__ __forceinline__ void linear_t16p(f32x4 (&out)[MT], const V64& in, con
   }
   Frag3 b[2];
   linear_t16p_core<MT, PF>(out, b, W, lane, [&] {
-    split_8(b[0], in.t[0], in.t[1]);
-    split_8(b[1], in.t[2], in.t[3]);
+    split_8<MIX>(b[0], in.t[0], in.t[1]);
+    split_8<MIX>(b[1], in.t[2], in.t[3]);
   });
 }
 

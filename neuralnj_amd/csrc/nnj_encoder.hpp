@@ -148,7 +148,8 @@ __global__ __launch_bounds__(512) void k_tok1p(const float* __restrict__ ctx, co
   const int r = 32 * rt + tok;                          // this lane's row of the column
   const bool valid = r < R;
   const long ncols = (long)B * C;
-  const float scaling = rsqrtf((float)NNJ_DH);         // axial_attention.py:214
+  // axial_attention.py:214, times log2(e): the column logits are in log2 units, a probability is one v_exp_f32 (2^x)
+  const float scaling = rsqrtf((float)NNJ_DH) * 1.4426950408889634f;
   // The token and its row-attention context of the NEXT column are loaded (raw: rows beyond R read row 0, they
   // are masked as keys and never stored) while the output projection of the current one runs: the two gathers
   // were 12-15k exposed cycles per column at the top of the loop.
@@ -296,7 +297,7 @@ __global__ __launch_bounds__(512) void k_tok1p(const float* __restrict__ ctx, co
         for (int jt = 0; jt < NWC; ++jt)
 #pragma unroll
           for (int k = 0; k < 16; ++k) {
-            const float p = nnj_exp(sc_[jt][k] - m);
+            const float p = __builtin_amdgcn_exp2f(sc_[jt][k] - m);
             sc_[jt][k] = p;
             l += p;
           }
@@ -364,12 +365,12 @@ __global__ __launch_bounds__(512) void k_tok1p(const float* __restrict__ ctx, co
             }
             mt = fmaxf(mt, __shfl_xor(mt, 32));
             const float mn = fmaxf(m, mt);                  // finite from the first tile on (rows 0..31 exist)
-            const float corr = nnj_exp(m - mn);             // first tile: exp(-inf) = 0 on l = 0, o = 0
+            const float corr = __builtin_amdgcn_exp2f(m - mn);             // first tile: exp(-inf) = 0 on l = 0, o = 0
             l *= corr;
 #pragma unroll
             for (int k = 0; k < 16; ++k) {
               o[k] *= corr;
-              const float p = nnj_exp(sc[k] - mn);          // masked keys: exp(-inf) = 0
+              const float p = __builtin_amdgcn_exp2f(sc[k] - mn);          // masked keys: exp(-inf) = 0
               sc[k] = p;
               l += p;
             }
@@ -419,6 +420,7 @@ __device__ __forceinline__ void flat_token(int t, int R, int C, int& c, int& r, 
 // (<= 128 registers): the LayerNorm -> fc1 -> GELU -> fc2 chain of one wave is latency bound, the other three
 // fill its gaps (no register prefetch needed).  Both weight matrices are resident as eight [64][64] operand
 // images (128 KiB); the hidden layer is walked 64 units at a time and never leaves the registers.
+constexpr int FFN_PF = 2;     // fragment reads in flight ahead of the MFMAs (k_ffn16 runs at 128 registers)
 __global__ __launch_bounds__(1024) void k_ffn16(float* __restrict__ x, FfnW wf, int B, int R, int C, int groups_per_b) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* W1l = smem;                         // four [64][64] images: hidden units 64q..64q+63
@@ -448,15 +450,23 @@ __global__ __launch_bounds__(1024) void k_ffn16(float* __restrict__ x, FfnW wf, 
     layer_norm_v64(y, xr, cf, cf + 64, kq);
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) out.t[mt] = *reinterpret_cast<const f32x4*>(cf + 128 + 16 * mt + 4 * kq);
+    // y is split ONCE (inside the loop it was split again for each of the four hidden blocks); both products read
+    // their weight fragments by hand ahead of the MFMAs, at two base addresses + immediate offsets (the compiler's own
+    // reads recomputed a swizzled address per fragment: 34 vector adds per 36 reads)
+    Frag3 yf[2];
+    split_8(yf[0], y.t[0], y.t[1]);
+    split_8(yf[1], y.t[2], y.t[3]);
 #pragma unroll 1
     for (int q = 0; q < 4; ++q) {              // 64 hidden units at a time
       V64 hdn;
-      linear_t16<4, false>(hdn.t, y, W1l + q * IMG64, cf + 192 + q * 64, lane);
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) hdn.t[mt] = *reinterpret_cast<const f32x4*>(cf + 192 + q * 64 + 16 * mt + 4 * kq);
+      linear_t16p_core<4, FFN_PF>(hdn.t, yf, W1l + q * IMG64, lane, [] {});
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
         for (int e = 0; e < 4; ++e) hdn.t[mt][e] = gelu_erf(hdn.t[mt][e]);
-      linear_t16<4, true, false>(out.t, hdn, W2l + q * IMG64, nullptr, lane);
+      linear_t16p<4, true, false, FFN_PF>(out.t, hdn, W2l + q * IMG64, nullptr, lane);
     }
     if (!valid) continue;
 #pragma unroll

@@ -365,7 +365,7 @@ __global__ __launch_bounds__(256, 2) void k_row_s(const uint8_t* __restrict__ Q6
       float tmax = -INFINITY;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        float s = acc[i][j][r] * qs;           // align_scaling (axial_attention.py:31-33, 77), see k_qkv6
+        float s = acc[i][j][r] * qs;           // align_scaling (axial_attention.py:31-33, 77) x log2(e), see k_qkv6
         s = ((is1 >> r) & 1u) ? fill : s;
         s = ((is2 >> r) & 1u) ? -INFINITY : s;
         acc[i][j][r] = s;
@@ -476,7 +476,7 @@ __global__ __launch_bounds__(256) void k_row_pv(const uint8_t* __restrict__ V6, 
       // probabilities of the 32 keys of this S image; registers 0-7 feed this k-step, 8-15 the next
       f32x16 p;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { p[r] = nnj_exp(s_cur[r] - m); lsum += p[r]; }
+      for (int r = 0; r < 16; ++r) { p[r] = __builtin_amdgcn_exp2f(s_cur[r] - m); lsum += p[r]; }   // logits in log2 units (k_row_s)
       split8<0>(bfr[0], p);
       split8<8>(bfr[1], p);
     }

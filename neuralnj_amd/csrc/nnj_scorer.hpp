@@ -539,7 +539,7 @@ __global__ __launch_bounds__(512) void k_inc_score(RowSet rs, ScorerW w, const i
       Frag3 sf[4];
       static_for<0, 4>([&](auto ki) {
         constexpr int ks = decltype(ki)::value;
-        split8<8 * (ks & 1)>(sf[ks], raw.sr[0][ks >> 1]);
+        split8<8 * (ks & 1), false>(sf[ks], raw.sr[0][ks >> 1]);
       });
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt)
@@ -588,7 +588,7 @@ __global__ __launch_bounds__(512) void k_inc_score(RowSet rs, ScorerW w, const i
     if constexpr (CTX) {
       f32x16 xg[1][2], g[1][2];
       linear6_pre<2, 2 * KT>(xg, at, img_t, lane);
-      linear6_T<2, 2, 1, true>(g, xg, Wg_l, cv + 64, lane);
+      linear6_T<2, 2, 1, true, false>(g, xg, Wg_l, cv + 64, lane);
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -598,7 +598,7 @@ __global__ __launch_bounds__(512) void k_inc_score(RowSet rs, ScorerW w, const i
         }
     }
     f32x16 s1[1][2];
-    linear6_T<2, 2, 1, true>(s1, x, S0_l, cv + 128, lane);
+    linear6_T<2, 2, 1, true, false>(s1, x, S0_l, cv + 128, lane);
     float s = 0.f;
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)

@@ -40,15 +40,23 @@ __device__ __forceinline__ Inc16 inc16(const RowSet& rs, const int* ij_prev, int
   L.sgn = r < m ? 1.0f : -1.0f;
   return L;
 }
-// x = S_m + sigmoid(U_r - U_m + s*b) (S_r - S_m)   (see inc_gate)
-__device__ __forceinline__ void gate16(V64& x, const V64& sr, const V64& ur, const V64& sm, const V64& um,
-                                       const float* bh, float sgn, int kq) {
+// x = S_m + sigmoid(U_r - U_m + s*b) (S_r - S_m)   (see inc_gate).  The accumulators of U_r = W_h S_r start at
+// s*b - U_m (gate_init16) instead of zero: the MFMAs add U_r on top and the gate is one sigmoid of the accumulator --
+// per element one fused multiply-add instead of a zero move, a subtraction and an addition.
+__device__ __forceinline__ void gate_init16(V64& ur, const V64& um, const float* bh, float sgn, int kq) {
 #pragma unroll
   for (int mt = 0; mt < 4; ++mt) {
     const f32x4 b4 = *reinterpret_cast<const f32x4*>(bh + 16 * mt + 4 * kq);
 #pragma unroll
+    for (int e = 0; e < 4; ++e) ur.t[mt][e] = sgn * b4[e] - um.t[mt][e];
+  }
+}
+__device__ __forceinline__ void gate16(V64& x, const V64& sr, const V64& ur, const V64& sm) {
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) {
+#pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const float z = sigmoid_l2((ur.t[mt][e] - um.t[mt][e]) + sgn * b4[e]);
+      const float z = sigmoid_l2(ur.t[mt][e]);
       x.t[mt][e] = sm.t[mt][e] + z * (sr.t[mt][e] - sm.t[mt][e]);
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -113,10 +121,9 @@ __global__ __launch_bounds__(64 * NW) void k_inc_alpha16(RowSet rs, ScorerW w, c
       V64 sm, um, ur;
       load_v64(sm, Sm + (size_t)c * 64, kq);
       load_v64(um, Um + (size_t)c * 64, kq);
-#pragma unroll
-      for (int mt = 0; mt < 4; ++mt) ur.t[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      gate_init16(ur, um, cv, L.sgn, kq);
       linear_t16p_core<4>(ur.t, sf, Wh_l, lane, [] {});
-      gate16(x, sr, ur, sm, um, cv, L.sgn, kq);
+      gate16(x, sr, ur, sm);
     }
     if constexpr (NG > 1) group_barrier_lds<NG>(cnt, epoch, status);     // everyone is done with the previous image
     // row r of the image: chunk 4*ks + kq = this lane's tiles 2ks, 2ks+1
@@ -229,15 +236,14 @@ __global__ __launch_bounds__(64 * T16_WAVES) void k_inc_score16(RowSet rs, Score
     // reads) and, transposed, the columns of the image
     Frag3 sf[2];
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) split_8(sf[ks], sr.t[2 * ks], sr.t[2 * ks + 1]);
+    for (int ks = 0; ks < 2; ++ks) split_8<false>(sf[ks], sr.t[2 * ks], sr.t[2 * ks + 1]);
     {
       V64 sm, um, ur;
       load_v64(sm, Sm + (size_t)c * 64, kq);
       load_v64(um, Um + (size_t)c * 64, kq);
-#pragma unroll
-      for (int mt = 0; mt < 4; ++mt) ur.t[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      gate_init16(ur, um, cv, L.sgn, kq);
       linear_t16p_core<4>(ur.t, sf, Wh_l, lane, [] {});
-      gate16(x, sr, ur, sm, um, cv, L.sgn, kq);
+      gate16(x, sr, ur, sm);
     }
     if constexpr (CTX) {
       if constexpr (NG > 1) __syncthreads();                     // everyone is done with the previous image
@@ -274,7 +280,7 @@ __global__ __launch_bounds__(64 * T16_WAVES) void k_inc_score16(RowSet rs, Score
         }
         __builtin_amdgcn_sched_barrier(0);
       });
-      linear_t16p<4, false>(g.t, xg, Wg_l, cv + 64, lane);
+      linear_t16p<4, false, true, 2, false>(g.t, xg, Wg_l, cv + 64, lane);
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
@@ -285,7 +291,7 @@ __global__ __launch_bounds__(64 * T16_WAVES) void k_inc_score16(RowSet rs, Score
         }
     }
     V64 s1;
-    linear_t16p<4, false>(s1.t, x, S0_l, cv + 128, lane);
+    linear_t16p<4, false, true, 2, false>(s1.t, x, S0_l, cv + 128, lane);
     float s = 0.f;
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
@@ -320,13 +326,13 @@ __global__ __launch_bounds__(64 * T16_WAVES) void k_inc_score16(RowSet rs, Score
 // SIMD, <= 256 registers): the latency of one tile's chain is covered by the other tiles of the same wave --
 // the phases below are loops over the tiles, i.e. NT independent chains -- and by the second wave.
 // Used for 33..48 rows (NT = 3: 48 instead of 64 padded pairs).  part[b][sc][pair r].
-template <int NT, bool CTX>
-__global__ __launch_bounds__(512) void k_inc_score_w(RowSet rs, ScorerW w, const int* __restrict__ ij_prev,
+template <int NT, bool CTX, int NW = 8>
+__global__ __launch_bounds__(64 * NW) void k_inc_score_w(RowSet rs, ScorerW w, const int* __restrict__ ij_prev,
                                                      const float* __restrict__ alpha,
                                                      const uint8_t* __restrict__ mask,
                                                      float* __restrict__ score_part, int n, int C, int cs) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  constexpr int NW = 8;
+  constexpr int WPF = 2;                                   // fragment reads ahead
   constexpr int RL = 16 * NT;                              // fp16 per image row
   constexpr int CH = 2 * NT;                               // 16-byte chunks per image row (8 r' each)
   constexpr int KSX = (NT + 1) / 2;                        // k-steps of the x_g GEMM (32 r' each)
@@ -399,12 +405,11 @@ __global__ __launch_bounds__(512) void k_inc_score_w(RowSet rs, ScorerW w, const
         // columns 16t + l15 of the image
         Frag3 sf[2];
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) split_8(sf[ks], sr[t].t[2 * ks], sr[t].t[2 * ks + 1]);
+        for (int ks = 0; ks < 2; ++ks) split_8<false>(sf[ks], sr[t].t[2 * ks], sr[t].t[2 * ks + 1]);
         V64 ur;
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) ur.t[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        linear_t16p_core<4>(ur.t, sf, Wh_l, lane, [] {});
-        gate16(x[t], sr[t], ur, sm, um, cv, sgn[t], kq);
+        gate_init16(ur, um, cv, sgn[t], kq);
+        linear_t16p_core<4, WPF>(ur.t, sf, Wh_l, lane, [] {});
+        gate16(x[t], sr[t], ur, sm);
         if constexpr (CTX) {
           const int wchunk = 2 * t + (l15 >> 3), we = l15 & 7;
 #pragma unroll
@@ -453,7 +458,7 @@ __global__ __launch_bounds__(512) void k_inc_score_w(RowSet rs, ScorerW w, const
             xg.t[mt] = mfma16_b6(a, bfr, xg.t[mt]);
           }
         }
-        linear_t16p<4, false>(g.t, xg, Wg_l, cv + 64, lane);
+        linear_t16p<4, false, true, WPF, false>(g.t, xg, Wg_l, cv + 64, lane);
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
@@ -463,7 +468,7 @@ __global__ __launch_bounds__(512) void k_inc_score_w(RowSet rs, ScorerW w, const
           }
       }
       V64 s1;
-      linear_t16p<4, false>(s1.t, x[t], S0_l, cv + 128, lane);
+      linear_t16p<4, false, true, WPF, false>(s1.t, x[t], S0_l, cv + 128, lane);
       float s = 0.f;
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt) {

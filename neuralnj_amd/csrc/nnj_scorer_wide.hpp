@@ -103,8 +103,7 @@ __global__ __launch_bounds__(512) void k_wide_alpha(RowSet rs, ScorerW w, const 
         const int o = rr[pt] * 8 + wswz6<8>(rr[pt], 4 * ks + kq);
         im4[o] = sf[ks].h; im4[PL + o] = sf[ks].m;
       }
-#pragma unroll
-      for (int mt = 0; mt < 4; ++mt) ur.t[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      gate_init16(ur, um, cv, sgn[pt], kq);
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
@@ -117,7 +116,7 @@ __global__ __launch_bounds__(512) void k_wide_alpha(RowSet rs, ScorerW w, const 
         }
         __builtin_amdgcn_sched_barrier(0);
       }
-      gate16(x[pt], sr, ur, sm, um, cv, sgn[pt], kq);
+      gate16(x[pt], sr, ur, sm);
     }
     __syncthreads();                                       // all RP rows are in the image
 #pragma unroll
@@ -267,8 +266,7 @@ __global__ __launch_bounds__(512) void k_wide_score(RowSet rs, ScorerW w, const 
           t16[o0] = (unsigned short)h; t16[o1] = (unsigned short)(h >> 16);
           t16[PLH + o0] = (unsigned short)m; t16[PLH + o1] = (unsigned short)(m >> 16);
         }
-#pragma unroll
-      for (int mt = 0; mt < 4; ++mt) ur.t[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      gate_init16(ur, um, cv, sgn[pt], kq);
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
@@ -281,7 +279,7 @@ __global__ __launch_bounds__(512) void k_wide_score(RowSet rs, ScorerW w, const 
         }
         __builtin_amdgcn_sched_barrier(0);
       }
-      gate16(x[pt], sr, ur, sm, um, cv, sgn[pt], kq);
+      gate16(x[pt], sr, ur, sm);
     }
     __syncthreads();                                       // all RP columns are in the image
 #pragma unroll
