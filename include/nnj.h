@@ -124,6 +124,18 @@ int nnj_env_step(nnj_handle* h, const float* state_dev, const int32_t* ij_dev,
                  float* state_out_dev, int32_t B, int32_t n, int32_t L,
                  void* ws_dev, size_t ws_bytes, void* stream);
 
+/* Sessions over the dense-state entry points.  The reference's loop (finetune_rl_search.py:121-164) hands the dense
+ * state from call to call: decode_zxr(state) -> argmax -> env.step(state) -> decode_zxr(new state) ...  The library
+ * keeps the rows of the tensor it last saw in nnj_pair_scores_full, or last returned from nnj_env_step / nnj_step, in
+ * slot layout inside the caller's workspace, with their cached per-row transforms and the live list -- the state of
+ * nnj_rollout_argmax's own loop.  nnj_pair_scores_incr, nnj_aggregate, nnj_env_step and nnj_step CONTINUE that session
+ * when their state_dev is that very tensor: same pointer, same workspace pointer, B, L and row count, and the caller
+ * has not written to it since.  They then transform no row again, merge in place and gather the dense output once
+ * (the reference copies the whole state twice per step); results are bit-identical to nnj_rollout_argmax's.  Any
+ * other input runs stateless from the dense tensor, as documented per function.  A caller that rewrites a tensor the
+ * session is bound to (or frees it and reuses the address) must call nnj_session_reset first. */
+int nnj_session_reset(nnj_handle* h);
+
 /* argmax(logits,-1) and flat index -> (i,j) -- reference
  * finetune_rl_search.py:145,159-160 (first maximal index wins).
  * ij_out int32 [B,2]; top2_gap_out float [B] may be NULL. */

@@ -42,6 +42,7 @@ _SIGS = {
     "nnj_score_index_map": ([_vp, _vp, _vp, C.c_int32, C.c_int32, _vp], C.c_int),
     "nnj_aggregate": ([_vp, _vp, _vp, _vp, C.c_int32, C.c_int32, C.c_int32, _vp, C.c_size_t, _vp], C.c_int),
     "nnj_env_step": ([_vp, _vp, _vp, _vp, C.c_int32, C.c_int32, C.c_int32, _vp, C.c_size_t, _vp], C.c_int),
+    "nnj_session_reset": ([_vp], C.c_int),
     "nnj_select_pair": ([_vp, _vp, _vp, _vp, C.c_int32, C.c_int32, _vp], C.c_int),
     "nnj_rollout_argmax": ([_vp, _vp, _vp, C.c_int32, C.c_int32, C.c_int32, _vp, _vp, _vp, _vp, _vp, _vp,
                             C.c_size_t, _vp], C.c_int),
@@ -139,6 +140,22 @@ class Nnj:
     def _stream(self):
         return _vp(torch.cuda.current_stream(self.device).cuda_stream)
 
+    # The library continues a session when it is handed the very tensor it last saw / returned (include/nnj.h,
+    # "Sessions").  The wrapper keeps that tensor alive (its address cannot be reused) and remembers its version
+    # counter: a tensor the caller has written to in place, or any other tensor, resets the session first.
+    def _session_in(self, state):
+        ref = getattr(self, "_sess_tensor", None)
+        if ref is None:
+            return
+        if state is not ref or state._version != self._sess_version:
+            if state.data_ptr() == ref.data_ptr():
+                self._chk(self.lib.nnj_session_reset(self.h))
+            self._sess_tensor = None
+
+    def _session_out(self, dense):
+        self._sess_tensor = dense
+        self._sess_version = dense._version
+
     def workspace(self, B, T, L):
         need = C.c_size_t()
         self._chk(self.lib.nnj_workspace_bytes(self.h, B, T, L, C.byref(need)))
@@ -203,6 +220,7 @@ class Nnj:
         ws = self.workspace(B, n, L)
         self._chk(self.lib.nnj_pair_scores_full(self.h, _p(state), _p(mask), _p(out), B, n, L, _p(ws), ws.numel(),
                                                 self._stream()))
+        self._session_out(state)           # the rows of `state` now live in a session
         return out
 
     def pair_scores_incr(self, state, mask, ij_prev, logits_prev):
@@ -213,6 +231,7 @@ class Nnj:
         logits_prev = self._f32(logits_prev)
         assert tuple(logits_prev.shape) == (B, (n + 1) * n // 2)
         out = torch.empty((B, n * (n - 1) // 2), dtype=torch.float32, device=self.device)
+        self._session_in(state)
         ws = self.workspace(B, n + 1, L)
         self._chk(self.lib.nnj_pair_scores_incr(self.h, _p(state), _p(mask), _p(ij_prev), _p(logits_prev), _p(out),
                                                 B, n, L, _p(ws), ws.numel(), self._stream()))
@@ -230,6 +249,7 @@ class Nnj:
         B, n, L, _ = state.shape
         ij = self._i32(ij)
         out = torch.empty((B, 1, L, self.D), dtype=torch.float32, device=self.device)
+        self._session_in(state)
         ws = self.workspace(B, n, L)
         self._chk(self.lib.nnj_aggregate(self.h, _p(state), _p(ij), _p(out), B, n, L, _p(ws), ws.numel(),
                                          self._stream()))
@@ -240,9 +260,13 @@ class Nnj:
         B, n, L, _ = state.shape
         ij = self._i32(ij)
         out = torch.empty((B, n - 1, L, self.D), dtype=torch.float32, device=self.device)
+        self._session_in(state)
+        in_session = getattr(self, "_sess_tensor", None) is state
         ws = self.workspace(B, n, L)
         self._chk(self.lib.nnj_env_step(self.h, _p(state), _p(ij), _p(out), B, n, L, _p(ws), ws.numel(),
                                         self._stream()))
+        if in_session:
+            self._session_out(out)
         return out
 
     def select_pair(self, logits, n):
@@ -294,9 +318,11 @@ class Nnj:
         lo = torch.empty((B, n * (n - 1) // 2), dtype=torch.float32, device=self.device)
         cij = torch.empty((B, 2), dtype=torch.int32, device=self.device)
         gap = torch.empty((B,), dtype=torch.float32, device=self.device)
+        self._session_in(state)
         ws = self.workspace(B, n1, L)
         self._chk(self.lib.nnj_step(self.h, _p(state), _p(mask), _p(ij), _p(lp), _p(fn), _p(st), _p(lo), _p(cij),
                                     _p(gap), B, n, L, _p(ws), ws.numel(), self._stream()))
+        self._session_out(st)
         return dict(state=st, logits=lo, ij=cij, top2_gap=gap)
 
     def topology_hash(self, merges):

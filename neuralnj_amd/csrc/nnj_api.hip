@@ -664,6 +664,43 @@ int need_ws(nnj_handle* h, void* ws, size_t ws_bytes, int B, int T, int C) {
   return NNJ_OK;
 }
 
+// ---- sessions over the dense-state entry points (nnj_pair_scores_full / _incr, nnj_aggregate, nnj_env_step, nnj_step)
+// The reference's loop hands the dense state [B,n,C,D] from call to call.  The library keeps the rows of the tensor
+// it has last SEEN (nnj_pair_scores_full) or RETURNED (nnj_env_step, nnj_step) in slot layout inside the caller's
+// workspace, next to their cached transforms (U, K', beta) and the live list -- the rollout's own state.  A call
+// whose `state` is that very tensor (same pointer, workspace, B, L and row count; the caller has not written to it)
+// continues the session: no row is transformed again and the merge runs in place, like inside nnj_rollout_argmax.
+// Anything else runs stateless from the dense tensor, as before.
+struct SessView { float* S; float* base; LoopWs w; int* live; int* ijs; RowSet rs; };
+bool sess_matches(const nnj_handle* h, const void* ws, const float* state, int B, int n, int L) {
+  const nnj_handle::StepSession& ss = h->sess;
+  return ss.valid && ss.ws == ws && ss.last_out == state && ss.B == B && ss.L == L && ss.n == n;
+}
+SessView sess_view(void* ws, int B, int T0, int C) {
+  SessView v;
+  v.S = static_cast<float*>(ws);
+  v.base = v.S + align_up((size_t)B * T0 * C * 64, 64);
+  v.w = loop_ws(B, T0, C);
+  v.live = reinterpret_cast<int*>(v.base + v.w.live);
+  v.ijs = reinterpret_cast<int*>(v.base + v.w.ij);
+  v.rs.S = v.S; v.rs.U = v.base + v.w.U; v.rs.Kp = v.base + v.w.Kp; v.rs.beta_part = v.base + v.w.beta;
+  v.rs.bstride = (long)T0 * C * 64; v.rs.live = v.live; v.rs.live_stride = T0; v.rs.ntile32 = (C + 31) / 32;
+  return v;
+}
+// start a session from a dense tensor of T0 rows: copy into the slots, identity live list, row transforms
+int sess_begin(nnj_handle* h, const SessView& v, const float* state, int B, int T0, int C, hipStream_t st) {
+  HIPCHK(h, hipMemcpyAsync(v.S, state, (size_t)B * T0 * C * 64 * sizeof(float), hipMemcpyDeviceToDevice, st));
+  {
+    Scope sc(h, st, PK_MISC);
+    hipLaunchKernelGGL(k_init_live, dim3((unsigned)((B * T0 + 255) / 256)), dim3(256), 0, st, v.live, T0, B, T0);
+  }
+  return launch_row_xf(h, v.S, v.base + v.w.U, v.base + v.w.Kp, v.base + v.w.beta, (long)T0 * C * 64, T0, T0, B, C, st);
+}
+void sess_set(nnj_handle* h, const void* ws, const float* dense, int B, int T0, int L, int n) {
+  nnj_handle::StepSession& ss = h->sess;
+  ss.valid = true; ss.ws = ws; ss.last_out = dense; ss.B = B; ss.T0 = T0; ss.L = L; ss.n = n;
+}
+
 // Every entry point selects the handle's device; the caller's current device (torch's, in a single process that drives
 // several GPUs) is put back when the call returns.
 struct DevGuard {
@@ -849,21 +886,22 @@ int nnj_pair_scores_full(nnj_handle* h, const float* state, const uint8_t* mask,
   if (int rc = check_shape(h, B, n, L)) return rc;
   if (int rc = need_ws(h, ws, ws_bytes, B, n, L)) return rc;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  float* base = static_cast<float*>(ws) + align_up((size_t)B * n * L * 64, 64);
-  const LoopWs w = loop_ws(B, n, L);
-  RowSet rs = dense_rowset(h, state, base, w, B, n, L, st);
+  // first decode of a loop: the rows go into a session (see sess_matches) that the following nnj_env_step /
+  // nnj_pair_scores_incr / nnj_aggregate calls on the same tensors continue
+  const SessView v = sess_view(ws, B, n, L);
+  if (int rc = sess_begin(h, v, state, B, n, L, st)) return rc;
   PairGeom g;
-  int* ij = reinterpret_cast<int*>(base + w.ij);
-  if (int rc = scorer_mask(h, mask, base, w, B, L, st, &mask)) return rc;
-  if (int rc = launch_pair_scores(h, rs, ij, mask, base, w, PAIRS_FULL, n, B, L, g, st)) return rc;
+  if (int rc = scorer_mask(h, mask, v.base, v.w, B, L, st, &mask)) return rc;
+  if (int rc = launch_pair_scores(h, v.rs, v.ijs, mask, v.base, v.w, PAIRS_FULL, n, B, L, g, st)) return rc;
   {
     Scope sc(h, st, PK_ASSEMBLE);
     hipLaunchKernelGGL(k_assemble_argmax, dim3((unsigned)B), dim3(256), 0, st, g.score_src, g.nsc, g.ppad,
                        (const float*)nullptr, (const int*)nullptr, logits_out, (float*)nullptr, 0L, (const int*)nullptr,
-                       0L, (int*)nullptr, 0L, (float*)nullptr, 0L, ij, (int)PAIRS_FULL, n, (const float*)nullptr, 0L, 1.0f,
+                       0L, (int*)nullptr, 0L, (float*)nullptr, 0L, v.ijs, (int)PAIRS_FULL, n, (const float*)nullptr, 0L, 1.0f,
                        h->d_flag, (const int*)nullptr, (int*)nullptr, 0);
   }
   HIPCHK(h, hipGetLastError());
+  sess_set(h, ws, state, B, n, L, n);
   return NNJ_OK;
 }
 
@@ -873,24 +911,26 @@ int nnj_pair_scores_incr(nnj_handle* h, const float* state, const uint8_t* mask,
   DevGuard dev_guard;
   if (int rc = ready(h)) return rc;
   if (!state || !ij_prev || !logits_prev || !logits_out || n < 2) return fail(h, NNJ_ERR_ARG, "nnj_pair_scores_incr: bad argument");
-  if (int rc = check_shape(h, B, n + 1, L)) return rc;
-  if (int rc = need_ws(h, ws, ws_bytes, B, n + 1, L)) return rc;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  float* base = static_cast<float*>(ws) + align_up((size_t)B * (n + 1) * L * 64, 64);
-  const LoopWs w = loop_ws(B, n + 1, L);
-  RowSet rs = dense_rowset(h, state, base, w, B, n, L, st);
+  const bool cont = sess_matches(h, ws, state, B, n, L);
+  const int T0 = cont ? h->sess.T0 : n + 1;
+  if (int rc = check_shape(h, B, T0, L)) return rc;
+  if (int rc = need_ws(h, ws, ws_bytes, B, T0, L)) return rc;      // (invalidates the session: re-validated below)
   PairGeom g;
-  int* ij = reinterpret_cast<int*>(base + w.ij);
-  if (int rc = scorer_mask(h, mask, base, w, B, L, st, &mask)) return rc;
-  if (int rc = launch_pair_scores(h, rs, ij_prev, mask, base, w, PAIRS_INCR, n, B, L, g, st)) return rc;
+  const SessView v = sess_view(ws, B, T0, L);
+  RowSet rs = v.rs;
+  if (!cont) rs = dense_rowset(h, state, v.base, v.w, B, n, L, st);
+  if (int rc = scorer_mask(h, mask, v.base, v.w, B, L, st, &mask)) return rc;
+  if (int rc = launch_pair_scores(h, rs, ij_prev, mask, v.base, v.w, PAIRS_INCR, n, B, L, g, st)) return rc;
   {
     Scope sc(h, st, PK_ASSEMBLE);
     hipLaunchKernelGGL(k_assemble_argmax, dim3((unsigned)B), dim3(256), 0, st, g.score_src, g.nsc, g.ppad,
                        logits_prev, ij_prev, logits_out, (float*)nullptr, 0L, (const int*)nullptr, 0L, (int*)nullptr, 0L,
-                       (float*)nullptr, 0L, ij, (int)PAIRS_INCR, n, (const float*)nullptr, 0L, 1.0f, h->d_flag,
+                       (float*)nullptr, 0L, v.ijs, (int)PAIRS_INCR, n, (const float*)nullptr, 0L, 1.0f, h->d_flag,
                        (const int*)nullptr, (int*)nullptr, 0);
   }
   HIPCHK(h, hipGetLastError());
+  if (cont) sess_set(h, ws, state, B, T0, L, n);
   return NNJ_OK;
 }
 
@@ -911,14 +951,17 @@ int nnj_aggregate(nnj_handle* h, const float* state, const int32_t* ij, float* o
   DevGuard dev_guard;
   if (int rc = ready(h)) return rc;
   if (!state || !ij || !out_row || n < 2) return fail(h, NNJ_ERR_ARG, "nnj_aggregate: bad argument");
-  if (int rc = check_shape(h, B, n, L)) return rc;
-  if (int rc = need_ws(h, ws, ws_bytes, B, n, L)) return rc;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  float* base = static_cast<float*>(ws) + align_up((size_t)B * n * L * 64, 64);
-  const LoopWs w = loop_ws(B, n, L);
-  RowSet rs = dense_rowset(h, state, base, w, B, n, L, st);
-  if (int rc = launch_aggregate(h, rs, ij, base, w, out_row, nullptr, nullptr, nullptr, (long)L * 64, 1, 0, n, B, L, st)) return rc;
+  const bool cont = sess_matches(h, ws, state, B, n, L);
+  const int T0 = cont ? h->sess.T0 : n;
+  if (int rc = check_shape(h, B, T0, L)) return rc;
+  if (int rc = need_ws(h, ws, ws_bytes, B, T0, L)) return rc;
+  const SessView v = sess_view(ws, B, T0, L);
+  RowSet rs = v.rs;
+  if (!cont) rs = dense_rowset(h, state, v.base, v.w, B, n, L, st);
+  if (int rc = launch_aggregate(h, rs, ij, v.base, v.w, out_row, nullptr, nullptr, nullptr, (long)L * 64, 1, 0, n, B, L, st)) return rc;
   HIPCHK(h, hipGetLastError());
+  if (cont) sess_set(h, ws, state, B, T0, L, n);           // the rows are untouched: the session goes on
   return NNJ_OK;
 }
 
@@ -927,14 +970,29 @@ int nnj_env_step(nnj_handle* h, const float* state, const int32_t* ij, float* st
   DevGuard dev_guard;
   if (int rc = ready(h)) return rc;
   if (!state || !ij || !state_out || n < 3) return fail(h, NNJ_ERR_ARG, "nnj_env_step: bad argument (n must be >= 3)");
-  if (int rc = check_shape(h, B, n, L)) return rc;
-  if (int rc = need_ws(h, ws, ws_bytes, B, n, L)) return rc;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  float* base = static_cast<float*>(ws) + align_up((size_t)B * n * L * 64, 64);
-  const LoopWs w = loop_ws(B, n, L);
-  RowSet rs = dense_rowset(h, state, base, w, B, n, L, st);
-  float* merged = base + w.merged;
-  if (int rc = launch_aggregate(h, rs, ij, base, w, merged, nullptr, nullptr, nullptr, (long)L * 64, 1, 0, n, B, L, st)) return rc;
+  const bool cont = sess_matches(h, ws, state, B, n, L);
+  const int T0 = cont ? h->sess.T0 : n;
+  if (int rc = check_shape(h, B, T0, L)) return rc;
+  if (int rc = need_ws(h, ws, ws_bytes, B, T0, L)) return rc;      // (invalidates the session: re-validated below)
+  const SessView v = sess_view(ws, B, T0, L);
+  if (cont) {
+    // in the session: merged row in place over slot(i) with its transforms, position j leaves the list, and the dense
+    // tensor the reference's env.step returns (environment.py:833-835) is one gather of the live rows
+    HIPCHK(h, hipMemcpyAsync(v.ijs, ij, (size_t)B * 2 * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+    if (int rc = launch_aggregate(h, v.rs, v.ijs, v.base, v.w, v.S, v.base + v.w.U, v.base + v.w.Kp, v.base + v.w.beta,
+                                  v.rs.bstride, T0, 1, n, B, L, st)) return rc;
+    Scope sc(h, st, PK_MISC);
+    hipLaunchKernelGGL(k_update_live, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, st, v.live, T0, (const int*)v.ijs, B, n);
+    hipLaunchKernelGGL(k_gather_rows, dim3(16, (unsigned)(n - 1), (unsigned)B), dim3(256), 0, st, (const float*)v.S,
+                       (const int*)v.live, T0, state_out, n - 1, (long)L * 16, (long)T0 * L * 16);
+    HIPCHK(h, hipGetLastError());
+    sess_set(h, ws, state_out, B, T0, L, n - 1);
+    return NNJ_OK;
+  }
+  RowSet rs = dense_rowset(h, state, v.base, v.w, B, n, L, st);
+  float* merged = v.base + v.w.merged;
+  if (int rc = launch_aggregate(h, rs, ij, v.base, v.w, merged, nullptr, nullptr, nullptr, (long)L * 64, 1, 0, n, B, L, st)) return rc;
   {
     Scope sc(h, st, PK_MISC);
     const long row_f4 = (long)L * 16;
@@ -942,6 +1000,12 @@ int nnj_env_step(nnj_handle* h, const float* state, const int32_t* ij, float* st
                        state_out, n, row_f4);
   }
   HIPCHK(h, hipGetLastError());
+  return NNJ_OK;
+}
+
+int nnj_session_reset(nnj_handle* h) {
+  if (!h) return fail(nullptr, NNJ_ERR_ARG, "null handle");
+  h->sess.valid = false;
   return NNJ_OK;
 }
 
@@ -973,23 +1037,18 @@ int nnj_step(nnj_handle* h, const float* state, const uint8_t* mask, const int32
   // when `state` is the tensor the previous call returned (same workspace, batch, sites and row count); any other
   // input starts a new one from the dense tensor (copy into slots + row transforms).  state_out is the dense
   // gather of the live rows the reference's env.step hands back (environment.py:833-835).
-  nnj_handle::StepSession& ss = h->sess;
-  const bool cont = ss.valid && ss.ws == ws && ss.last_out == state && ss.B == B && ss.L == L && ss.n == n + 1;
-  const int T0 = cont ? ss.T0 : n + 1;
+  const bool cont = sess_matches(h, ws, state, B, n + 1, L);
+  const int T0 = cont ? h->sess.T0 : n + 1;
   if (int rc = check_shape(h, B, T0, L)) return rc;
   if (int rc = need_ws(h, ws, ws_bytes, B, T0, L)) return rc;      // (invalidates the session: re-validated below)
-  float* S = static_cast<float*>(ws);
-  float* base = S + align_up((size_t)B * T0 * C * 64, 64);
-  const LoopWs w = loop_ws(B, T0, C);
-  int* live = reinterpret_cast<int*>(base + w.live);
-  int* ijs = reinterpret_cast<int*>(base + w.ij);
+  const SessView v = sess_view(ws, B, T0, C);
+  float* S = v.S;
+  float* base = v.base;
+  const LoopWs w = v.w;
+  int* live = v.live;
+  int* ijs = v.ijs;
   if (!cont) {
-    HIPCHK(h, hipMemcpyAsync(S, state, (size_t)B * T0 * C * 64 * sizeof(float), hipMemcpyDeviceToDevice, st));
-    {
-      Scope sc(h, st, PK_MISC);
-      hipLaunchKernelGGL(k_init_live, dim3((unsigned)((B * T0 + 255) / 256)), dim3(256), 0, st, live, T0, B, T0);
-    }
-    launch_row_xf(h, S, base + w.U, base + w.Kp, base + w.beta, (long)T0 * C * 64, T0, T0, B, C, st);
+    if (int rc = sess_begin(h, v, state, B, T0, C, st)) return rc;
   }
   RowSet rs;
   rs.S = S; rs.U = base + w.U; rs.Kp = base + w.Kp; rs.beta_part = base + w.beta;
@@ -1019,7 +1078,7 @@ int nnj_step(nnj_handle* h, const float* state, const uint8_t* mask, const int32
                        T0, state_out, n, (long)C * 16, (long)T0 * C * 16);
   }
   HIPCHK(h, hipGetLastError());
-  ss.valid = true; ss.ws = ws; ss.last_out = state_out; ss.B = B; ss.T0 = T0; ss.L = L; ss.n = n;
+  sess_set(h, ws, state_out, B, T0, L, n);
   return NNJ_OK;
 }
 

@@ -61,6 +61,23 @@ class UnrootedPhyloTree(PhyloTree):
         self.min_seq_index = rooted.min_seq_index
         self.log_score = rooted.log_score
         self.topo_repr = format_rtree_topology(self, True, None)
+        self._keys = None
+        self._tuple = None
+
+    # the nested (left, len, right, len) tuples (what raxmlpy.treestr_to_tuples yields in the reference) are built
+    # when somebody reads them: evaluate_loglikelihood returns the best tree's only, and building them for every tree
+    # of a batch of 256 was a tenth of the host time of a rollout
+    @property
+    def rtree_op_tuple(self):
+        if self._tuple is None and self._keys is not None:
+            self._tuple = _newick_tuple(self, self._keys)
+        return self._tuple
+
+    @rtree_op_tuple.setter
+    def rtree_op_tuple(self, v):
+        self._tuple = v
+
+    utree_op_tuple = rtree_op_tuple
 
 
 def format_rtree_topology(tree, at_root=False, sequence_keys=None):
@@ -136,7 +153,7 @@ class PhyInferEnv:
             new_tree.log_score = NO_SCORE if log_score is None else float(log_score)
             ut = UnrootedPhyloTree(new_tree)
             ut.utree_op_str = format_rtree(new_tree, True, None, keys)
-            ut.rtree_op_tuple = ut.utree_op_tuple = _newick_tuple(new_tree, keys)
+            ut._keys = keys                                    # rtree_op_tuple / utree_op_tuple: built on first read
             self.states[b] = PhylogeneticTreeState([ut])
             return True
         trees = st.subtrees
@@ -162,6 +179,13 @@ class PhyInferEnv:
                 raise NotImplementedError("the mean-aggregate fallback (agent=None) is not part of the hot path")
             dev = self.state_tensor.device
             ij_t = torch.tensor(ij, dtype=torch.long, device=dev)
+            if hasattr(agent, "_context") and getattr(agent, "batch_input", None) is self.state_tensor:
+                # this package's PhyloATTN: aggregate + compaction as ONE device call (nnj_env_step).  When the state
+                # is the tensor the preceding decode_zxr scored, the library continues its session: merged row in
+                # place, no row transformed again, one gather for the dense tensor returned here (include/nnj.h,
+                # "Sessions") -- instead of aggregate + cat + gather, i.e. two copies of the whole state per step
+                self.state_tensor = agent._context().env_step(self.state_tensor, ij_t)
+                return done
             new = agent.aggregate(None, None, (ij_t[:, 0], ij_t[:, 1]), batchwise_ij_indices=True)
             base = []
             for (i, j) in ij:

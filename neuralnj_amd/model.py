@@ -88,7 +88,10 @@ class PhyloATTN(nn.Module):
         if self._ctx is None or self._ctx.device != dev:
             self._ctx = Nnj(self.cfgs, dev)
             self._packed_version = None
-        version = sum(p._version for p in self.parameters()) + 7919 * id(self._ctx)
+        plist = self.__dict__.get("_plist")              # (walking the module tree per call cost 0.5 ms)
+        if plist is None:
+            plist = self.__dict__["_plist"] = list(self.parameters())
+        version = sum(p._version for p in plist) + 7919 * id(self._ctx)
         if version != self._packed_version:
             sd = {k: v.detach() for k, v in self.state_dict().items()}
             self._ctx.load_weights(_weights.pack(self.cfgs, sd))

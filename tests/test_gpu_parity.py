@@ -315,6 +315,50 @@ def test_fused_step_reproduces_the_rollout(name, ctx_cache):
     g.check_numeric()
 
 
+@pytest.mark.parametrize("name", ["synth_b2_t8_l128_s1", "synth_b1_t20_l256_s0"])
+def test_dense_state_session_reproduces_the_rollout(name, ctx_cache):
+    """The reference's call sequence decode_zxr -> argmax -> env.step -> decode_zxr ... through the dense-state entry
+    points (nnj_pair_scores_full / nnj_env_step / nnj_pair_scores_incr): handed the tensors it produced, the library
+    continues a session (include/nnj.h) and gives the tables of nnj_rollout_argmax bit for bit; a state tensor the
+    caller has rewritten in place is NOT taken for the session's (stateless path, same values within tolerance)."""
+    z, cfgs, packed = load_golden(name)
+    g = ctx_cache(cfgs, packed)
+    codes, mask = torch.from_numpy(z["codes"]), torch.from_numpy(z["mask"])
+    B, T, L = z["codes"].shape
+    ref = g.rollout_argmax(codes, mask, want_trace=True)
+    tables = split_trace(ref["logits"].cpu().numpy(), T)
+    merges = ref["merges"].cpu().numpy()
+    state = g.encode(codes, mask)
+    logits = g.pair_scores_full(state, mask)
+    assert np.array_equal(logits.cpu().numpy(), tables[0])
+    for step, n in enumerate(range(T, 2, -1)):
+        ij = torch.from_numpy(merges[:, step].copy())
+        if step == 2:
+            # a merged row computed from the session's rows, not in place: the session goes on afterwards
+            row = g.aggregate(state, ij)
+        new_state = g.env_step(state, ij)
+        if step == 2:
+            slot = int(merges[0, step, 0])
+            assert torch.equal(row[0, 0], new_state[0, slot])
+        state = new_state
+        assert state.shape[1] == n - 1
+        logits = g.pair_scores_incr(state, mask, ij, logits)
+        assert np.array_equal(logits.cpu().numpy(), tables[step + 1]), f"table after merge {step + 1}"
+    g.check_numeric()
+    # in-place write to the session's tensor: the wrapper resets the session, the call runs stateless
+    state = g.encode(codes, mask)
+    l0 = g.pair_scores_full(state, mask)
+    ij0 = torch.from_numpy(merges[:, 0].copy())
+    s1 = g.env_step(state, ij0)
+    want = g.pair_scores_incr(s1, mask, ij0, l0).cpu().numpy()
+    s1.mul_(1.0)                                            # bumps the version counter, values unchanged
+    got = g.pair_scores_incr(s1, mask, ij0, l0).cpu().numpy()
+    np.testing.assert_allclose(got, want, atol=RTOL * np.abs(want).max())
+    s1.add_(1.0)                                            # really different rows: the result must follow them
+    moved = g.pair_scores_incr(s1, mask, ij0, l0).cpu().numpy()
+    assert np.abs(moved - want).max() > 1e-3 * np.abs(want).max()
+
+
 def test_batch_shards_reproduce_the_whole_batch(ctx_cache):
     """Multi-GPU sharding is a contiguous split of the batch: a shard must give what the same
     alignments give inside the whole batch.  Launch geometry (site chunks per workgroup, small-batch kernels)

@@ -38,7 +38,8 @@ def test_index_map_all_merges(n):
         lib.nnjo_index_map_one(C.c_int32(n), C.c_int32(ip), C.c_int32(jp), buf.ctypes.data_as(C.c_void_p))
         assert buf.tolist() == a.tolist()
     got = utils.get_score_indices_to_prev(np.array([[0, 1], [1, n]]), None, n, 2)
-    assert got[0] == utils.index_map_one(n, 0, 1).tolist() and got[1] == utils.index_map_one(n, 1, n).tolist()
+    assert np.asarray(got).dtype == np.int64 and np.asarray(got).shape == (2, n * (n - 1) // 2)
+    assert list(got[0]) == utils.index_map_one(n, 0, 1).tolist() and list(got[1]) == utils.index_map_one(n, 1, n).tolist()
 
 
 def test_config_defaults_and_yaml():
