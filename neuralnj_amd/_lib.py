@@ -138,7 +138,8 @@ class Nnj:
             pass
 
     def _stream(self):
-        return _vp(torch.cuda.current_stream(self.device).cuda_stream)
+        self._last_stream = torch.cuda.current_stream(self.device)      # the stream the workspace was last used on
+        return _vp(self._last_stream.cuda_stream)
 
     # The library continues a session when it is handed the very tensor it last saw / returned (include/nnj.h,
     # "Sessions").  The wrapper keeps that tensor alive (its address cannot be reused) and remembers its version
@@ -160,7 +161,11 @@ class Nnj:
         need = C.c_size_t()
         self._chk(self.lib.nnj_workspace_bytes(self.h, B, T, L, C.byref(need)))
         if self._ws is None or self._ws.numel() < need.value:
+            if self._ws is not None and getattr(self, "_last_stream", None) is not None:
+                # kernels of the last call may still read the old buffer on a stream other than the allocator's
+                self._ws.record_stream(self._last_stream)
             self._ws = None
+            self._sess_tensor = None                # a session lives in the workspace it was started in
             self._ws = torch.empty(need.value, dtype=torch.uint8, device=self.device)
         return self._ws
 
