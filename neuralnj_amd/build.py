@@ -57,5 +57,39 @@ def build_hip(force: bool = False, verbose: bool = False) -> str:
     return LIB
 
 
+# ---- libnnj_train_hip.so: the differentiable operators of the Finetune mode (include/nnj_train.h), a library of its
+# own (the inference library and its source hash -- which profiles/traffic.json is keyed on -- do not depend on it)
+TRAIN_CSRC = os.path.join(HERE, "csrc_train")
+TRAIN_LIB = os.path.join(HERE, "libnnj_train_hip.so")
+TRAIN_STAMP = TRAIN_LIB + ".srchash"
+
+
+def train_source_hash() -> str:
+    h = hashlib.sha256(" ".join(FLAGS).encode())
+    for f in sorted(glob.glob(os.path.join(TRAIN_CSRC, "*"))) + [os.path.join(HERE, "..", "include", "nnj_train.h")]:
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
+def build_train(force: bool = False, verbose: bool = False) -> str:
+    stale = not os.path.exists(TRAIN_LIB) or not os.path.exists(TRAIN_STAMP)
+    if not stale:
+        with open(TRAIN_STAMP) as f:
+            stale = f.read().strip() != train_source_hash()
+    if not force and not stale:
+        return TRAIN_LIB
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    cmd = [hipcc] + FLAGS + ["-o", TRAIN_LIB, "nnj_train.hip"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, cwd=TRAIN_CSRC, check=True)
+    with open(TRAIN_STAMP, "w") as f:
+        f.write(train_source_hash() + "\n")
+    return TRAIN_LIB
+
+
 if __name__ == "__main__":
     print(build_hip(force=True, verbose=True))
+    print(build_train(force=True, verbose=True))

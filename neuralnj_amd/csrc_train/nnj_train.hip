@@ -1,0 +1,383 @@
+// nnj_train.hip -- libnnj_train_hip.so (include/nnj_train.h): forward and backward kernels of the operators of the
+// reference's Finetune mode, gfx950.  A first, unfused path: fp32 FMA arithmetic, one kernel per operator; the graph
+// is kept by torch.autograd.Function objects on the host (neuralnj_amd/train_ops.py).  No CPU fallback.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/nnj_train.h"
+
+namespace {
+char g_err[512] = "";
+int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+#define CHK_LAUNCH()                                                                              \
+  do {                                                                                            \
+    hipError_t e_ = hipGetLastError();                                                            \
+    if (e_ != hipSuccess) return fail(-3, "%s: %s", __func__, hipGetErrorString(e_));             \
+  } while (0)
+inline unsigned blocks_for(int64_t n, int per) { return (unsigned)((n + per - 1) / per); }
+
+// ------------------------------------------------------------------ strided batched GEMM
+// 64 x 64 output tile per workgroup of 256 threads (4 x 4 outputs per thread), k in steps of 16 through LDS.
+// Loads walk whichever of (m, k) / (k, n) has unit stride fastest, so nn.Linear operands, their transposes and the
+// head-strided attention operands are all read in contiguous pieces.
+constexpr int TM = 64, TN = 64, TK = 16;
+__global__ __launch_bounds__(256) void k_gemm(nnjt_gemm g) {
+  __shared__ float As[TK][TM + 4];
+  __shared__ float Bs[TK][TN + 4];
+  const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+  const int m0 = blockIdx.y * TM, n0 = blockIdx.x * TN;
+  const int b1 = blockIdx.z / g.nb2, b2 = blockIdx.z % g.nb2;
+  const float* A = g.A + b1 * g.sAb1 + b2 * g.sAb2;
+  const float* B = g.B + b1 * g.sBb1 + b2 * g.sBb2;
+  float* C = g.C + b1 * g.sCb1 + b2 * g.sCb2;
+  float acc[4][4] = {};
+  const bool a_kfast = g.sAk == 1, b_kfast = g.sBk == 1;
+  for (int k0 = 0; k0 < g.K; k0 += TK) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int e = tid + 256 * i;
+      {
+        const int m = a_kfast ? e / TK : e % TM, k = a_kfast ? e % TK : e / TM;
+        const bool ok = m0 + m < g.M && k0 + k < g.K;
+        As[k][m] = ok ? A[(int64_t)(m0 + m) * g.sAm + (int64_t)(k0 + k) * g.sAk] : 0.f;
+      }
+      {
+        const int n = b_kfast ? e / TK : e % TN, k = b_kfast ? e % TK : e / TN;
+        const bool ok = n0 + n < g.N && k0 + k < g.K;
+        Bs[k][n] = ok ? B[(int64_t)(k0 + k) * g.sBk + (int64_t)(n0 + n) * g.sBn] : 0.f;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < TK; ++k) {
+      float a[4], b[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { a[i] = As[k][ty * 4 + i]; b[i] = Bs[k][tx * 4 + i]; }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(a[i], b[j], acc[i][j]);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int m = m0 + ty * 4 + i, n = n0 + tx * 4 + j;
+      if (m < g.M && n < g.N) {
+        float* c = C + (int64_t)m * g.sCm + (int64_t)n * g.sCn;
+        *c = g.beta == 0.f ? g.alpha * acc[i][j] : g.alpha * acc[i][j] + g.beta * *c;
+      }
+    }
+}
+
+// ------------------------------------------------------------------ bias, column sums
+__global__ void k_add_bias(float* y, const float* __restrict__ bias, int64_t n, int cols) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) y[i] += bias[i % cols];
+}
+// out[c] += sum_r x[r, c]: a workgroup owns 256 rows, thread = column (cols <= 256), one atomic per column and block
+__global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ x, float* out, int64_t rows, int cols) {
+  const int c = threadIdx.x;
+  if (c >= cols) return;
+  const int64_t r0 = (int64_t)blockIdx.x * 256, r1 = r0 + 256 < rows ? r0 + 256 : rows;
+  float s = 0.f;
+  for (int64_t r = r0; r < r1; ++r) s += x[r * cols + c];
+  atomicAdd(out + c, s);
+}
+
+// ------------------------------------------------------------------ LayerNorm over 64 features: one wavefront per row
+__global__ __launch_bounds__(256) void k_ln_fwd(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                const float* __restrict__ beta, float* __restrict__ y,
+                                                float* __restrict__ mean, float* __restrict__ rstd, int64_t rows) {
+  const int lane = threadIdx.x & 63;
+  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  const float v = x[r * 64 + lane];
+  float s = v;
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o);
+  const float mu = s * (1.0f / 64.0f);
+  const float d = v - mu;
+  float q = d * d;
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) q += __shfl_xor(q, o);
+  const float rs = rsqrtf(q * (1.0f / 64.0f) + 1e-5f);
+  y[r * 64 + lane] = d * rs * gamma[lane] + beta[lane];
+  if (lane == 0) { mean[r] = mu; rstd[r] = rs; }
+}
+// dx = rstd * (g - mean(g) - xhat * mean(g * xhat)), g = dy * gamma; dgamma += sum dy * xhat; dbeta += sum dy.
+// A workgroup walks 64 rows per wave and adds its partial sums with one atomic per feature and wave.
+__global__ __launch_bounds__(256) void k_ln_bwd(const float* __restrict__ dy, const float* __restrict__ x,
+                                                const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                const float* __restrict__ rstd, float* __restrict__ dx,
+                                                float* dgamma, float* dbeta, int64_t rows) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float gm = gamma[lane];
+  float ag = 0.f, ab = 0.f;
+  const int64_t r0 = ((int64_t)blockIdx.x * 4 + wave) * 64;
+  for (int64_t r = r0; r < r0 + 64 && r < rows; ++r) {
+    const float xh = (x[r * 64 + lane] - mean[r]) * rstd[r];
+    const float d = dy[r * 64 + lane];
+    const float g = d * gm;
+    float s1 = g, s2 = g * xh;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+    dx[r * 64 + lane] = rstd[r] * (g - s1 * (1.0f / 64.0f) - xh * s2 * (1.0f / 64.0f));
+    ag += d * xh;
+    ab += d;
+  }
+  atomicAdd(dgamma + lane, ag);
+  atomicAdd(dbeta + lane, ab);
+}
+
+// ------------------------------------------------------------------ elementwise
+__global__ void k_gelu_fwd(const float* __restrict__ x, float* __restrict__ y, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) { const float v = x[i]; y[i] = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
+}
+__global__ void k_gelu_bwd(const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ dx, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    const float v = x[i];
+    const float cdf = 0.5f * (1.0f + erff(v * 0.70710678118654752440f));
+    const float pdf = 0.39894228040143267794f * expf(-0.5f * v * v);
+    dx[i] = dy[i] * (cdf + v * pdf);
+  }
+}
+__device__ __forceinline__ float sigm(float t) { return 1.0f / (1.0f + expf(-t)); }
+__global__ void k_gate_fwd(const float* __restrict__ h, const float* __restrict__ a, const float* __restrict__ b,
+                           float* __restrict__ out, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) { const float z = sigm(h[i]); out[i] = z * a[i] + (1.0f - z) * b[i]; }
+}
+__global__ void k_gate_bwd(const float* __restrict__ dout, const float* __restrict__ h, const float* __restrict__ a,
+                           const float* __restrict__ b, float* __restrict__ dh, float* __restrict__ da,
+                           float* __restrict__ db, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    const float z = sigm(h[i]), d = dout[i];
+    dh[i] = d * (a[i] - b[i]) * z * (1.0f - z);
+    da[i] = d * z;
+    db[i] = d * (1.0f - z);
+  }
+}
+__global__ void k_axpby(float a, const float* x, float b, const float* y, float* out, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = a * x[i] + (y ? b * y[i] : 0.f);
+}
+__global__ void k_rowscale(const float* __restrict__ x, const float* __restrict__ s, float* __restrict__ out,
+                           int64_t n, int cols) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = x[i] * s[i / cols];
+}
+__global__ void k_fill_where(float* x, const uint8_t* __restrict__ sel, float value, int64_t n, int inner, int sel_rows,
+                             int cols) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int64_t r = i / cols;
+  const int c = (int)(i % cols);
+  if (sel[((r / inner) % sel_rows) * cols + c]) x[i] = value;
+}
+
+// ------------------------------------------------------------------ softmax over the last dim: one wavefront per row
+__global__ __launch_bounds__(256) void k_softmax_fwd(const float* __restrict__ x, const uint8_t* __restrict__ keep,
+                                                     float* __restrict__ y, int64_t rows, int cols) {
+  const int lane = threadIdx.x & 63;
+  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  const float* xr = x + r * cols;
+  const uint8_t* kr = keep ? keep + r * cols : nullptr;
+  float m = -INFINITY;
+  for (int c = lane; c < cols; c += 64)
+    if (!kr || kr[c]) m = fmaxf(m, xr[c]);
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  float s = 0.f;
+  for (int c = lane; c < cols; c += 64)
+    if (!kr || kr[c]) s += expf(xr[c] - m);
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o);
+  const float inv = 1.0f / s;
+  for (int c = lane; c < cols; c += 64) y[r * cols + c] = (!kr || kr[c]) ? expf(xr[c] - m) * inv : 0.f;
+}
+__global__ __launch_bounds__(256) void k_softmax_bwd(const float* __restrict__ dy, const float* __restrict__ y,
+                                                     float* __restrict__ dx, int64_t rows, int cols) {
+  const int lane = threadIdx.x & 63;
+  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  float s = 0.f;
+  for (int c = lane; c < cols; c += 64) s += y[r * cols + c] * dy[r * cols + c];
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o);
+  for (int c = lane; c < cols; c += 64) dx[r * cols + c] = y[r * cols + c] * (dy[r * cols + c] - s);
+}
+
+// ------------------------------------------------------------------ row gathers
+__global__ void k_gather_rows(const float* __restrict__ src, const int64_t* __restrict__ idx, float* __restrict__ out,
+                              int n, int p, int64_t width) {
+  const int b = blockIdx.z, q = blockIdx.y;
+  const int64_t row = idx[(int64_t)b * p + q];
+  const float* s = src + ((int64_t)b * n + row) * width;
+  float* o = out + ((int64_t)b * p + q) * width;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < width; i += (int64_t)gridDim.x * blockDim.x) o[i] = s[i];
+}
+__global__ void k_scatter_rows_add(const float* __restrict__ dout, const int64_t* __restrict__ idx, float* dsrc, int n,
+                                   int p, int64_t width) {
+  const int b = blockIdx.z, q = blockIdx.y;
+  const int64_t row = idx[(int64_t)b * p + q];
+  float* s = dsrc + ((int64_t)b * n + row) * width;
+  const float* o = dout + ((int64_t)b * p + q) * width;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < width; i += (int64_t)gridDim.x * blockDim.x)
+    atomicAdd(s + i, o[i]);
+}
+
+// ------------------------------------------------------------------ 5-d permuted copy
+struct Perm5 { int64_t d[5], s[5]; };
+__global__ void k_permute5(const float* in, float* out, Perm5 p, int64_t n, int inverse) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int64_t rem = i, off = 0;
+#pragma unroll
+  for (int k = 4; k >= 0; --k) { off += (rem % p.d[k]) * p.s[k]; rem /= p.d[k]; }
+  if (inverse) const_cast<float*>(in)[off] = out[i];
+  else out[i] = in[off];
+}
+}  // namespace
+
+extern "C" {
+int nnjt_abi_version(void) { return 1; }
+const char* nnjt_last_error(void) { return g_err; }
+
+int nnjt_gemm_run(const nnjt_gemm* g, void* stream) {
+  if (!g || !g->A || !g->B || !g->C) return fail(-1, "nnjt_gemm_run: null operand");
+  if (g->M <= 0 || g->N <= 0 || g->K <= 0 || g->nb1 <= 0 || g->nb2 <= 0) return fail(-1, "nnjt_gemm_run: empty shape");
+  const int64_t nb = (int64_t)g->nb1 * g->nb2;
+  if (nb > 65535) return fail(-1, "nnjt_gemm_run: more than 65535 batch entries (%lld)", (long long)nb);
+  const dim3 grid((g->N + TN - 1) / TN, (g->M + TM - 1) / TM, (unsigned)nb);
+  hipLaunchKernelGGL(k_gemm, grid, dim3(256), 0, static_cast<hipStream_t>(stream), *g);
+  CHK_LAUNCH();
+  return 0;
+}
+int nnjt_add_bias(float* y, const float* bias, int64_t rows, int32_t cols, void* stream) {
+  if (!y || !bias) return fail(-1, "nnjt_add_bias: null");
+  const int64_t n = rows * cols;
+  hipLaunchKernelGGL(k_add_bias, dim3(blocks_for(n, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), y, bias, n, cols);
+  CHK_LAUNCH();
+  return 0;
+}
+int nnjt_colsum(const float* x, float* out, int64_t rows, int32_t cols, void* stream) {
+  if (!x || !out || cols > 256) return fail(-1, "nnjt_colsum: null or more than 256 columns");
+  hipLaunchKernelGGL(k_colsum, dim3(blocks_for(rows, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), x, out, rows, cols);
+  CHK_LAUNCH();
+  return 0;
+}
+int nnjt_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
+                       int64_t rows, int32_t cols, void* stream) {
+  if (cols != 64) return fail(-2, "nnjt_layernorm: 64 features (embed_dim of the shipped model), got %d", cols);
+  hipLaunchKernelGGL(k_ln_fwd, dim3(blocks_for(rows, 4)), dim3(256), 0, static_cast<hipStream_t>(stream), x, gamma, beta, y,
+                     mean, rstd, rows);
+  CHK_LAUNCH();
+  return 0;
+}
+int nnjt_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
+                       float* dx, float* dgamma, float* dbeta, int64_t rows, int32_t cols, void* stream) {
+  if (cols != 64) return fail(-2, "nnjt_layernorm: 64 features, got %d", cols);
+  hipLaunchKernelGGL(k_ln_bwd, dim3(blocks_for(rows, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), dy, x, gamma,
+                     mean, rstd, dx, dgamma, dbeta, rows);
+  CHK_LAUNCH();
+  return 0;
+}
+int nnjt_gelu_fwd(const float* x, float* y, int64_t n, void* stream) {
+  hipLaunchKernelGGL(k_gelu_fwd, dim3(blocks_for(n, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), x, y, n);
+  CHK_LAUNCH();
+  return 0;
+}
+int nnjt_gelu_bwd(const float* dy, const float* x, float* dx, int64_t n, void* stream) {
+  hipLaunchKernelGGL(k_gelu_bwd, dim3(blocks_for(n, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), dy, x, dx, n);
+  CHK_LAUNCH();
+  return 0;
+}
+int nnjt_gate_fwd(const float* h, const float* a, const float* b, float* out, int64_t n, void* stream) {
+  hipLaunchKernelGGL(k_gate_fwd, dim3(blocks_for(n, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), h, a, b, out, n);
+  CHK_LAUNCH();
+  return 0;
+}
+int nnjt_gate_bwd(const float* dout, const float* h, const float* a, const float* b, float* dh, float* da, float* db,
+                  int64_t n, void* stream) {
+  hipLaunchKernelGGL(k_gate_bwd, dim3(blocks_for(n, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), dout, h, a, b, dh,
+                     da, db, n);
+  CHK_LAUNCH();
+  return 0;
+}
+int nnjt_softmax_fwd(const float* x, const uint8_t* keep, float* y, int64_t rows, int32_t cols, void* stream) {
+  hipLaunchKernelGGL(k_softmax_fwd, dim3(blocks_for(rows, 4)), dim3(256), 0, static_cast<hipStream_t>(stream), x, keep, y,
+                     rows, cols);
+  CHK_LAUNCH();
+  return 0;
+}
+int nnjt_softmax_bwd(const float* dy, const float* y, float* dx, int64_t rows, int32_t cols, void* stream) {
+  hipLaunchKernelGGL(k_softmax_bwd, dim3(blocks_for(rows, 4)), dim3(256), 0, static_cast<hipStream_t>(stream), dy, y, dx,
+                     rows, cols);
+  CHK_LAUNCH();
+  return 0;
+}
+int nnjt_axpby(float a, const float* x, float b, const float* y, float* out, int64_t n, void* stream) {
+  if (!x || !out) return fail(-1, "nnjt_axpby: null");
+  hipLaunchKernelGGL(k_axpby, dim3(blocks_for(n, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), a, x, b, y, out, n);
+  CHK_LAUNCH();
+  return 0;
+}
+int nnjt_rowscale(const float* x, const float* s, float* out, int64_t rows, int32_t cols, void* stream) {
+  const int64_t n = rows * cols;
+  hipLaunchKernelGGL(k_rowscale, dim3(blocks_for(n, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), x, s, out, n, cols);
+  CHK_LAUNCH();
+  return 0;
+}
+int nnjt_fill_where(float* x, const uint8_t* sel, float value, int64_t rows, int32_t inner, int32_t sel_rows,
+                    int32_t cols, void* stream) {
+  const int64_t n = rows * cols;
+  hipLaunchKernelGGL(k_fill_where, dim3(blocks_for(n, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), x, sel, value, n,
+                     inner, sel_rows, cols);
+  CHK_LAUNCH();
+  return 0;
+}
+int nnjt_gather_rows(const float* src, const int64_t* idx, float* out, int32_t B, int32_t n, int32_t p, int64_t width,
+                     void* stream) {
+  if (p > 65535 || B > 65535) return fail(-1, "nnjt_gather_rows: p and B up to 65535");
+  const unsigned gx = (unsigned)(width >= 256 * 64 ? 64 : (width + 255) / 256);
+  hipLaunchKernelGGL(k_gather_rows, dim3(gx, (unsigned)p, (unsigned)B), dim3(256), 0, static_cast<hipStream_t>(stream), src,
+                     idx, out, n, p, width);
+  CHK_LAUNCH();
+  return 0;
+}
+int nnjt_scatter_rows_add(const float* dout, const int64_t* idx, float* dsrc, int32_t B, int32_t n, int32_t p,
+                          int64_t width, void* stream) {
+  if (p > 65535 || B > 65535) return fail(-1, "nnjt_scatter_rows_add: p and B up to 65535");
+  const unsigned gx = (unsigned)(width >= 256 * 64 ? 64 : (width + 255) / 256);
+  hipLaunchKernelGGL(k_scatter_rows_add, dim3(gx, (unsigned)p, (unsigned)B), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     dout, idx, dsrc, n, p, width);
+  CHK_LAUNCH();
+  return 0;
+}
+int nnjt_permute5(const float* in, float* out, const int64_t* dims, const int64_t* strides, int32_t inverse, void* stream) {
+  Perm5 p;
+  int64_t n = 1;
+  for (int k = 0; k < 5; ++k) { p.d[k] = dims[k]; p.s[k] = strides[k]; n *= dims[k]; }
+  if (n <= 0) return fail(-1, "nnjt_permute5: empty");
+  hipLaunchKernelGGL(k_permute5, dim3(blocks_for(n, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), in, out, p, n,
+                     inverse);
+  CHK_LAUNCH();
+  return 0;
+}
+}

@@ -112,7 +112,20 @@ class PhyloATTN(nn.Module):
             raise ValueError("encode_zxr: input is not made of the six site vectors of the reference's CHARS_DICT")
         return codes.to(torch.uint8)
 
+    # ------------------------------------------------------------------ Finetune mode (gradients)
+    def _wants_grad(self):
+        """The reference fine-tunes by calling these same methods outside torch.no_grad() (finetune_rl_search.py:113,
+        129, 164 with eval=False) and back-propagating through them: with gradients enabled the differentiable
+        operators of train_model.py run (forward and backward kernels of libnnj_train_hip.so); under no_grad the fused
+        inference kernels."""
+        return torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+
     def encode_zxr(self, batch_input, batch_seq_mask=None):
+        if self._wants_grad():
+            from . import train_model
+            if batch_input.dim() != 4 or batch_input.shape[-1] != self.vocab_size:
+                raise ValueError("encode_zxr expects [B, rows, cols, vocab] one-hot input")
+            return train_model.encode(self, batch_input, batch_seq_mask)
         ctx = self._context()
         if batch_input.dim() != 4 or batch_input.shape[-1] != self.vocab_size:
             raise ValueError("encode_zxr expects [B, rows, cols, vocab] one-hot input")
@@ -126,6 +139,14 @@ class PhyloATTN(nn.Module):
         return ctx.encode(codes, batch_seq_mask)
 
     def decode_zxr(self, batch_input, batch_seq_mask=None, indices_to_prev_info=None):
+        if self._wants_grad():
+            from . import train_model
+            self.batch_input = batch_input
+            self.seq_mask = None if batch_seq_mask is None else ~batch_seq_mask[:, None, :: self.patch_size]
+            if not self.patch_num:
+                self.patch_num = math.ceil(batch_input.shape[2] / self.patch_size)
+            scores = train_model.decode(self, batch_input, batch_seq_mask, indices_to_prev_info)
+            return {"logits": scores, "distance": scores}
         ctx = self._context()
         actions_ij_prev, _score_indices_to_prev, logits_prev = indices_to_prev_info
         self.batch_input = batch_input
@@ -143,6 +164,16 @@ class PhyloATTN(nn.Module):
                                       "pair scoring goes through decode_zxr")
         if self.batch_input is None:
             raise RuntimeError("aggregate() needs the state stashed by a preceding decode_zxr()")
+        if self._wants_grad():
+            from . import train_model
+            ii, jj = ij_indices
+            ii = torch.as_tensor(ii).to(self.batch_input.device).to(torch.int64).view(-1, 1)
+            jj = torch.as_tensor(jj).to(self.batch_input.device).to(torch.int64).view(-1, 1)
+            st = self.batch_input.contiguous()
+            from .train_ops import GatherRows
+            xi = GatherRows.apply(st, ii) if x_i is None else x_i
+            xj = GatherRows.apply(st, jj) if x_j is None else x_j
+            return train_model.aggregate(self, st, xi, xj, ii, jj)
         ctx = self._context()
         ii, jj = ij_indices
         ij = torch.stack([torch.as_tensor(ii), torch.as_tensor(jj)], dim=1)

@@ -201,3 +201,46 @@ def main(argv=None):
 
 if __name__ == "__main__":
     main()
+
+
+def reinforce_loss(batch, agent, env, forced_merges, tree_scores, baseline, temperature=1.0, entropy_reg_strength=0.01,
+                   device=None):
+    """One episode of the reference's RL_finetuning with gradients (finetune_rl_search.py:78-189 with eval=False, and
+    the loss of :292-307): the model / environment calls of the reference's loop, differentiable (train_model.py: every
+    operator a HIP forward + backward kernel), then
+        loss = mean_b(-(sum_t log p_t[a_t]) * (score_b - baseline)) + strength * (-sum_t mean_b H(p_t)).
+    `forced_merges` int [B,T-1,2] replaces the reference's Categorical sampling (its RNG stream is the caller's
+    business: sample with Nnj.rollout_sample and pass the merges here); `tree_scores` [B] are the rewards (the
+    reference's raxml-ng log-likelihoods; likelihood.tree_optimize here).  The few table-sized operations of the
+    reference's own driver (log_softmax, gather, the sums of the loss) are torch operations, as they are there.
+    Returns (loss, per-step tables)."""
+    device = device or next(agent.parameters()).device
+    arr = batch["data"].to(device)
+    mask = batch["seq_weights"].to(device) == 0
+    env.init_states(batch["seqs"], batch["seq_keys"], arr)
+    merges = np.asarray(forced_merges)
+    B = merges.shape[0]
+    env.state_tensor = agent.encode_zxr(env.init_state_tensor, mask)
+    ij_prev, logits_prev, selected, log_ps, tables, step = None, None, [], [], [], 0
+    while True:
+        n = env.state_tensor.shape[1]
+        idx = None
+        if ij_prev is not None:
+            idx = torch.from_numpy(np.array(utils.get_score_indices_to_prev(ij_prev, env, n, B))).to(device)
+        logits = agent.decode_zxr(env.state_tensor, mask, (ij_prev, idx, logits_prev))["logits"]
+        tables.append(logits)
+        log_p = torch.log_softmax(logits / temperature, dim=-1)
+        ij = [tuple(int(v) for v in merges[b, step]) for b in range(B)]
+        actions = torch.tensor([env.action_indices_dict[n][p] for p in ij], device=device)
+        ij_prev = torch.tensor(ij, dtype=torch.int32, device=device)
+        if env.step(actions, [(None, None)] * B, branch_optimize=False, agent=agent):
+            break
+        step += 1
+        selected.append(torch.gather(log_p, 1, actions.unsqueeze(1)))
+        log_ps.append(log_p)
+        logits_prev = logits
+    selected = torch.cat(selected, dim=1)
+    scores = torch.as_tensor(tree_scores, dtype=torch.float32, device=device)
+    policy_loss = (-(selected.sum(dim=1)) * (scores - baseline)).mean()
+    entropy_reg = -sum([-torch.sum(torch.exp(lp) * lp, dim=1).mean() for lp in log_ps])
+    return policy_loss + entropy_reg * entropy_reg_strength, tables

@@ -25,6 +25,21 @@ def test_library_builds_and_exports_header(repo_root):
     assert lib.nnj_abi_version() == 1
 
 
+def test_train_library_exports_its_header(repo_root):
+    """libnnj_train_hip.so (the Finetune operators) exports exactly what include/nnj_train.h declares."""
+    from neuralnj_amd import build, train_ops
+    build.build_train()
+    lib = train_ops.load_library()
+    src = open(os.path.join(repo_root, "include", "nnj_train.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    names = sorted(set(re.findall(r"\b(nnjt_[a-z0-9_]+)\s*\(", src)))
+    assert len(names) >= 19
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/nnj_train.h but not exported"
+    assert set(train_ops.exported_symbols()) == set(names)
+    assert lib.nnjt_abi_version() == 1
+
+
 def test_param_count_and_argument_errors():
     from neuralnj_amd import _lib
     lib = _lib.load_library()

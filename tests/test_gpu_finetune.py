@@ -1,0 +1,127 @@
+"""Finetune mode: the differentiable operators of libnnj_train_hip.so -- forward AND backward kernels
+-- against torch's own operators on the same device, and the gradient of the reference's REINFORCE + entropy loss for
+all 172 parameter tensors against golden gradients captured from the reference itself (tests/golden/grad_*.npz,
+gen_golden_grad.py: the reference's model.py / environment.py under torch.autograd on the CPU)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from neuralnj_amd import synth, utils, weights
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _dev():
+    return torch.device("cuda:0")
+
+
+def _check(got, want, tol, what):
+    scale = float(want.abs().max()) + 1e-30
+    err = float((got - want).abs().max())
+    assert err <= tol * scale, f"{what}: {err:.3e} vs scale {scale:.3e}"
+
+
+def _grad_pair(fn_ours, fn_torch, inputs, tol=2e-5):
+    """forward and every input gradient of an operator against torch's"""
+    a = [t.clone().requires_grad_(t.is_floating_point()) for t in inputs]
+    b = [t.clone().requires_grad_(t.is_floating_point()) for t in inputs]
+    ya, yb = fn_ours(*a), fn_torch(*b)
+    _check(ya.detach(), yb.detach(), tol, "forward")
+    w = torch.randn_like(yb)
+    (ya * w).sum().backward()
+    (yb * w).sum().backward()
+    for k, (ta, tb) in enumerate(zip(a, b)):
+        if tb.grad is not None:
+            assert ta.grad is not None, f"no gradient for input {k}"
+            _check(ta.grad, tb.grad, 10 * tol, f"gradient of input {k}")
+
+
+def test_operators_match_torch():
+    from neuralnj_amd import train_ops as T
+    d = _dev()
+    g = torch.Generator(device="cpu").manual_seed(0)
+    R = lambda *s: torch.randn(*s, generator=g).to(d)
+    F = torch.nn.functional
+    _grad_pair(lambda x, w, b: T.Linear.apply(x, w, b), lambda x, w, b: F.linear(x, w, b), [R(3, 70, 64), R(48, 64), R(48)])
+    _grad_pair(lambda x, w, b: T.Linear.apply(x, w, b), lambda x, w, b: F.linear(x, w, b), [R(9000, 4), R(64, 4), R(64)])  # long k in dW
+    _grad_pair(lambda x, w, b: T.LayerNorm.apply(x, w, b), lambda x, w, b: F.layer_norm(x, (64,), w, b, 1e-5), [R(5, 33, 64), R(64), R(64)])
+    _grad_pair(lambda x: T.Gelu.apply(x), lambda x: F.gelu(x), [R(1000) * 3])
+    _grad_pair(lambda h, a, b: T.Gate.apply(h, a, b), lambda h, a, b: torch.sigmoid(h) * a + (1 - torch.sigmoid(h)) * b, [R(7, 64), R(7, 64), R(7, 64)])
+    keep = (torch.rand(6, 5, 50, generator=g) > 0.2).to(torch.uint8).to(d)
+    keep[..., 0] = 1
+    _grad_pair(lambda x: T.Softmax.apply(x, keep), lambda x: torch.softmax(x.masked_fill(keep == 0, float("-inf")), -1), [R(6, 5, 50)])
+    _grad_pair(lambda x: T.Softmax.apply(x, None), lambda x: torch.softmax(x, -1), [R(40, 130)])
+    _grad_pair(lambda x, y: T.Axpby.apply(x, y, 0.5, -2.0), lambda x, y: 0.5 * x - 2.0 * y, [R(100), R(100)])
+    s = R(12).abs()
+    _grad_pair(lambda x: T.RowScale.apply(x, s), lambda x: x * s[:, None], [R(12, 64)])
+    sel = (torch.rand(3, 20, generator=g) > 0.5).to(torch.uint8).to(d)
+    _grad_pair(lambda x: T.FillWhere.apply(x, sel, -10000.0, 4 * 7, 3),
+               lambda x: x.view(3, 4, 7, 20).masked_fill(sel.bool()[:, None, None, :], -10000.0).view(84, 20), [R(84, 20)])
+    idx = torch.randint(0, 9, (2, 13), generator=g).to(d)
+    _grad_pair(lambda x: T.GatherRows.apply(x, idx), lambda x: torch.gather(x, 1, idx[:, :, None, None].expand(-1, -1, 5, 64)), [R(2, 9, 5, 64)])
+    _grad_pair(lambda x: T.Permute.apply(x, (2, 3, 1, 0, 4)), lambda x: x.permute(2, 3, 1, 0, 4).contiguous(), [R(5, 7, 2, 8, 8)])
+    _grad_pair(lambda x: T.Permute.apply(x, (1, 2, 0, 3)), lambda x: x.permute(1, 2, 0, 3).contiguous(), [R(2, 5, 7, 64)])
+    _grad_pair(lambda a, b: T.Bmm.apply(a, b, True, 0.3), lambda a, b: 0.3 * a @ b.transpose(1, 2), [R(6, 70, 40), R(6, 33, 40)])
+    _grad_pair(lambda a, b: T.Bmm.apply(a, b, False, 1.0), lambda a, b: a @ b, [R(6, 70, 33), R(6, 33, 40)])
+    _grad_pair(lambda a, b: T.Bmm.apply(a, b, True, 1.0), lambda a, b: a @ b.transpose(1, 2), [R(2, 9, 20000), R(2, 7, 20000)], tol=5e-5)  # long k
+
+
+@pytest.mark.parametrize("name", ["b2_t6_l48_pad", "b2_t8_l128_s0"])
+def test_finetune_gradients_match_the_reference(name):
+    from neuralnj_amd.environment import PhyInferEnv
+    from neuralnj_amd.model import PhyloATTN
+    from neuralnj_amd.rollout import reinforce_loss
+    z = np.load(os.path.join(GOLD, f"grad_{name}.npz"), allow_pickle=True)
+    cfgs = utils.shipped_config()
+    cfgs.model.num_enc_layers = int(z["layers"])
+    agent = PhyloATTN(cfgs)
+    sd = weights.seeded_state(cfgs, int(z["wseed"]), str(z["style"]))
+    agent.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    agent = agent.to(_dev()).eval()
+    codes, mask = z["codes"], z["mask"]
+    B, T, L = codes.shape
+    batch = {"data": torch.from_numpy(synth.codes_to_onehot(codes)), "seqs": [synth.codes_to_seqs(codes[b]) for b in range(B)],
+             "seq_keys": [[f"taxon{i + 1}" for i in range(T)] for _ in range(B)],
+             "seq_weights": torch.from_numpy((~mask).astype(np.float32))}
+    env = PhyInferEnv(cfgs, _dev())
+    loss, tables = reinforce_loss(batch, agent, env, z["merges"], z["tree_scores"], float(z["baseline"]),
+                                  float(z["temperature"]), float(z["strength"]))
+    got_tables = torch.cat([t.detach().reshape(B, -1) for t in tables], dim=1).cpu().numpy()
+    want = z["tables"]
+    assert np.abs(got_tables - want).max() <= 1e-4 * np.abs(want).max()
+    assert abs(float(loss.detach()) - float(z["loss"])) <= 2e-4 * max(1.0, abs(float(z["loss"])))
+    agent.zero_grad()
+    loss.backward()
+    ref = z["grads"]
+    # Per tensor: max |difference| <= 4e-3 of the tensor's own largest gradient (fp32 on both sides; the gradients
+    # through the near-uniform softmaxes of the "plain" weights are differences of nearly equal terms).  Four kinds of
+    # tensor have a gradient that vanishes ANALYTICALLY -- a bias added to every key of a softmax attention shifts all
+    # logits of a query alike (row / column k_proj.bias, g_attn_k.bias), and s_out.2.bias shifts every score of a
+    # table alike (the policy and entropy gradients of a table sum to zero): there both sides hold rounding noise,
+    # and the check is that ours is noise too (<= 1e-4 of the model's largest gradient).
+    gmax = float(np.abs(ref).max())
+    zero = ("row_self_attention.layer.k_proj.bias", "column_self_attention.layer.k_proj.bias", "g_attn_k.bias", "s_out.2.bias")
+    off, worst, bad = 0, 0.0, []
+    for k, p in agent.state_dict(keep_vars=True).items():
+        n = p.numel()
+        want_g = ref[off:off + n].reshape(tuple(p.shape))
+        off += n
+        assert p.grad is not None, k
+        got_g = p.grad.detach().cpu().numpy()
+        if k.endswith(zero):
+            assert float(np.abs(want_g).max()) <= 1e-4 * gmax, k          # ... and that the reference agrees it vanishes
+            if float(np.abs(got_g).max()) > 1e-4 * gmax:
+                bad.append(f"{k}: should vanish, max {np.abs(got_g).max():.2e}")
+            continue
+        scale = max(float(np.abs(want_g).max()), 1e-7 * gmax)
+        err = float(np.abs(got_g - want_g).max()) / scale
+        worst = max(worst, err)
+        if err > 4e-3:
+            bad.append(f"{k}: {err:.2e} (|g| max {np.abs(want_g).max():.3e})")
+    assert off == ref.size
+    assert not bad, "gradients differ from the reference's: " + "; ".join(bad[:12])
+    print(f"{name}: loss {float(loss.detach()):.6f} (reference {float(z['loss']):.6f}), worst per-tensor gradient error "
+          f"{worst:.2e} of the tensor's own scale (largest gradient of the model {gmax:.3e})")

@@ -439,7 +439,8 @@ def test_model_env_api_follows_reference_call_sequence():
     assert np.array_equal(merges2, z["merges"]) and best2 == best
     # arbitrary (non one-hot) float input goes through the on-device embed MLP, like the reference's .float()
     soft = torch.rand(2, 8, 128, 4)
-    got = agent.encode_zxr(soft, torch.zeros(2, 128, dtype=torch.bool)).cpu().numpy()
+    with torch.no_grad():                   # (with gradients enabled the Finetune operators would run instead)
+        got = agent.encode_zxr(soft, torch.zeros(2, 128, dtype=torch.bool)).cpu().numpy()
     from oracle_lib import Oracle
     ref = Oracle(cfgs, packed).encode(soft.numpy(), np.zeros((2, 128), bool))
     np.testing.assert_allclose(got, ref, atol=RTOL * np.abs(ref).max())
