@@ -175,34 +175,6 @@ def search_inference(cfgs, test_dir, write_dir, stop_step=100, device="cuda", mo
     return out
 
 
-def main(argv=None):
-    import argparse
-    ap = argparse.ArgumentParser(description="NeuralNJ Argmax inference on MI355X (neuralnj_amd)")
-    ap.add_argument("--config_path", type=str, required=True)
-    ap.add_argument("--infer_opt", type=str, default="Argmax")
-    ap.add_argument("--output", type=str, default=None)
-    ap.add_argument("--stop_step", type=int, default=100)
-    args = ap.parse_args(argv)
-    if args.infer_opt not in ("Argmax", "Search"):
-        raise SystemExit("--infer_opt Argmax and Search are implemented (Finetune needs the backward pass: not built)")
-    cfgs = utils.empty_config()
-    cfgs.merge_from_file(args.config_path)
-    base = os.path.dirname(os.path.abspath(args.config_path))
-    test_dir = cfgs.instance_path if os.path.isabs(cfgs.instance_path) else os.path.join(base, "..", cfgs.instance_path)
-    if cfgs.reload_checkpoint_path and not os.path.isabs(cfgs.reload_checkpoint_path):
-        cfgs.reload_checkpoint_path = os.path.join(base, "..", cfgs.reload_checkpoint_path)
-    name = os.path.basename(os.path.normpath(test_dir))
-    write_dir = args.output or f"output/{args.infer_opt}_dim{cfgs.model.embed_dim}_patch{cfgs.model.patch_size}/{name}"
-    if args.infer_opt == "Search":
-        search_inference(cfgs, test_dir, write_dir, stop_step=args.stop_step)
-    else:
-        argmax_inference(cfgs, test_dir, write_dir)
-
-
-if __name__ == "__main__":
-    main()
-
-
 def reinforce_loss(batch, agent, env, forced_merges, tree_scores, baseline, temperature=1.0, entropy_reg_strength=0.01,
                    device=None):
     """One episode of the reference's RL_finetuning with gradients (finetune_rl_search.py:78-189 with eval=False, and
@@ -244,3 +216,115 @@ def reinforce_loss(batch, agent, env, forced_merges, tree_scores, baseline, temp
     policy_loss = (-(selected.sum(dim=1)) * (scores - baseline)).mean()
     entropy_reg = -sum([-torch.sum(torch.exp(lp) * lp, dim=1).mean() for lp in log_ps])
     return policy_loss + entropy_reg * entropy_reg_strength, tables
+
+
+def rl_finetuning(cfgs, batch, agent, optimizer, env, stop_step=20, seed=0, model=None, temperature=1.0, device=None):
+    """Counterpart of the reference's RL_finetuning (finetune_rl_search.py:192-335) for one alignment: per episode one
+    sampled rollout of the current policy (nnj_rollout_sample: the fused inference kernels), its tree scored by
+    log-likelihood on the GPU (likelihood.tree_optimize where the reference calls raxml-ng), the episode replayed with
+    gradients (reinforce_loss), loss.backward(); after `cfgs.num_episodes` episodes the gradients are clipped by value
+    and the optimizer steps.  Baseline as in the reference: the first epoch's is one greedy (Argmax) rollout's score,
+    later ones the running maximum of the epoch means.  The replay buffer of the reference (re-injecting stored
+    trajectories into the sampled batch) is not part of this driver.
+    Returns dict(the_best_tree, the_best_score, step_cur, losses)."""
+    from . import likelihood as lk
+    device = device or next(agent.parameters()).device
+    ctx = agent._context()
+    codes = (batch["codes"] if "codes" in batch else agent.onehot_to_codes(batch["data"].to(device)))[:1].to(device)
+    mask = (batch["seq_weights"].to(device) == 0)[:1]
+    one = {k: (v[:1] if not isinstance(v, list) else v[:1]) for k, v in batch.items()}
+    T = codes.shape[1]
+    rng = np.random.default_rng(seed)
+    agent.eval()
+
+    def score(merges):
+        ll, br = lk.tree_optimize(agent._context(), codes, merges, None, model, mask=mask)
+        return ll.to(torch.float32), br
+
+    with torch.no_grad():
+        greedy = ctx.rollout_argmax(codes, mask)["merges"]
+        baseline_val = float(score(greedy)[0][0])
+    best_tree, best_score, losses, batch_scores, step_cur = None, -np.inf, [], [], 0
+    for epoch in range(1, int(cfgs.num_epoch) + 1):
+        if epoch > 1 and batch_scores:
+            baseline_val = max(baseline_val, sum(batch_scores) / len(batch_scores))
+            batch_scores = []
+        optimizer.zero_grad()
+        for episode in range(int(cfgs.num_episodes)):
+            with torch.no_grad():
+                u = torch.from_numpy(rng.random((1, T - 1)).astype(np.float32))
+                merges = agent._context().rollout_sample(codes, mask, u, temperature=temperature, replicas=1)["merges"]
+                agent._context().check_numeric()
+                sc, br = score(merges)
+            loss, _ = reinforce_loss(one, agent, env, merges.cpu().numpy(), sc, baseline_val, temperature,
+                                     float(cfgs.entropy_reg_strength), device)
+            loss.backward()
+            losses.append(float(loss.detach()))
+            batch_scores.append(float(sc[0]))
+            if float(sc[0]) > best_score:
+                best_score = float(sc[0])
+                env.init_states([batch["seqs"][0]], [batch["seq_keys"][0]], None)
+                env.apply_merges(merges.cpu().numpy(), br.cpu().numpy(), sc.cpu().numpy())
+                best_tree = env.states[0].subtrees[0].utree_op_str
+            step_cur += 1
+            if episode == int(cfgs.num_episodes) - 1:
+                torch.nn.utils.clip_grad_value_(agent.parameters(), clip_value=float(cfgs.clip_value))
+                optimizer.step()
+        if step_cur >= int(stop_step):
+            break
+    return dict(the_best_tree=best_tree, the_best_score=best_score, step_cur=step_cur, losses=losses,
+                baseline=baseline_val)
+
+
+def finetune_inference(cfgs, test_dir, write_dir, stop_step=20, device="cuda", model=None):
+    """Counterpart of the reference's finetune_inference (finetune_rl_search.py:544-577): the checkpoint's policy and
+    one Adam optimizer are fine-tuned on every *.phy file in turn (rl_finetuning; as in the reference the network is
+    NOT reset between files) and the best tree of each file is written as <name>.tre."""
+    from .phydata import load_pi_instance
+    os.makedirs(write_dir, exist_ok=True)
+    agent = PhyloATTN(cfgs).to(device)
+    if cfgs.reload_checkpoint_path:
+        ckpt = torch.load(cfgs.reload_checkpoint_path, map_location="cpu")
+        agent.load_state_dict(ckpt["model_state_dict"])
+    optimizer = torch.optim.Adam(agent.parameters(), lr=float(cfgs.lr))
+    env = PhyInferEnv(cfgs, device)
+    out = {}
+    for fname in sorted(os.listdir(test_dir)):
+        if not fname.endswith(".phy"):
+            continue
+        batch = load_pi_instance(os.path.join(test_dir, fname))
+        res = rl_finetuning(cfgs, batch, agent, optimizer, env, stop_step=stop_step, model=model, device=torch.device(device))
+        with open(os.path.join(write_dir, fname[:-4] + ".tre"), "w") as f:
+            f.write(res["the_best_tree"])
+        out[fname] = res
+    return out
+
+
+def main(argv=None):
+    import argparse
+    ap = argparse.ArgumentParser(description="NeuralNJ Argmax inference on MI355X (neuralnj_amd)")
+    ap.add_argument("--config_path", type=str, required=True)
+    ap.add_argument("--infer_opt", type=str, default="Argmax")
+    ap.add_argument("--output", type=str, default=None)
+    ap.add_argument("--stop_step", type=int, default=100)
+    args = ap.parse_args(argv)
+    if args.infer_opt not in ("Argmax", "Search", "Finetune"):
+        raise SystemExit("--infer_opt is one of Argmax, Search, Finetune")
+    cfgs = utils.empty_config()
+    cfgs.merge_from_file(args.config_path)
+    base = os.path.dirname(os.path.abspath(args.config_path))
+    test_dir = cfgs.instance_path if os.path.isabs(cfgs.instance_path) else os.path.join(base, "..", cfgs.instance_path)
+    if cfgs.reload_checkpoint_path and not os.path.isabs(cfgs.reload_checkpoint_path):
+        cfgs.reload_checkpoint_path = os.path.join(base, "..", cfgs.reload_checkpoint_path)
+    name = os.path.basename(os.path.normpath(test_dir))
+    write_dir = args.output or f"output/{args.infer_opt}_dim{cfgs.model.embed_dim}_patch{cfgs.model.patch_size}/{name}"
+    if args.infer_opt == "Search":
+        search_inference(cfgs, test_dir, write_dir, stop_step=args.stop_step)
+    elif args.infer_opt == "Finetune":
+        finetune_inference(cfgs, test_dir, write_dir, stop_step=args.stop_step)
+    else:
+        argmax_inference(cfgs, test_dir, write_dir)
+
+
+if __name__ == "__main__":
+    main()

@@ -15,6 +15,8 @@ def golden_names(max_taxa=None, min_taxa=None):
     out = []
     for p in sorted(glob.glob(os.path.join(GOLDEN_DIR, "*.npz"))):
         nm = os.path.basename(p)[:-4]
+        if nm.startswith("grad_"):          # golden GRADIENTS of the Finetune loss (tests/test_gpu_finetune.py)
+            continue
         z = np.load(p)
         T = z["codes"].shape[1]
         if max_taxa is not None and T > max_taxa:

