@@ -234,6 +234,44 @@ def compat_path(cfgs, packed, codes, T, L, dev):
                 trees_per_sec=B / dt, ms_per_rollout=1e3 * dt), m
 
 
+def finetune_episode(cfgs, T, L, dev):
+    """Seconds per episode of the Finetune mode at B = 1 on the bench shape: one sampled rollout on the
+    fused kernels, the episode replayed with gradients (neuralnj_amd.rollout.reinforce_loss: forward and backward
+    kernels of libnnj_train_hip.so), backward, clipped Adam step.  A side figure; never fails the bench."""
+    try:
+        from neuralnj_amd.environment import PhyInferEnv
+        from neuralnj_amd.model import PhyloATTN
+        from neuralnj_amd.rollout import reinforce_loss
+        agent = PhyloATTN(cfgs)
+        sd = weights.seeded_state(cfgs, 0, "plain")
+        agent.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+        agent = agent.to(dev).eval()
+        opt = torch.optim.Adam(agent.parameters(), lr=1e-5)
+        c = synth.synth_codes_tree(1, T, L, seed=3)
+        batch = {"data": torch.from_numpy(synth.codes_to_onehot(c)), "seqs": [synth.codes_to_seqs(c[0])],
+                 "seq_keys": [[f"taxon{i + 1}" for i in range(T)]], "seq_weights": torch.ones((1, L), dtype=torch.float32)}
+        times = []
+        for ep in range(3):
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            with torch.no_grad():
+                u = torch.from_numpy(np.random.default_rng(ep).random((1, T - 1)).astype(np.float32))
+                m = agent._context().rollout_sample(torch.from_numpy(c), None, u, temperature=1.0, replicas=1)["merges"]
+            opt.zero_grad()
+            loss, _ = reinforce_loss(batch, agent, PhyInferEnv(cfgs, dev), m.cpu().numpy(), np.array([1.0], np.float32), 0.5)
+            loss.backward()
+            torch.nn.utils.clip_grad_value_(agent.parameters(), clip_value=1.0)
+            opt.step()
+            torch.cuda.synchronize(dev)
+            if ep:
+                times.append(time.perf_counter() - t0)
+        return {"workload": f"Finetune episode, B=1, {T}x{L}: sampled rollout + differentiable replay + backward + Adam",
+                "s_per_episode": float(np.median(times)), "peak_mem_gb": torch.cuda.max_memory_allocated(dev) / 2 ** 30,
+                "note": "first, unfused fp32 path (DESIGN.md 14); gradients pinned to the reference's (tests/test_gpu_finetune.py)"}
+    except Exception as e:                                    # pragma: no cover
+        return {"error": f"{type(e).__name__}: {e}"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -473,6 +511,8 @@ def main():
             whole = g.rollout_argmax(codes, mask)["merges"].cpu()
             out["step_api_path"] = step_api_path(g, codes, mask, T, whole)
             g.set_concurrency(args.streams)
+        if world == 1 and not args.no_compat:
+            out["finetune_episode"] = finetune_episode(cfgs, T, L, dev)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfgs, packed, T, L)
         if verified is not None:
