@@ -26,57 +26,64 @@ int fail(int code, const char* fmt, ...) {
 inline unsigned blocks_for(int64_t n, int per) { return (unsigned)((n + per - 1) / per); }
 
 // ------------------------------------------------------------------ strided batched GEMM
-// 64 x 64 output tile per workgroup of 256 threads (4 x 4 outputs per thread), k in steps of 16 through LDS.
-// Loads walk whichever of (m, k) / (k, n) has unit stride fastest, so nn.Linear operands, their transposes and the
-// head-strided attention operands are all read in contiguous pieces.
-constexpr int TM = 64, TN = 64, TK = 16;
+// 128 x 64 output tile per workgroup of four waves, each wave 32 rows x 64 columns in two 32x32 accumulators of
+// v_mfma_f32_32x32x2_f32 (exact fp32 products and sums, like the fmaf chain torch's fp32 GEMM is compared with); k in
+// steps of 16 through LDS.  Loads walk whichever of (m, k) / (k, n) has unit stride fastest, so nn.Linear operands,
+// their transposes and the head-strided attention operands are all read in contiguous pieces.  A first version of
+// this kernel did the products on the vector pipe (4 x 4 outputs per thread): 85 % of a Finetune episode's GPU time.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int TM = 128, TN = 64, TK = 16;
 __global__ __launch_bounds__(256) void k_gemm(nnjt_gemm g) {
   __shared__ float As[TK][TM + 4];
   __shared__ float Bs[TK][TN + 4];
-  const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, kh = lane >> 5;
   const int m0 = blockIdx.y * TM, n0 = blockIdx.x * TN;
   const int b1 = blockIdx.z / g.nb2, b2 = blockIdx.z % g.nb2;
   const float* A = g.A + b1 * g.sAb1 + b2 * g.sAb2;
   const float* B = g.B + b1 * g.sBb1 + b2 * g.sBb2;
   float* C = g.C + b1 * g.sCb1 + b2 * g.sCb2;
-  float acc[4][4] = {};
+  f32x16 acc[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
   const bool a_kfast = g.sAk == 1, b_kfast = g.sBk == 1;
   for (int k0 = 0; k0 < g.K; k0 += TK) {
 #pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int e = tid + 256 * i;
+      const int m = a_kfast ? e / TK : e % TM, k = a_kfast ? e % TK : e / TM;
+      const bool ok = m0 + m < g.M && k0 + k < g.K;
+      As[k][m] = ok ? A[(int64_t)(m0 + m) * g.sAm + (int64_t)(k0 + k) * g.sAk] : 0.f;
+    }
+#pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int e = tid + 256 * i;
-      {
-        const int m = a_kfast ? e / TK : e % TM, k = a_kfast ? e % TK : e / TM;
-        const bool ok = m0 + m < g.M && k0 + k < g.K;
-        As[k][m] = ok ? A[(int64_t)(m0 + m) * g.sAm + (int64_t)(k0 + k) * g.sAk] : 0.f;
-      }
-      {
-        const int n = b_kfast ? e / TK : e % TN, k = b_kfast ? e % TK : e / TN;
-        const bool ok = n0 + n < g.N && k0 + k < g.K;
-        Bs[k][n] = ok ? B[(int64_t)(k0 + k) * g.sBk + (int64_t)(n0 + n) * g.sBn] : 0.f;
-      }
+      const int n = b_kfast ? e / TK : e % TN, k = b_kfast ? e % TK : e / TN;
+      const bool ok = n0 + n < g.N && k0 + k < g.K;
+      Bs[k][n] = ok ? B[(int64_t)(k0 + k) * g.sBk + (int64_t)(n0 + n) * g.sBn] : 0.f;
     }
     __syncthreads();
+#if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
-    for (int k = 0; k < TK; ++k) {
-      float a[4], b[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) { a[i] = As[k][ty * 4 + i]; b[i] = Bs[k][tx * 4 + i]; }
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(a[i], b[j], acc[i][j]);
+    for (int kk = 0; kk < TK; kk += 2) {
+      const float a = As[kk + kh][32 * wave + l31];          // A[m = lane & 31][k = lane >> 5]
+      const float bl = Bs[kk + kh][l31], bh = Bs[kk + kh][32 + l31];
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bl, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bh, acc[1], 0, 0, 0);
     }
+#endif
     __syncthreads();
   }
+  // C/D layout: register r of a lane = row (r & 3) + 8 (r >> 2) + 4 (lane >> 5), column lane & 31
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int t = 0; t < 2; ++t)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int m = m0 + ty * 4 + i, n = n0 + tx * 4 + j;
+    for (int r = 0; r < 16; ++r) {
+      const int m = m0 + 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * kh, n = n0 + 32 * t + l31;
       if (m < g.M && n < g.N) {
         float* c = C + (int64_t)m * g.sCm + (int64_t)n * g.sCn;
-        *c = g.beta == 0.f ? g.alpha * acc[i][j] : g.alpha * acc[i][j] + g.beta * *c;
+        *c = g.beta == 0.f ? g.alpha * acc[t][r] : g.alpha * acc[t][r] + g.beta * *c;
       }
     }
 }
@@ -86,11 +93,11 @@ __global__ void k_add_bias(float* y, const float* __restrict__ bias, int64_t n, 
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) y[i] += bias[i % cols];
 }
-// out[c] += sum_r x[r, c]: a workgroup owns 256 rows, thread = column (cols <= 256), one atomic per column and block
+// out[c] += sum_r x[r, c]: a workgroup owns 64 rows, thread = column (cols <= 256), one atomic per column and block
 __global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ x, float* out, int64_t rows, int cols) {
   const int c = threadIdx.x;
   if (c >= cols) return;
-  const int64_t r0 = (int64_t)blockIdx.x * 256, r1 = r0 + 256 < rows ? r0 + 256 : rows;
+  const int64_t r0 = (int64_t)blockIdx.x * 64, r1 = r0 + 64 < rows ? r0 + 64 : rows;
   float s = 0.f;
   for (int64_t r = r0; r < r1; ++r) s += x[r * cols + c];
   atomicAdd(out + c, s);
@@ -278,7 +285,7 @@ int nnjt_add_bias(float* y, const float* bias, int64_t rows, int32_t cols, void*
 }
 int nnjt_colsum(const float* x, float* out, int64_t rows, int32_t cols, void* stream) {
   if (!x || !out || cols > 256) return fail(-1, "nnjt_colsum: null or more than 256 columns");
-  hipLaunchKernelGGL(k_colsum, dim3(blocks_for(rows, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), x, out, rows, cols);
+  hipLaunchKernelGGL(k_colsum, dim3(blocks_for(rows, 64)), dim3(256), 0, static_cast<hipStream_t>(stream), x, out, rows, cols);
   CHK_LAUNCH();
   return 0;
 }

@@ -100,7 +100,7 @@ def gemm(A, B, Cout, M, N, K, sA, sB, sC, nb=(1, 1), bA=(0, 0), bB=(0, 0), bC=(0
     _chk(load_library().nnjt_gemm_run(C.byref(g), _st(Cout)))
 
 
-_SPLIT = 4096      # contraction lengths above this are cut into pieces summed by a second product
+_SPLIT = 512       # contractions longer than twice this are cut into pieces (one workgroup each) summed by a second product
 
 
 def gemm_longk(A, B, Cout, M, N, K, sA, sB, sC, alpha=1.0):

@@ -101,7 +101,8 @@ def test_finetune_gradients_match_the_reference(name):
     # tensor have a gradient that vanishes ANALYTICALLY -- a bias added to every key of a softmax attention shifts all
     # logits of a query alike (row / column k_proj.bias, g_attn_k.bias), and s_out.2.bias shifts every score of a
     # table alike (the policy and entropy gradients of a table sum to zero): there both sides hold rounding noise,
-    # and the check is that ours is noise too (<= 1e-4 of the model's largest gradient).
+    # and the check is that ours is noise too (<= 1e-3 of the model's largest gradient: the noise is fp32 rounding of
+    # sums of ~1e2..1e4 cancelling terms and moves with the order of summation).
     gmax = float(np.abs(ref).max())
     zero = ("row_self_attention.layer.k_proj.bias", "column_self_attention.layer.k_proj.bias", "g_attn_k.bias", "s_out.2.bias")
     off, worst, bad = 0, 0.0, []
@@ -112,8 +113,8 @@ def test_finetune_gradients_match_the_reference(name):
         assert p.grad is not None, k
         got_g = p.grad.detach().cpu().numpy()
         if k.endswith(zero):
-            assert float(np.abs(want_g).max()) <= 1e-4 * gmax, k          # ... and that the reference agrees it vanishes
-            if float(np.abs(got_g).max()) > 1e-4 * gmax:
+            assert float(np.abs(want_g).max()) <= 1e-3 * gmax, k          # ... and that the reference agrees it vanishes
+            if float(np.abs(got_g).max()) > 1e-3 * gmax:
                 bad.append(f"{k}: should vanish, max {np.abs(got_g).max():.2e}")
             continue
         scale = max(float(np.abs(want_g).max()), 1e-7 * gmax)
