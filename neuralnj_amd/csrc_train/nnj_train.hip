@@ -34,8 +34,8 @@ inline unsigned blocks_for(int64_t n, int per) { return (unsigned)((n + per - 1)
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int TM = 128, TN = 64, TK = 16;
 __global__ __launch_bounds__(256) void k_gemm(nnjt_gemm g) {
-  __shared__ float As[TK][TM + 4];
-  __shared__ float Bs[TK][TN + 4];
+  __shared__ __attribute__((aligned(16))) float As[TK][TM + 4];
+  __shared__ __attribute__((aligned(16))) float Bs[TK][TN + 4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, kh = lane >> 5;
   const int m0 = blockIdx.y * TM, n0 = blockIdx.x * TN;
   const int b1 = blockIdx.z / g.nb2, b2 = blockIdx.z % g.nb2;
@@ -48,20 +48,67 @@ __global__ __launch_bounds__(256) void k_gemm(nnjt_gemm g) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
   const bool a_kfast = g.sAk == 1, b_kfast = g.sBk == 1;
+  // 16-byte loads along the unit-stride direction where the operand allows it (aligned base, other stride a multiple
+  // of four floats): the products of the model are short (k = 64 for every nn.Linear), so the operand loads, not the
+  // MFMAs, are most of this kernel; scalar loads otherwise
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  const bool a_vec = ((a_kfast && g.sAm % 4 == 0) || (g.sAm == 1 && g.sAk % 4 == 0)) && ((uintptr_t)A % 16 == 0);
+  const bool b_vec = ((b_kfast && g.sBn % 4 == 0) || (g.sBn == 1 && g.sBk % 4 == 0)) && ((uintptr_t)B % 16 == 0);
   for (int k0 = 0; k0 < g.K; k0 += TK) {
+    if (a_vec) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int e = tid + 256 * i;
-      const int m = a_kfast ? e / TK : e % TM, k = a_kfast ? e % TK : e / TM;
-      const bool ok = m0 + m < g.M && k0 + k < g.K;
-      As[k][m] = ok ? A[(int64_t)(m0 + m) * g.sAm + (int64_t)(k0 + k) * g.sAk] : 0.f;
+      for (int i = 0; i < 2; ++i) {
+        const int e = tid + 256 * i;                         // 512 groups of four
+        if (a_kfast) {                                       // four consecutive k of one row
+          const int m = e / (TK / 4), k = 4 * (e % (TK / 4));
+          f4 v = {0.f, 0.f, 0.f, 0.f};
+          if (m0 + m < g.M && k0 + k + 3 < g.K) v = *reinterpret_cast<const f4*>(A + (int64_t)(m0 + m) * g.sAm + (k0 + k));
+          else if (m0 + m < g.M)
+            for (int t = 0; t < 4; ++t) if (k0 + k + t < g.K) v[t] = A[(int64_t)(m0 + m) * g.sAm + (k0 + k + t)];
+          As[k][m] = v[0]; As[k + 1][m] = v[1]; As[k + 2][m] = v[2]; As[k + 3][m] = v[3];
+        } else {                                             // four consecutive rows of one k
+          const int m = 4 * (e % (TM / 4)), k = e / (TM / 4);
+          f4 v = {0.f, 0.f, 0.f, 0.f};
+          if (k0 + k < g.K && m0 + m + 3 < g.M) v = *reinterpret_cast<const f4*>(A + (int64_t)(k0 + k) * g.sAk + (m0 + m));
+          else if (k0 + k < g.K)
+            for (int t = 0; t < 4; ++t) if (m0 + m + t < g.M) v[t] = A[(int64_t)(k0 + k) * g.sAk + (m0 + m + t)];
+          *reinterpret_cast<f4*>(&As[k][m]) = v;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int e = tid + 256 * i;
+        const int m = a_kfast ? e / TK : e % TM, k = a_kfast ? e % TK : e / TM;
+        const bool ok = m0 + m < g.M && k0 + k < g.K;
+        As[k][m] = ok ? A[(int64_t)(m0 + m) * g.sAm + (int64_t)(k0 + k) * g.sAk] : 0.f;
+      }
     }
+    if (b_vec) {
+      const int e = tid;                                     // 256 groups of four
+      if (b_kfast) {
+        const int n = e / (TK / 4), k = 4 * (e % (TK / 4));
+        f4 v = {0.f, 0.f, 0.f, 0.f};
+        if (n0 + n < g.N && k0 + k + 3 < g.K) v = *reinterpret_cast<const f4*>(B + (int64_t)(n0 + n) * g.sBn + (k0 + k));
+        else if (n0 + n < g.N)
+          for (int t = 0; t < 4; ++t) if (k0 + k + t < g.K) v[t] = B[(int64_t)(n0 + n) * g.sBn + (k0 + k + t)];
+        Bs[k][n] = v[0]; Bs[k + 1][n] = v[1]; Bs[k + 2][n] = v[2]; Bs[k + 3][n] = v[3];
+      } else {
+        const int n = 4 * (e % (TN / 4)), k = e / (TN / 4);
+        f4 v = {0.f, 0.f, 0.f, 0.f};
+        if (k0 + k < g.K && n0 + n + 3 < g.N) v = *reinterpret_cast<const f4*>(B + (int64_t)(k0 + k) * g.sBk + (n0 + n));
+        else if (k0 + k < g.K)
+          for (int t = 0; t < 4; ++t) if (n0 + n + t < g.N) v[t] = B[(int64_t)(k0 + k) * g.sBk + (n0 + n + t)];
+        *reinterpret_cast<f4*>(&Bs[k][n]) = v;
+      }
+    } else {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int e = tid + 256 * i;
-      const int n = b_kfast ? e / TK : e % TN, k = b_kfast ? e % TK : e / TN;
-      const bool ok = n0 + n < g.N && k0 + k < g.K;
-      Bs[k][n] = ok ? B[(int64_t)(k0 + k) * g.sBk + (int64_t)(n0 + n) * g.sBn] : 0.f;
+      for (int i = 0; i < 4; ++i) {
+        const int e = tid + 256 * i;
+        const int n = b_kfast ? e / TK : e % TN, k = b_kfast ? e % TK : e / TN;
+        const bool ok = n0 + n < g.N && k0 + k < g.K;
+        Bs[k][n] = ok ? B[(int64_t)(k0 + k) * g.sBk + (int64_t)(n0 + n) * g.sBn] : 0.f;
+      }
     }
     __syncthreads();
 #if defined(__HIP_DEVICE_COMPILE__)

@@ -96,7 +96,11 @@ def main():
     import utils as ref_utils          # noqa: E402
     ref = (None, ref_utils, ref_model.PhyloATTN, ref_env.PhyInferEnv)
     # merges: the reference's own Argmax trees of the matching forward fixtures (any valid merge list would do)
-    for name, src, layers, pad in (("b2_t8_l128_s0", "synth_b2_t8_l128_s0", 6, 0), ("b2_t6_l48_pad", None, 2, 5)):
+    only = sys.argv[1] if len(sys.argv) > 1 else None
+    for name, src, layers, pad in (("b2_t8_l128_s0", "synth_b2_t8_l128_s0", 6, 0), ("b2_t6_l48_pad", None, 2, 5),
+                                   ("b1_t20_l256_s1", "synth_b1_t20_l256_s1", 6, 0)):
+        if only and name != only:
+            continue
         if src is not None:
             z = np.load(os.path.join(HERE, src + ".npz"), allow_pickle=True)
             codes, mask, merges, wseed, style = z["codes"], z["mask"], z["merges"], int(z["wseed"]), str(z["style"])
@@ -112,7 +116,7 @@ def main():
                     i, j = sorted(rng.choice(n, size=2, replace=False))
                     merges[b, s] = (i, j)
             wseed, style = 17, "plain"
-        scores = np.array([0.8, -0.4], dtype=np.float32)
+        scores = np.array([0.8, -0.4], dtype=np.float32)[:codes.shape[0]]
         run_case(name, codes, mask, merges, wseed, style, layers, ref, scores)
 
 

@@ -69,7 +69,7 @@ def test_operators_match_torch():
     _grad_pair(lambda a, b: T.Bmm.apply(a, b, True, 1.0), lambda a, b: a @ b.transpose(1, 2), [R(2, 9, 20000), R(2, 7, 20000)], tol=5e-5)  # long k
 
 
-@pytest.mark.parametrize("name", ["b2_t6_l48_pad", "b2_t8_l128_s0"])
+@pytest.mark.parametrize("name", ["b2_t6_l48_pad", "b2_t8_l128_s0", "b1_t20_l256_s1"])
 def test_finetune_gradients_match_the_reference(name):
     from neuralnj_amd.environment import PhyInferEnv
     from neuralnj_amd.model import PhyloATTN
