@@ -8,8 +8,9 @@
  * contiguous fp32 on the device unless a stride is spelled out; `stream` is a hipStream_t.  Every function returns 0 or
  * a negative error code (nnjt_last_error() says why); nothing synchronises the stream.
  *
- * This is a first, UNFUSED path: plain fp32 FMA arithmetic, one kernel per operator, activations kept by the caller
- * (DESIGN.md 14).  It is separate from libnnj_hip.so (inference), which it neither links nor changes.
+ * This is a first, UNFUSED path: fp32 arithmetic (the contractions on v_mfma_f32_32x32x2_f32), one kernel per operator,
+ * activations kept by the caller.  It is separate from libnnj_hip.so (inference), which it neither links
+ * nor changes.
  */
 #ifndef NNJ_TRAIN_H
 #define NNJ_TRAIN_H

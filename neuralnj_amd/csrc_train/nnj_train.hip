@@ -1,6 +1,7 @@
 // nnj_train.hip -- libnnj_train_hip.so (include/nnj_train.h): forward and backward kernels of the operators of the
-// reference's Finetune mode, gfx950.  A first, unfused path: fp32 FMA arithmetic, one kernel per operator; the graph
-// is kept by torch.autograd.Function objects on the host (neuralnj_amd/train_ops.py).  No CPU fallback.
+// reference's Finetune mode, gfx950.  A first, unfused path: fp32 arithmetic (contractions on the fp32 matrix pipe), one
+// kernel per operator; the graph is kept by torch.autograd.Function objects on the host (neuralnj_amd/train_ops.py).
+// No CPU fallback.
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdarg.h>

@@ -151,3 +151,56 @@ def test_finetune_inference_file_to_tree(tmp_path):
     assert all(k + ":" in tree for k in keys) and tree.endswith(";")
     assert res["step_cur"] == 6 and len(res["losses"]) == 6 and all(np.isfinite(res["losses"]))
     assert np.isfinite(res["the_best_score"]) and res["the_best_score"] < 0
+
+
+def test_finetune_gradients_match_the_fp64_oracle_on_a_seeded_case():
+    """A case that is in no fixture (3 alignments of 12 taxa x 96 sites, padded sites, 3 layers, random merge lists):
+    the HIP gradients against the float64 gradient oracle (oracle/grad_oracle.py, itself pinned to the reference's
+    gradients in tests/test_grad_oracle.py: its float32 build reproduces them exactly, its float64 build differs from
+    them by up to 7e-4 of a tensor's scale -- the fp32 rounding of the reference itself)."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(GOLD), "..", "oracle"))
+    import grad_oracle
+    from neuralnj_amd.environment import PhyInferEnv
+    from neuralnj_amd.model import PhyloATTN
+    from neuralnj_amd.rollout import reinforce_loss
+    B, T, L, layers = 3, 12, 96, 3
+    cfgs = utils.shipped_config()
+    cfgs.model.num_enc_layers = layers
+    st = weights.seeded_state(cfgs, 41, "sharp")
+    codes = synth.synth_codes_tree(B, T, L, seed=8)
+    mask = np.zeros((B, L), dtype=bool)
+    mask[1, -7:] = True
+    codes[1, :, -7:] = 5
+    rng = np.random.default_rng(5)
+    merges = np.zeros((B, T - 1, 2), dtype=np.int32)
+    for b in range(B):
+        for s, n in enumerate(range(T, 1, -1)):
+            merges[b, s] = sorted(rng.choice(n, size=2, replace=False))
+    scores = np.array([0.3, -1.2, 0.9], dtype=np.float32)
+    sd64 = {k: torch.from_numpy(v).double().requires_grad_(True) for k, v in st.items()}
+    l64, _ = grad_oracle.reinforce_loss(sd64, synth.codes_to_onehot(codes), mask, merges, scores, 0.1, 1.0, 0.02, layers)
+    l64.backward()
+    agent = PhyloATTN(cfgs)
+    agent.load_state_dict({k: torch.from_numpy(v) for k, v in st.items()}, strict=True)
+    agent = agent.to(_dev()).eval()
+    batch = {"data": torch.from_numpy(synth.codes_to_onehot(codes)), "seqs": [synth.codes_to_seqs(codes[b]) for b in range(B)],
+             "seq_keys": [[f"taxon{i + 1}" for i in range(T)] for _ in range(B)],
+             "seq_weights": torch.from_numpy((~mask).astype(np.float32))}
+    loss, _ = reinforce_loss(batch, agent, PhyInferEnv(cfgs, _dev()), merges, scores, 0.1, 1.0, 0.02)
+    assert abs(float(loss.detach()) - float(l64.detach())) <= 2e-4 * max(1.0, abs(float(l64.detach())))
+    agent.zero_grad()
+    loss.backward()
+    gmax = max(float(p.grad.abs().max()) for p in sd64.values())
+    zero = ("row_self_attention.layer.k_proj.bias", "column_self_attention.layer.k_proj.bias", "g_attn_k.bias", "s_out.2.bias")
+    worst = 0.0
+    for k, p in agent.state_dict(keep_vars=True).items():
+        want = sd64[k].grad.numpy()
+        got = p.grad.detach().cpu().numpy().astype(np.float64)
+        if k.endswith(zero):
+            assert np.abs(got).max() <= 1e-3 * gmax, k
+            continue
+        err = float(np.abs(got - want).max()) / max(float(np.abs(want).max()), 1e-7 * gmax)
+        worst = max(worst, err)
+        assert err <= 4e-3, f"{k}: {err:.2e}"
+    print(f"seeded case: worst per-tensor difference from the fp64 gradient {worst:.2e}")
