@@ -224,8 +224,8 @@ def rl_finetuning(cfgs, batch, agent, optimizer, env, stop_step=20, seed=0, mode
     log-likelihood on the GPU (likelihood.tree_optimize where the reference calls raxml-ng), the episode replayed with
     gradients (reinforce_loss), loss.backward(); after `cfgs.num_episodes` episodes the gradients are clipped by value
     and the optimizer steps.  Baseline as in the reference: the first epoch's is one greedy (Argmax) rollout's score,
-    later ones the running maximum of the epoch means.  The replay buffer of the reference (re-injecting stored
-    trajectories into the sampled batch) is not part of this driver.
+    later ones the running maximum of the epoch means.  The reference's replay buffer re-injects nothing (its `sample`
+    returns None, utils.py:99), so every action here is sampled too; utils.ReplayBuffer keeps the same surface.
     Returns dict(the_best_tree, the_best_score, step_cur, losses)."""
     from . import likelihood as lk
     device = device or next(agent.parameters()).device

@@ -162,6 +162,35 @@ def get_score_indices_to_prev(actions_ij_prev, env, nb_seq, batch_size):
     return index_map_batch(int(nb_seq), a)
 
 
+class ReplayBuffer:
+    """Same surface as the reference's utils.ReplayBuffer (utils.py:67-100): the best `replay_buffer_size` distinct
+    trees seen so far, distinct by `topo_repr` (the comparison nnj_topology_hash does on the device for whole batches).
+    `sample` returns None exactly like the reference's, whose trajectory re-injection is switched off (utils.py:99:
+    `return None`), so a rollout that consults the buffer samples every action itself."""
+
+    def __init__(self, replay_buffer_size):
+        self.replay_buffer_size = replay_buffer_size
+        self.trees, self.scores = [], []
+
+    def get_size(self):
+        return len(self.trees)
+
+    def add(self, trees, scores):
+        for tree, score in zip(trees, scores):
+            if any(t.topo_repr == tree.topo_repr for t in self.trees):
+                continue
+            if len(self.trees) < self.replay_buffer_size:
+                self.trees.append(tree)
+                self.scores.append(score)
+            else:
+                k = self.scores.index(min(self.scores))
+                if score > self.scores[k]:
+                    self.trees[k], self.scores[k] = tree, score
+
+    def sample(self, sample_num):
+        return None
+
+
 # ---------------------------------------------------------------- RF distance
 def _newick_splits(newick: str):
     """Bipartitions (as frozensets of leaf names, normalised against the full leaf
