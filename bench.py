@@ -251,6 +251,7 @@ def finetune_episode(cfgs, T, L, dev):
         batch = {"data": torch.from_numpy(synth.codes_to_onehot(c)), "seqs": [synth.codes_to_seqs(c[0])],
                  "seq_keys": [[f"taxon{i + 1}" for i in range(T)]], "seq_weights": torch.ones((1, L), dtype=torch.float32)}
         times = []
+        torch.cuda.reset_peak_memory_stats(dev)
         for ep in range(3):
             torch.cuda.synchronize(dev)
             t0 = time.perf_counter()

@@ -137,6 +137,7 @@ class PhyInferEnv:
             for b in range(self.batch_size)]
         self.init_state_tensor = seq_arrays
         self.state_tensor = None
+        self._merge_log = []                     # (i, j) of every step: the merge lists branch_optimize=True scores
 
     def _merge_host(self, b, i, j, lengths=None, log_score=None):
         """Tree half of one merge for batch element b; returns True when the tree is complete.
@@ -164,15 +165,20 @@ class PhyInferEnv:
 
     def step(self, actions, edge_actions=None, parallel=True, branch_optimize=False, agent=None,
              step_action=False):
-        if branch_optimize:
-            raise NotImplementedError("RAxML branch-length optimisation is outside the Argmax hot path")
         n = self.states[0].num_trees
         pairs = self.tree_pairs_dict[n]
         acts = actions.tolist() if hasattr(actions, "tolist") else list(actions)
         ij = [pairs[int(a)] for a in acts]
+        self._merge_log.append(ij)
         done = False
         for b, (i, j) in enumerate(ij):
             done = self._merge_host(b, i, j)
+        if done and branch_optimize:
+            # The reference scores the finished trees here with raxml-ng (optimize_branch_length_*, environment.py:
+            # 625-672: branch lengths optimised, log-likelihood under GTR+I+G).  Same place, on the GPU: the merge lists
+            # of the batch go through nnj_tree_optimize (likelihood.py; default model parameters, not optimised) and
+            # the trees are rebuilt with their branch lengths and scores.
+            self._score_finished_trees(agent)
         if not done:
             # tensor half (reference environment.py:760-835) on the device
             if agent is None:
@@ -203,6 +209,30 @@ class PhyInferEnv:
             cat = torch.cat((self.state_tensor, new), dim=1)
             self.state_tensor = torch.gather(cat, 1, base[:, :, None, None].expand(-1, -1, cat.size(2), cat.size(3)))
         return done
+
+    def _score_finished_trees(self, agent):
+        if agent is None or not hasattr(agent, "_context"):
+            raise NotImplementedError("branch_optimize=True scores the trees on the GPU and needs this package's agent")
+        from . import likelihood as lk
+        ctx = agent._context()
+        arr = self.init_state_tensor
+        if arr is None:
+            raise RuntimeError("branch_optimize=True needs the alignment passed to init_states")
+        codes = arr if arr.dim() == 3 else agent.onehot_to_codes(arr.to(ctx.device))
+        merges = torch.tensor(self._merge_log, dtype=torch.int32).permute(1, 0, 2).contiguous()      # [B, T-1, 2]
+        ll = torch.empty(merges.shape[0], dtype=torch.float64)
+        br = torch.empty(tuple(merges.shape[:2]) + (2,), dtype=torch.float32)
+        if all(torch.equal(codes[0], codes[b]) for b in range(1, codes.shape[0])):
+            l, r = lk.tree_optimize(ctx, codes[:1], merges)          # replicas of one alignment (Search / Finetune)
+            ll, br = l.cpu(), r.cpu()
+        else:
+            for b in range(merges.shape[0]):
+                l, r = lk.tree_optimize(ctx, codes[b:b + 1], merges[b:b + 1])
+                ll[b], br[b] = l[0].cpu(), r[0].cpu()
+        seqs, keys, log = self.batch_seqs, self.seq_keys, self._merge_log
+        self.init_states(seqs, keys, arr)
+        self._merge_log = log
+        self.apply_merges(merges.numpy(), br.numpy(), ll.numpy())
 
     def apply_merges(self, merges, brlen=None, log_scores=None):
         """Fast path: replay a device-produced merge list [B,T-1,2] on the host trees; brlen [B,T-1,2] and

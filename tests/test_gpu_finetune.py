@@ -204,3 +204,48 @@ def test_finetune_gradients_match_the_fp64_oracle_on_a_seeded_case():
         worst = max(worst, err)
         assert err <= 4e-3, f"{k}: {err:.2e}"
     print(f"seeded case: worst per-tensor difference from the fp64 gradient {worst:.2e}")
+
+
+def test_env_step_branch_optimize_scores_trees_on_the_gpu():
+    """The reference's loop with branch_optimize=True (what RL_Search / RL_finetuning pass to env.step,
+    finetune_rl_search.py:164 via :367, :286): the finished trees are scored where the reference calls raxml-ng, by the
+    GPU likelihood -- same values as likelihood.tree_optimize on the same merge lists, real branch lengths in the
+    Newick strings."""
+    from neuralnj_amd import likelihood as lk
+    from neuralnj_amd.environment import PhyInferEnv
+    from neuralnj_amd.model import PhyloATTN
+    cfgs = utils.shipped_config()
+    cfgs.model.num_enc_layers = 2
+    st = weights.seeded_state(cfgs, 2, "sharp")
+    agent = PhyloATTN(cfgs)
+    agent.load_state_dict({k: torch.from_numpy(v) for k, v in st.items()}, strict=True)
+    agent = agent.to(_dev()).eval()
+    B, T, L = 2, 7, 96
+    codes = synth.synth_codes_tree(B, T, L, seed=12)
+    onehot = torch.from_numpy(synth.codes_to_onehot(codes))
+    mask = torch.zeros(B, L, dtype=torch.bool)
+    env = PhyInferEnv(cfgs, _dev())
+    env.init_states([synth.codes_to_seqs(codes[b]) for b in range(B)], [[f"taxon{i + 1}" for i in range(T)]] * B, onehot)
+    merges, ij_prev, logits_prev = [], None, None
+    with torch.no_grad():
+        env.state_tensor = agent.encode_zxr(env.init_state_tensor, mask)
+        while True:
+            n = env.state_tensor.shape[1]
+            idx = None if ij_prev is None else torch.from_numpy(np.array(utils.get_score_indices_to_prev(ij_prev, env, n, B))).to(_dev())
+            logits = agent.decode_zxr(env.state_tensor, mask, (ij_prev, idx, logits_prev))["logits"]
+            actions = torch.argmax(logits, dim=-1)
+            ij = [env.tree_pairs_dict[n][int(a)] for a in actions]
+            merges.append(ij)
+            ij_prev = torch.tensor(ij, dtype=torch.int32, device=_dev())
+            if env.step(actions, [(None, None)] * B, branch_optimize=True, agent=agent):
+                break
+            logits_prev = logits
+    scores, _, _, best = env.evaluate_loglikelihood()
+    m = torch.tensor(merges, dtype=torch.int32).permute(1, 0, 2).contiguous()
+    for b in range(B):
+        ll, _ = lk.tree_optimize(agent._context(), torch.from_numpy(codes[b:b + 1]), m[b:b + 1])
+        assert abs(float(scores[b]) - float(ll[0])) <= 1e-6 * abs(float(ll[0]))
+    import re
+    lengths = [float(x) for x in re.findall(r":([0-9.eE+-]+)", best)]
+    assert float(scores.max()) < 0 and best.endswith(";")
+    assert len(lengths) >= 2 * T - 3 and len(set(lengths)) > 3          # optimised lengths, not the dummy constant
