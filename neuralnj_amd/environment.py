@@ -269,3 +269,24 @@ def _newick_tuple(tree, keys):
         return keys[tree.seq_indices[0]]
     return (_newick_tuple(tree.left_tree_data["tree"], keys), DUMMY_BRANCH,
             _newick_tuple(tree.right_tree_data["tree"], keys), DUMMY_BRANCH)
+
+
+def compute_raw_tree_log_score(env, rtree_str_batch, parallel=False, agent=None):
+    """Reference environment.py:394-441: optimise the branch lengths of the given Newick trees of env's alignments and
+    return their log-likelihoods -- there one raxml-ng call per tree (`pllpy.optimize_brlen(..., iters=3)`), here the
+    trees become merge lists (utils.newick_to_merges) and go through nnj_tree_optimize on the GPU.  `agent`: this
+    package's PhyloATTN (its device context); the reference's signature has no such argument because its scorer is a CPU
+    library."""
+    from . import likelihood as lk
+    from . import utils
+    from .phydata import seqs_to_codes
+    if agent is None or not hasattr(agent, "_context"):
+        raise NotImplementedError("compute_raw_tree_log_score scores on the GPU: pass agent=<neuralnj_amd PhyloATTN>")
+    ctx = agent._context()
+    out = []
+    for b, tree in enumerate(rtree_str_batch):
+        merges, br = utils.newick_to_merges(tree, env.seq_keys[b])
+        codes = torch.from_numpy(seqs_to_codes(env.batch_seqs[b])[None])
+        ll, _ = lk.tree_optimize(ctx, codes, torch.from_numpy(merges[None]), torch.from_numpy(br[None]))
+        out.append(float(ll[0]))
+    return out

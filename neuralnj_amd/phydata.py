@@ -105,3 +105,34 @@ def load_pi_instance(path):
         "seqs": [seqs], "seq_keys": [keys], "seq_weights": torch.from_numpy(weights),
         "file_paths": [path], "taxa_nums": [n_taxa], "seq_lens": [n_sites],
     }
+
+
+def load_phy_file(file_path):
+    """Reference phydata.py:478-496: sequential PHYLIP, one 'name sequence' line per taxon ('?' and '.' read as N)."""
+    with open(file_path, "r") as f:
+        lines = [ln for ln in f.readlines() if ln.strip()]
+    num_sequences, sequence_length = map(int, lines[0].split())
+    sequences = {}
+    for line in lines[1:]:
+        parts = line.split()
+        sequences[parts[0]] = "".join(parts[1:]).upper().replace("?", "N").replace(".", "N")
+    assert num_sequences == len(sequences)
+    assert sequence_length == len(next(iter(sequences.values())))
+    return list(sequences.values()), list(sequences.keys()), num_sequences, sequence_length
+
+
+def load_tree_file(file_path, device=None, pos=5):
+    """Reference phydata.py:633-: a label tree for SUPERVISED training (Bio.Phylo -> PhyloTree with inner-node names);
+    the inference and Finetune drivers import the name and never call it.  Here: the Newick string of the file; turn
+    it into a merge list with utils.newick_to_merges to score it (environment.compute_raw_tree_log_score)."""
+    with open(file_path, "r") as f:
+        return f.read().strip()
+
+
+class PhySampler:                      # reference phydata.py:442: batch sampler of the supervised training set
+    def __init__(self, *a, **k):
+        raise NotImplementedError("PhySampler belongs to supervised training (train.py), which is not part of this package")
+
+
+def custom_collate_fn(batch):          # reference phydata.py:1031: collate of the supervised training set
+    raise NotImplementedError("custom_collate_fn belongs to supervised training (train.py), which is not part of this package")

@@ -162,6 +162,76 @@ def get_score_indices_to_prev(actions_ij_prev, env, nb_seq, batch_size):
     return index_map_batch(int(nb_seq), a)
 
 
+def newick_to_merges(newick: str, keys):
+    """A binary (or root-trifurcating) Newick tree over the taxa `keys` -> (merges int32 [T-1,2], brlen float32
+    [T-1,2]) in the convention of the NJ loop (environment.py:764-768: the merged subtree takes position i, position j
+    leaves the list; brlen[s] = lengths of the edges above rows i and j of merge s, 0.1 where the string has none).
+    Lets a tree that did not come from a rollout (the reference's raw_tree_file / c_best_tree_file, a RAxML result) be
+    scored by nnj_tree_loglik / nnj_tree_optimize."""
+    s = newick.strip().rstrip(";").replace(" ", "")
+    pos = 0
+
+    def parse():
+        nonlocal pos
+        if s[pos] == "(":
+            pos += 1
+            kids = [parse()]
+            while s[pos] == ",":
+                pos += 1
+                kids.append(parse())
+            assert s[pos] == ")", "unbalanced Newick string"
+            pos += 1
+            node = kids
+        else:
+            node = None
+        start = pos
+        while pos < len(s) and s[pos] not in ",():":
+            pos += 1
+        label = s[start:pos]
+        length = None
+        if pos < len(s) and s[pos] == ":":
+            pos += 1
+            start = pos
+            while pos < len(s) and s[pos] not in ",()":
+                pos += 1
+            length = float(s[start:pos])
+        return (node if node is not None else label, length)
+
+    root, _ = parse()
+    if not isinstance(root, list):
+        raise ValueError("a single-leaf tree has no merges")
+    if len(root) == 3:                       # trifurcating (unrooted) root: join the last two first, like the reference
+        b, a = root.pop(), root.pop()
+        root.append(([a, b], 0.0))
+    index = {k: i for i, k in enumerate(keys)}
+    live = list(range(len(keys)))            # subtree ids by position; leaves are their taxon index
+    merges, brlen = [], []
+    next_id = [len(keys)]
+
+    def build(node):
+        kids, _ = node
+        if not isinstance(kids, list):
+            return index[kids]
+        if len(kids) != 2:
+            raise ValueError("only binary trees (and a trifurcating root) can be turned into a merge list")
+        ids = [build(k) for k in kids]
+        lens = [0.1 if k[1] is None else float(k[1]) for k in kids]
+        pa, pb = live.index(ids[0]), live.index(ids[1])
+        (i, li), (j, lj) = sorted(((pa, lens[0]), (pb, lens[1])))
+        merges.append((i, j))
+        brlen.append((li, lj))
+        me = next_id[0]
+        next_id[0] += 1
+        live[i] = me
+        del live[j]
+        return me
+
+    build((root, None))
+    if len(merges) != len(keys) - 1:
+        raise ValueError("the tree does not contain every taxon exactly once")
+    return np.array(merges, dtype=np.int32), np.array(brlen, dtype=np.float32)
+
+
 class ReplayBuffer:
     """Same surface as the reference's utils.ReplayBuffer (utils.py:67-100): the best `replay_buffer_size` distinct
     trees seen so far, distinct by `topo_repr` (the comparison nnj_topology_hash does on the device for whole batches).

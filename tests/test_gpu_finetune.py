@@ -249,3 +249,32 @@ def test_env_step_branch_optimize_scores_trees_on_the_gpu():
     lengths = [float(x) for x in re.findall(r":([0-9.eE+-]+)", best)]
     assert float(scores.max()) < 0 and best.endswith(";")
     assert len(lengths) >= 2 * T - 3 and len(set(lengths)) > 3          # optimised lengths, not the dummy constant
+
+
+def test_compute_raw_tree_log_score_scores_newick_trees():
+    """environment.compute_raw_tree_log_score (reference environment.py:394-441): Newick trees that did not come from a
+    rollout are scored on the GPU -- the tree of a rollout written as Newick and read back scores like its merge list."""
+    from neuralnj_amd import likelihood as lk
+    from neuralnj_amd.environment import PhyInferEnv, compute_raw_tree_log_score
+    from neuralnj_amd.model import PhyloATTN
+    cfgs = utils.shipped_config()
+    cfgs.model.num_enc_layers = 1
+    agent = PhyloATTN(cfgs)
+    agent.load_state_dict({k: torch.from_numpy(v) for k, v in weights.seeded_state(cfgs, 2, "sharp").items()}, strict=True)
+    agent = agent.to(_dev()).eval()
+    T, L = 9, 120
+    codes = synth.synth_codes_tree(1, T, L, seed=6)
+    keys = [f"taxon{i + 1}" for i in range(T)]
+    rng = np.random.default_rng(1)
+    merges = np.array([[sorted(rng.choice(n, size=2, replace=False)) for n in range(T, 1, -1)]], dtype=np.int32)
+    ll, br = lk.tree_optimize(agent._context(), torch.from_numpy(codes), torch.from_numpy(merges))
+    env = PhyInferEnv(cfgs, _dev())
+    env.init_states([synth.codes_to_seqs(codes[0])], [keys], None)
+    env.apply_merges(merges, br.cpu().numpy(), ll.cpu().numpy())
+    newick = env.states[0].subtrees[0].utree_op_str
+    got = compute_raw_tree_log_score(env, [newick], agent=agent)
+    # three more optimisation sweeps from the lengths in the string: the likelihood can only rise, and only a little
+    assert float(ll[0]) - 1e-6 * abs(float(ll[0])) <= got[0] <= float(ll[0]) + 1e-3 * abs(float(ll[0]))
+    m2, b2 = utils.newick_to_merges(newick, keys)             # ... and without optimisation it is the same number
+    same = lk.tree_loglik(agent._context(), torch.from_numpy(codes), torch.from_numpy(m2[None]), torch.from_numpy(b2[None]))
+    assert abs(float(same[0]) - float(ll[0])) <= 1e-5 * abs(float(ll[0]))

@@ -151,3 +151,51 @@ def test_rf_distance():
     assert utils.rf_distance(s, s)[0] == 0
     # rooted binary vs its unrooted reading: same splits
     assert utils.rf_distance("((A, B), (C, (D, E)));", "(A, B, (C, (D, E)));")[0] == 0
+
+
+def test_newick_to_merges_round_trip():
+    """utils.newick_to_merges turns any binary Newick tree (trifurcating root included) into a merge list of the NJ
+    loop's convention: replayed through the environment it gives the same topology and the same branch lengths."""
+    from neuralnj_amd.environment import PhyInferEnv
+    cfgs = utils.shipped_config()
+    rng = np.random.default_rng(0)
+    for _ in range(25):
+        T = int(rng.integers(3, 14))
+        keys = [f"taxon{i + 1}" for i in range(T)]
+        merges = [tuple(sorted(rng.choice(n, size=2, replace=False))) for n in range(T, 1, -1)]
+        br = rng.random((1, T - 1, 2)).astype(np.float32) + 0.01
+        env = PhyInferEnv(cfgs, "cpu")
+        env.init_states([[""] * T], [keys], None)
+        env.apply_merges(np.array([merges]), br, np.array([-1.0]))
+        nw = env.states[0].subtrees[0].utree_op_str
+        m2, b2 = utils.newick_to_merges(nw, keys)
+        env2 = PhyInferEnv(cfgs, "cpu")
+        env2.init_states([[""] * T], [keys], None)
+        env2.apply_merges(m2[None], b2[None], np.array([-1.0]))
+        assert utils.rf_distance(nw, env2.states[0].subtrees[0].utree_op_str)[0] == 0
+        assert sorted(np.round(br.reshape(-1), 5).tolist()) == sorted(np.round(b2.reshape(-1), 5).tolist())
+    m, b = utils.newick_to_merges("(taxon1:0.1,taxon2:0.2,(taxon3:0.3,taxon4:0.4):0.5);", [f"taxon{i + 1}" for i in range(4)])
+    assert m.tolist() == [[2, 3], [1, 2], [0, 1]]
+    with pytest.raises(ValueError):
+        utils.newick_to_merges("(taxon1,taxon2,taxon3,taxon4);", [f"taxon{i + 1}" for i in range(4)])
+
+
+def test_reference_driver_import_lines_resolve():
+    """The import lines of the reference's driver (finetune_rl_search.py:13-28) against the drop-in module names of
+    neuralnj_amd/compat (in a process of its own: the names `model`, `utils` ... are too generic to put on this one's
+    path)."""
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "from environment import PhyInferEnv, compute_raw_tree_log_score\n"
+        "import environment\n"
+        "from model import PhyloATTN as PGPI\n"
+        "import utils\n"
+        "from phydata import PhySampler, custom_collate_fn, load_pi_instance, load_tree_file, load_phy_file_multirow, load_phy_file\n"
+        "c = utils.empty_config(); utils.set_evolution_model('GTR+I+G'); utils.ReplayBuffer(4); utils.get_score_indices_to_prev\n"
+        "assert len(PGPI(utils.shipped_config()).state_dict()) == 172\n"
+        "print('ok')\n") % (repo, os.path.join(repo, "neuralnj_amd", "compat"))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stderr[-2000:]
