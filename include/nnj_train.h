@@ -42,6 +42,10 @@ int nnjt_gemm_run(const nnjt_gemm* g, void* stream);
 int nnjt_add_bias(float* y, const float* bias, int64_t rows, int32_t cols, void* stream);
 int nnjt_colsum(const float* x, float* out, int64_t rows, int32_t cols, void* stream);
 
+/* out[c] = sum_r x[r, c] (rows x cols, any number of columns; rows added in order): the second step of a contraction
+ * that was cut into pieces along k (weight gradients over millions of tokens, attention logits over sites x features). */
+int nnjt_sum_rows(const float* x, float* out, int64_t rows, int64_t cols, void* stream);
+
 /* nn.LayerNorm(64), eps 1e-5 (reference msa_modules.py:107): y = (x - mean) * rstd * gamma + beta over the last dim.
  * Forward keeps mean / rstd per row for the backward; dgamma / dbeta are ACCUMULATED (+=). */
 int nnjt_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,

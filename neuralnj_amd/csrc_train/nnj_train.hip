@@ -151,6 +151,16 @@ __global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ x, flo
   atomicAdd(out + c, s);
 }
 
+// out[c] = sum_r x[r, c] for any number of columns (thread = column, rows walked in order: deterministic): the second
+// step of a contraction cut into pieces
+__global__ void k_sum_rows(const float* __restrict__ x, float* __restrict__ out, int64_t rows, int64_t cols) {
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= cols) return;
+  float s = 0.f;
+  for (int64_t r = 0; r < rows; ++r) s += x[r * cols + c];
+  out[c] = s;
+}
+
 // ------------------------------------------------------------------ LayerNorm over 64 features: one wavefront per row
 __global__ __launch_bounds__(256) void k_ln_fwd(const float* __restrict__ x, const float* __restrict__ gamma,
                                                 const float* __restrict__ beta, float* __restrict__ y,
@@ -334,6 +344,12 @@ int nnjt_add_bias(float* y, const float* bias, int64_t rows, int32_t cols, void*
 int nnjt_colsum(const float* x, float* out, int64_t rows, int32_t cols, void* stream) {
   if (!x || !out || cols > 256) return fail(-1, "nnjt_colsum: null or more than 256 columns");
   hipLaunchKernelGGL(k_colsum, dim3(blocks_for(rows, 64)), dim3(256), 0, static_cast<hipStream_t>(stream), x, out, rows, cols);
+  CHK_LAUNCH();
+  return 0;
+}
+int nnjt_sum_rows(const float* x, float* out, int64_t rows, int64_t cols, void* stream) {
+  if (!x || !out || rows <= 0 || cols <= 0) return fail(-1, "nnjt_sum_rows: bad argument");
+  hipLaunchKernelGGL(k_sum_rows, dim3(blocks_for(cols, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), x, out, rows, cols);
   CHK_LAUNCH();
   return 0;
 }

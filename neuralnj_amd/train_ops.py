@@ -35,6 +35,7 @@ _SIGS = {
     "nnjt_gemm_run": ([C.POINTER(Gemm), _vp], C.c_int),
     "nnjt_add_bias": ([_vp, _vp, _i64, _i32, _vp], C.c_int),
     "nnjt_colsum": ([_vp, _vp, _i64, _i32, _vp], C.c_int),
+    "nnjt_sum_rows": ([_vp, _vp, _i64, _i64, _vp], C.c_int),
     "nnjt_layernorm_fwd": ([_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp], C.c_int),
     "nnjt_layernorm_bwd": ([_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp], C.c_int),
     "nnjt_gelu_fwd": ([_vp, _vp, _i64, _vp], C.c_int),
@@ -100,27 +101,36 @@ def gemm(A, B, Cout, M, N, K, sA, sB, sC, nb=(1, 1), bA=(0, 0), bB=(0, 0), bC=(0
     _chk(load_library().nnjt_gemm_run(C.byref(g), _st(Cout)))
 
 
-_SPLIT = 512       # contractions longer than twice this are cut into pieces (one workgroup each) summed by a second product
+def _piece(M, N, K, nb=1):
+    """length of the pieces a contraction of length K is cut into: enough pieces that the launch has a few hundred
+    workgroups (one 128 x 64 output tile per piece and batch entry), none shorter than 64; 0 = do not cut"""
+    tiles = ((M + 127) // 128) * ((N + 63) // 64) * nb
+    want = max(1, 256 // tiles)
+    if want == 1 or K < 128:
+        return 0
+    piece = max(64, -(-K // want))
+    piece = -(-piece // 16) * 16
+    return piece if piece < K else 0
 
 
 def gemm_longk(A, B, Cout, M, N, K, sA, sB, sC, alpha=1.0):
-    """Cout[m,n] = alpha * sum_k A[m,k] B[k,n] for a long contraction (weight gradients: k = tokens; the pair scorer's
-    attention logits: k = sites x features): pieces of _SPLIT as a batch into a scratch, then ones^T x scratch."""
-    if K <= 2 * _SPLIT:
+    """Cout[m,n] = alpha * sum_k A[m,k] B[k,n] for a contraction that is long next to its output (weight gradients: k =
+    tokens; the pair scorer's attention logits: k = sites x features): a single workgroup per output tile would walk k
+    alone, so k is cut into pieces computed as a batch into a scratch, which nnjt_sum_rows adds up in order."""
+    piece = _piece(M, N, K)
+    if not piece:
         return gemm(A, B, Cout, M, N, K, sA, sB, sC, alpha=alpha)
-    nfull = K // _SPLIT
-    tail = K - nfull * _SPLIT
+    nfull = K // piece
+    tail = K - nfull * piece
     parts = torch.empty((nfull + (1 if tail else 0), M, N), dtype=torch.float32, device=Cout.device)
-    gemm(A, B, parts, M, N, _SPLIT, sA, sB, (N, 1), nb=(nfull, 1), bA=(_SPLIT * sA[1], 0), bB=(_SPLIT * sB[0], 0),
+    gemm(A, B, parts, M, N, piece, sA, sB, (N, 1), nb=(nfull, 1), bA=(piece * sA[1], 0), bB=(piece * sB[0], 0),
          bC=(M * N, 0), alpha=alpha)
     if tail:
-        At = A.view(-1)[nfull * _SPLIT * sA[1]:]
-        Bt = B.view(-1)[nfull * _SPLIT * sB[0]:]
+        At = A.view(-1)[nfull * piece * sA[1]:]
+        Bt = B.view(-1)[nfull * piece * sB[0]:]
         gemm(At, Bt, parts[nfull], M, N, tail, sA, sB, (N, 1), alpha=alpha)
-    # Cout (one row of M*N values) = ones[1 x parts] @ parts[parts x M*N]
-    assert sC == (N, 1) and Cout.is_contiguous(), "long contractions write dense outputs"
-    ones = torch.ones(parts.shape[0], dtype=torch.float32, device=Cout.device)
-    gemm(ones, parts, Cout, 1, M * N, parts.shape[0], (0, 1), (M * N, 1), (M * N, 1))
+    assert sC == (N, 1) and Cout.is_contiguous(), "cut contractions write dense outputs"
+    _chk(load_library().nnjt_sum_rows(_p(parts), _p(Cout), parts.shape[0], M * N, _st(Cout)))
 
 
 # ---------------------------------------------------------------------------------------------------- operators
@@ -429,7 +439,7 @@ class Bmm(torch.autograd.Function):
 
 def _bgemm(A, B, Cout, nb, M, N, K, sA, sB, sC, bsA, bsB, bsC, alpha):
     """batched product with a long-contraction path and the 65535-entry grid limit handled here"""
-    if K > 2 * _SPLIT and nb <= 64:
+    if nb <= 64 and _piece(M, N, K, nb):
         for b in range(nb):
             gemm_longk(A[b], B[b], Cout[b], M, N, K, sA, sB, sC, alpha=alpha)
         return
