@@ -151,12 +151,13 @@ int nnj_select_pair(nnj_handle* h, const float* logits_dev, int32_t* ij_out_dev,
  *   forced_next_dev  NULL, or int32 [B,2]: returned in chosen_ij_dev instead of the argmax (teacher forcing)
  *   state_out_dev    [B,n,C,D]     logits_out_dev [B,P(n)]   chosen_ij_dev int32 [B,2]   top2_gap_dev [B] or NULL
  * n = number of rows AFTER the merge, n >= 2.
- * A loop of calls is a session: the library keeps the rows in slot layout, with the cached per-row transforms, inside
- * the caller's workspace, so consecutive steps re-transform nothing.  The session continues when state_dev is the
- * state_out_dev of the previous call (same workspace pointer, B, L, and n+1 = the previous n); anything else --
- * another tensor, another workspace, any other entry point called on the same workspace in between -- starts a new
- * session from the dense state_dev (copy + row transforms).  Iterated from the encoder output it reproduces
- * nnj_rollout_argmax bit for bit.  state_out_dev is the dense tensor the reference's env.step returns. */
+ * A loop of calls is a session (see "Sessions" above): the library keeps the rows in slot layout, with the cached
+ * per-row transforms, inside the caller's workspace, so consecutive steps re-transform nothing.  The session continues
+ * when state_dev is the tensor the library last saw or returned (same workspace pointer, B, L, and n+1 = the session's
+ * row count); anything else -- another tensor, another workspace, an entry point other than the dense-state ones
+ * (nnj_encode, nnj_rollout_*) on the same workspace in between -- starts a new session from the dense state_dev (copy
+ * + row transforms).  Iterated from the encoder output it reproduces nnj_rollout_argmax bit for bit.  state_out_dev
+ * is the dense tensor the reference's env.step returns. */
 int nnj_step(nnj_handle* h, const float* state_dev, const uint8_t* mask_dev, const int32_t* ij_dev,
              const float* logits_prev_dev, const int32_t* forced_next_dev, float* state_out_dev,
              float* logits_out_dev, int32_t* chosen_ij_dev, float* top2_gap_dev, int32_t B, int32_t n, int32_t L,
