@@ -192,7 +192,14 @@ def reinforce_loss(batch, agent, env, forced_merges, tree_scores, baseline, temp
     env.init_states(batch["seqs"], batch["seq_keys"], arr)
     merges = np.asarray(forced_merges)
     B = merges.shape[0]
-    env.state_tensor = agent.encode_zxr(env.init_state_tensor, mask)
+    if B > 1 and agent._wants_grad() and all(torch.equal(arr[0], arr[b]) for b in range(1, B)) \
+            and all(torch.equal(mask[0], mask[b]) for b in range(1, B)):
+        # replicas of ONE alignment (the batch of the reference's Search / Finetune loops): encoded once, the gradient
+        # of the shared encoding is the sum over the replicas
+        from .train_model import ExpandBatch
+        env.state_tensor = ExpandBatch.apply(agent.encode_zxr(env.init_state_tensor[:1], mask[:1]), B)
+    else:
+        env.state_tensor = agent.encode_zxr(env.init_state_tensor, mask)
     ij_prev, logits_prev, selected, log_ps, tables, step = None, None, [], [], [], 0
     while True:
         n = env.state_tensor.shape[1]
@@ -232,7 +239,6 @@ def rl_finetuning(cfgs, batch, agent, optimizer, env, stop_step=20, seed=0, mode
     ctx = agent._context()
     codes = (batch["codes"] if "codes" in batch else agent.onehot_to_codes(batch["data"].to(device)))[:1].to(device)
     mask = (batch["seq_weights"].to(device) == 0)[:1]
-    one = {k: (v[:1] if not isinstance(v, list) else v[:1]) for k, v in batch.items()}
     T = codes.shape[1]
     rng = np.random.default_rng(seed)
     agent.eval()
@@ -245,31 +251,36 @@ def rl_finetuning(cfgs, batch, agent, optimizer, env, stop_step=20, seed=0, mode
         greedy = ctx.rollout_argmax(codes, mask)["merges"]
         baseline_val = float(score(greedy)[0][0])
     best_tree, best_score, losses, batch_scores, step_cur = None, -np.inf, [], [], 0
+    E = int(cfgs.num_episodes)
+    reps = {k: (v[:1] * E if isinstance(v, list) else v[:1].expand(E, *v.shape[1:])) for k, v in batch.items()}
     for epoch in range(1, int(cfgs.num_epoch) + 1):
         if epoch > 1 and batch_scores:
             baseline_val = max(baseline_val, sum(batch_scores) / len(batch_scores))
             batch_scores = []
         optimizer.zero_grad()
-        for episode in range(int(cfgs.num_episodes)):
-            with torch.no_grad():
-                u = torch.from_numpy(rng.random((1, T - 1)).astype(np.float32))
-                merges = agent._context().rollout_sample(codes, mask, u, temperature=temperature, replicas=1)["merges"]
-                agent._context().check_numeric()
-                sc, br = score(merges)
-            loss, _ = reinforce_loss(one, agent, env, merges.cpu().numpy(), sc, baseline_val, temperature,
-                                     float(cfgs.entropy_reg_strength), device)
-            loss.backward()
-            losses.append(float(loss.detach()))
-            batch_scores.append(float(sc[0]))
-            if float(sc[0]) > best_score:
-                best_score = float(sc[0])
-                env.init_states([batch["seqs"][0]], [batch["seq_keys"][0]], None)
-                env.apply_merges(merges.cpu().numpy(), br.cpu().numpy(), sc.cpu().numpy())
-                best_tree = env.states[0].subtrees[0].utree_op_str
-            step_cur += 1
-            if episode == int(cfgs.num_episodes) - 1:
-                torch.nn.utils.clip_grad_value_(agent.parameters(), clip_value=float(cfgs.clip_value))
-                optimizer.step()
+        # The reference runs the epoch's episodes one after the other against the same weights and baseline and adds
+        # their gradients up (loss.backward() per episode, one optimizer step per epoch).  Here they run as ONE batch of
+        # E replicas: sampled together, scored together, replayed with gradients together (the alignment encoded
+        # once); E x the batch-mean loss is the sum of the E episode losses.
+        with torch.no_grad():
+            u = torch.from_numpy(rng.random((E, T - 1)).astype(np.float32))
+            merges = agent._context().rollout_sample(codes, mask, u, temperature=temperature, replicas=E)["merges"]
+            agent._context().check_numeric()
+            sc, br = score(merges)
+        loss, _ = reinforce_loss(reps, agent, env, merges.cpu().numpy(), sc, baseline_val, temperature,
+                                 float(cfgs.entropy_reg_strength), device)
+        (loss * E).backward()
+        losses.append(float(loss.detach()))
+        batch_scores.extend(float(v) for v in sc)
+        k = int(torch.argmax(sc))
+        if float(sc[k]) > best_score:
+            best_score = float(sc[k])
+            env.init_states([batch["seqs"][0]], [batch["seq_keys"][0]], None)
+            env.apply_merges(merges[k:k + 1].cpu().numpy(), br[k:k + 1].cpu().numpy(), sc[k:k + 1].cpu().numpy())
+            best_tree = env.states[0].subtrees[0].utree_op_str
+        step_cur += E
+        torch.nn.utils.clip_grad_value_(agent.parameters(), clip_value=float(cfgs.clip_value))
+        optimizer.step()
         if step_cur >= int(stop_step):
             break
     return dict(the_best_tree=best_tree, the_best_score=best_score, step_cur=step_cur, losses=losses,

@@ -212,3 +212,21 @@ def env_step(model, state, ij):
     base = r + (r >= j_idx)                                  # positions of the old rows once j is gone ...
     base = torch.where(r == i_idx, torch.full_like(base, n), base).contiguous()   # ... the merged row (index n) at i
     return T.GatherRows.apply(_CatRows.apply(state, new), base)
+
+
+class ExpandBatch(torch.autograd.Function):
+    """x [1, ...] -> [B, ...] (B replicas of one encoded alignment: the reference re-encodes the same alignment for every
+    replica of a batch); the gradient is the sum over the replicas (nnjt_sum_rows)."""
+
+    @staticmethod
+    def forward(ctx, x, B):
+        ctx.shape = tuple(x.shape)
+        return x.expand(B, *x.shape[1:]).contiguous()
+
+    @staticmethod
+    def backward(ctx, d):
+        d = d.contiguous()
+        B = d.shape[0]
+        out = torch.empty(ctx.shape, dtype=torch.float32, device=d.device)
+        T._chk(T.load_library().nnjt_sum_rows(T._p(d), T._p(out), B, d.numel() // B, T._st(d)))
+        return out, None
