@@ -149,7 +149,7 @@ def test_finetune_inference_file_to_tree(tmp_path):
     res = finetune_inference(cfgs, str(d), str(tmp_path / "out"), stop_step=6, device="cuda:0")["a.phy"]
     tree = (tmp_path / "out" / "a.tre").read_text()
     assert all(k + ":" in tree for k in keys) and tree.endswith(";")
-    assert res["step_cur"] == 6 and len(res["losses"]) == 6 and all(np.isfinite(res["losses"]))
+    assert res["step_cur"] == 6 and len(res["losses"]) == 3 and all(np.isfinite(res["losses"]))   # 3 epochs x 2 episodes
     assert np.isfinite(res["the_best_score"]) and res["the_best_score"] < 0
 
 
@@ -278,3 +278,42 @@ def test_compute_raw_tree_log_score_scores_newick_trees():
     m2, b2 = utils.newick_to_merges(newick, keys)             # ... and without optimisation it is the same number
     same = lk.tree_loglik(agent._context(), torch.from_numpy(codes), torch.from_numpy(m2[None]), torch.from_numpy(b2[None]))
     assert abs(float(same[0]) - float(ll[0])) <= 1e-5 * abs(float(ll[0]))
+
+
+def test_batched_episodes_equal_the_sum_of_single_episodes():
+    """rl_finetuning runs the episodes of an epoch as one batch of replicas (one encoding, shared): E x the batch loss
+    and its gradient equal the sum over the E episodes run one by one, as the reference runs them."""
+    from neuralnj_amd.environment import PhyInferEnv
+    from neuralnj_amd.model import PhyloATTN
+    from neuralnj_amd.rollout import reinforce_loss
+    E, T, L = 3, 7, 64
+    cfgs = utils.shipped_config()
+    cfgs.model.num_enc_layers = 2
+    st = weights.seeded_state(cfgs, 9, "sharp")
+    codes = synth.synth_codes_tree(1, T, L, seed=2)
+    rng = np.random.default_rng(7)
+    merges = np.array([[sorted(rng.choice(n, size=2, replace=False)) for n in range(T, 1, -1)] for _ in range(E)], dtype=np.int32)
+    scores = np.array([0.5, -0.7, 1.1], dtype=np.float32)
+
+    def run(sel):
+        agent = PhyloATTN(cfgs)
+        agent.load_state_dict({k: torch.from_numpy(v) for k, v in st.items()}, strict=True)
+        agent = agent.to(_dev()).eval()
+        total = 0.0
+        for idx in sel:
+            B = len(idx)
+            batch = {"data": torch.from_numpy(synth.codes_to_onehot(codes)).expand(B, -1, -1, -1),
+                     "seqs": [synth.codes_to_seqs(codes[0])] * B, "seq_keys": [[f"taxon{i + 1}" for i in range(T)]] * B,
+                     "seq_weights": torch.ones((B, L), dtype=torch.float32)}
+            loss, _ = reinforce_loss(batch, agent, PhyInferEnv(cfgs, _dev()), merges[idx], scores[idx], 0.2, 1.0, 0.05)
+            (loss * B).backward()
+            total += float(loss.detach()) * B
+        return total, {k: p.grad.detach().cpu().numpy() for k, p in agent.state_dict(keep_vars=True).items()}
+
+    l_b, g_b = run([[0, 1, 2]])
+    l_s, g_s = run([[0], [1], [2]])
+    assert abs(l_b - l_s) <= 1e-4 * max(1.0, abs(l_s))
+    gmax = max(float(np.abs(v).max()) for v in g_s.values())
+    for k in g_s:
+        scale = max(float(np.abs(g_s[k]).max()), 1e-3 * gmax)      # (floor: the analytically vanishing gradients are noise)
+        assert float(np.abs(g_b[k] - g_s[k]).max()) <= 2e-3 * scale, k
