@@ -225,7 +225,8 @@ def reinforce_loss(batch, agent, env, forced_merges, tree_scores, baseline, temp
     return policy_loss + entropy_reg * entropy_reg_strength, tables
 
 
-def rl_finetuning(cfgs, batch, agent, optimizer, env, stop_step=20, seed=0, model=None, temperature=1.0, device=None):
+def rl_finetuning(cfgs, batch, agent, optimizer, env, stop_step=20, seed=0, model=None, temperature=1.0, device=None,
+                  dist=None):
     """Counterpart of the reference's RL_finetuning (finetune_rl_search.py:192-335) for one alignment: per episode one
     sampled rollout of the current policy (nnj_rollout_sample: the fused inference kernels), its tree scored by
     log-likelihood on the GPU (likelihood.tree_optimize where the reference calls raxml-ng), the episode replayed with
@@ -233,14 +234,20 @@ def rl_finetuning(cfgs, batch, agent, optimizer, env, stop_step=20, seed=0, mode
     and the optimizer steps.  Baseline as in the reference: the first epoch's is one greedy (Argmax) rollout's score,
     later ones the running maximum of the epoch means.  The reference's replay buffer re-injects nothing (its `sample`
     returns None, utils.py:99), so every action here is sampled too; utils.ReplayBuffer keeps the same surface.
+    `dist` (an initialised torch.distributed, one process per GPU): the episodes of an epoch are split over the ranks
+    (every rank samples with its own stream), the gradients are summed by one all-reduce of one flat bucket per
+    optimizer step (sharding.allreduce_gradients) and every rank takes the same step; the best tree is each rank's own.
     Returns dict(the_best_tree, the_best_score, step_cur, losses)."""
     from . import likelihood as lk
+    from . import sharding
     device = device or next(agent.parameters()).device
+    world = dist.get_world_size() if dist is not None and dist.is_initialized() else 1
+    rank = dist.get_rank() if world > 1 else 0
     ctx = agent._context()
     codes = (batch["codes"] if "codes" in batch else agent.onehot_to_codes(batch["data"].to(device)))[:1].to(device)
     mask = (batch["seq_weights"].to(device) == 0)[:1]
     T = codes.shape[1]
-    rng = np.random.default_rng(seed)
+    rng = np.random.default_rng([seed, rank])
     agent.eval()
 
     def score(merges):
@@ -251,7 +258,8 @@ def rl_finetuning(cfgs, batch, agent, optimizer, env, stop_step=20, seed=0, mode
         greedy = ctx.rollout_argmax(codes, mask)["merges"]
         baseline_val = float(score(greedy)[0][0])
     best_tree, best_score, losses, batch_scores, step_cur = None, -np.inf, [], [], 0
-    E = int(cfgs.num_episodes)
+    lo, hi = sharding.shard_bounds(int(cfgs.num_episodes), world, rank)
+    E = max(hi - lo, 1)                      # (a rank without an episode still runs one: every rank joins the all-reduce)
     reps = {k: (v[:1] * E if isinstance(v, list) else v[:1].expand(E, *v.shape[1:])) for k, v in batch.items()}
     for epoch in range(1, int(cfgs.num_epoch) + 1):
         if epoch > 1 and batch_scores:
@@ -278,7 +286,8 @@ def rl_finetuning(cfgs, batch, agent, optimizer, env, stop_step=20, seed=0, mode
             env.init_states([batch["seqs"][0]], [batch["seq_keys"][0]], None)
             env.apply_merges(merges[k:k + 1].cpu().numpy(), br[k:k + 1].cpu().numpy(), sc[k:k + 1].cpu().numpy())
             best_tree = env.states[0].subtrees[0].utree_op_str
-        step_cur += E
+        step_cur += int(cfgs.num_episodes) if world > 1 else E
+        sharding.allreduce_gradients(agent.parameters(), dist)
         torch.nn.utils.clip_grad_value_(agent.parameters(), clip_value=float(cfgs.clip_value))
         optimizer.step()
         if step_cur >= int(stop_step):

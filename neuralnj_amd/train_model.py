@@ -143,6 +143,12 @@ def decode(model, state, pad, info):
     keep = keep.contiguous()
     state = state.contiguous()
     if logits_prev is None:
+        # the unfused path keeps every activation of the all-pairs step: ~14 tensors of [B, P(n), C, D] floats
+        need = 14 * B * (n * (n - 1) // 2) * C * D * 4
+        total = torch.cuda.get_device_properties(dev).total_memory
+        if need > 0.8 * total:
+            raise RuntimeError(f"Finetune (unfused first path): the all-pairs step of {B} x {n} rows x {C} sites needs about "
+                               f"{need / 2**30:.0f} GiB of activations, the device has {total / 2**30:.0f} GiB")
         row, col = torch.triu_indices(n, n, offset=1, device=dev)
         i_idx = row.unsqueeze(0).expand(B, -1).contiguous()
         j_idx = col.unsqueeze(0).expand(B, -1).contiguous()

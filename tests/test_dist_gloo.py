@@ -68,3 +68,28 @@ def test_shard_bounds_cover_everything():
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             sizes = [b - a for a, b in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+def _grad_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(0)
+    params = [torch.nn.Parameter(torch.zeros(3, 5)), torch.nn.Parameter(torch.zeros(7)), torch.nn.Parameter(torch.zeros(2, 2))]
+    params[0].grad = torch.full((3, 5), float(rank + 1))
+    params[1].grad = torch.arange(7, dtype=torch.float32) * (rank + 1)
+    if rank == 0:
+        params[2].grad = torch.ones(2, 2)                      # rank 1 has no gradient for this tensor
+    sharding.allreduce_gradients(params, dist)
+    np.save(os.path.join(out_dir, f"g{rank}.npy"), np.concatenate([p.grad.numpy().reshape(-1) for p in params]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gradient_bucket_allreduce(tmp_path):
+    """The one exchange step of the Finetune mode: gradients of all parameters summed over the ranks through one flat
+    bucket; a tensor without a gradient on some rank contributes zeros."""
+    world = 2
+    mp.spawn(_grad_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    want = np.concatenate([np.full(15, 3.0), np.arange(7) * 3.0, np.ones(4)])
+    for r in range(world):
+        assert np.array_equal(np.load(tmp_path / f"g{r}.npy"), want)

@@ -314,6 +314,10 @@ def test_batched_episodes_equal_the_sum_of_single_episodes():
     l_s, g_s = run([[0], [1], [2]])
     assert abs(l_b - l_s) <= 1e-4 * max(1.0, abs(l_s))
     gmax = max(float(np.abs(v).max()) for v in g_s.values())
+    zero = ("row_self_attention.layer.k_proj.bias", "column_self_attention.layer.k_proj.bias", "g_attn_k.bias", "s_out.2.bias")
     for k in g_s:
-        scale = max(float(np.abs(g_s[k]).max()), 1e-3 * gmax)      # (floor: the analytically vanishing gradients are noise)
+        if k.endswith(zero):                     # analytically vanishing gradients: rounding noise on both sides
+            assert max(float(np.abs(g_b[k]).max()), float(np.abs(g_s[k]).max())) <= 1e-3 * gmax, k
+            continue
+        scale = max(float(np.abs(g_s[k]).max()), 1e-4 * gmax)
         assert float(np.abs(g_b[k] - g_s[k]).max()) <= 2e-3 * scale, k
