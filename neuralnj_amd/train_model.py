@@ -143,18 +143,32 @@ def decode(model, state, pad, info):
     keep = keep.contiguous()
     state = state.contiguous()
     if logits_prev is None:
-        # the unfused path keeps every activation of the all-pairs step: ~14 tensors of [B, P(n), C, D] floats
-        need = 14 * B * (n * (n - 1) // 2) * C * D * 4
-        total = torch.cuda.get_device_properties(dev).total_memory
-        if need > 0.8 * total:
-            raise RuntimeError(f"Finetune (unfused first path): the all-pairs step of {B} x {n} rows x {C} sites needs about "
-                               f"{need / 2**30:.0f} GiB of activations, the device has {total / 2**30:.0f} GiB")
+        # The unfused path keeps every activation of the all-pairs step: ~14 tensors of [B, pairs, C, D] floats.  Above
+        # a budget (a third of the device, or NNJ_TRAIN_PAIR_CHUNK pairs) the pairs go through in chunks under
+        # torch.utils.checkpoint: a chunk's activations are dropped after its forward and recomputed in its backward
+        # (one more scorer forward), so BASELINE configs[4] (200 x 4096: 19,900 pairs, ~270 GB unchunked) fits.
+        import os
         row, col = torch.triu_indices(n, n, offset=1, device=dev)
-        i_idx = row.unsqueeze(0).expand(B, -1).contiguous()
-        j_idx = col.unsqueeze(0).expand(B, -1).contiguous()
-        x_i = T.GatherRows.apply(state, i_idx)
-        x_j = T.GatherRows.apply(state, j_idx)
-        return decode_gg(model, state, x_i, x_j, keep, i_idx, j_idx)
+        P = row.numel()
+        per_pair = 14 * B * C * D * 4
+        budget = torch.cuda.get_device_properties(dev).total_memory // 3
+        chunk = int(os.environ.get("NNJ_TRAIN_PAIR_CHUNK", "0")) or max(64, budget // per_pair)
+        if chunk >= P:
+            i_idx = row.unsqueeze(0).expand(B, -1).contiguous()
+            j_idx = col.unsqueeze(0).expand(B, -1).contiguous()
+            return decode_gg(model, state, T.GatherRows.apply(state, i_idx), T.GatherRows.apply(state, j_idx), keep, i_idx, j_idx)
+        from torch.utils.checkpoint import checkpoint
+
+        def part(st, lo, hi):
+            i_idx = row[lo:hi].unsqueeze(0).expand(B, -1).contiguous()
+            j_idx = col[lo:hi].unsqueeze(0).expand(B, -1).contiguous()
+            return decode_gg(model, st, T.GatherRows.apply(st, i_idx), T.GatherRows.apply(st, j_idx), keep, i_idx, j_idx)
+
+        out = None
+        for lo in range(0, P, chunk):
+            piece = checkpoint(part, state, lo, min(P, lo + chunk), use_reentrant=False)
+            out = piece if out is None else _cat_last(out, piece)
+        return out
     ip = torch.as_tensor(actions_ij_prev).to(dev)[:, 0].to(torch.int64)
     r = torch.arange(n, device=dev, dtype=torch.int64).unsqueeze(0).expand(B, n)
     i_idx = torch.minimum(ip.unsqueeze(1), r).contiguous()                     # sort((i_prev, r))

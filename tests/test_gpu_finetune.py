@@ -321,3 +321,39 @@ def test_batched_episodes_equal_the_sum_of_single_episodes():
             continue
         scale = max(float(np.abs(g_s[k]).max()), 1e-4 * gmax)
         assert float(np.abs(g_b[k] - g_s[k]).max()) <= 2e-3 * scale, k
+
+
+def test_chunked_all_pairs_step_gives_the_same_gradients(monkeypatch):
+    """Above a memory budget the all-pairs step runs in chunks under activation checkpointing (what lets a 200 x 4096
+    episode fit): same loss and gradients as the unchunked step (the chunk size forced small here)."""
+    from neuralnj_amd.environment import PhyInferEnv
+    from neuralnj_amd.model import PhyloATTN
+    from neuralnj_amd.rollout import reinforce_loss
+    B, T, L = 2, 9, 64
+    cfgs = utils.shipped_config()
+    cfgs.model.num_enc_layers = 1
+    st = weights.seeded_state(cfgs, 5, "sharp")
+    codes = synth.synth_codes_tree(B, T, L, seed=1)
+    rng = np.random.default_rng(2)
+    merges = np.array([[sorted(rng.choice(n, size=2, replace=False)) for n in range(T, 1, -1)] for _ in range(B)], dtype=np.int32)
+    batch = {"data": torch.from_numpy(synth.codes_to_onehot(codes)), "seqs": [synth.codes_to_seqs(codes[b]) for b in range(B)],
+             "seq_keys": [[f"taxon{i + 1}" for i in range(T)]] * B, "seq_weights": torch.ones((B, L), dtype=torch.float32)}
+
+    def run():
+        agent = PhyloATTN(cfgs)
+        agent.load_state_dict({k: torch.from_numpy(v) for k, v in st.items()}, strict=True)
+        agent = agent.to(_dev()).eval()
+        loss, _ = reinforce_loss(batch, agent, PhyInferEnv(cfgs, _dev()), merges, np.array([0.4, -0.6], np.float32), 0.1, 1.0, 0.03)
+        loss.backward()
+        return float(loss.detach()), {k: p.grad.detach().cpu().numpy() for k, p in agent.state_dict(keep_vars=True).items()}
+
+    l0, g0 = run()
+    monkeypatch.setenv("NNJ_TRAIN_PAIR_CHUNK", "7")            # 36 pairs -> chunks of 7
+    l1, g1 = run()
+    assert abs(l0 - l1) <= 1e-5 * max(1.0, abs(l0))
+    gmax = max(float(np.abs(v).max()) for v in g0.values())
+    zero = ("row_self_attention.layer.k_proj.bias", "column_self_attention.layer.k_proj.bias", "g_attn_k.bias", "s_out.2.bias")
+    for k in g0:
+        if k.endswith(zero):
+            continue
+        assert float(np.abs(g1[k] - g0[k]).max()) <= 2e-3 * max(float(np.abs(g0[k]).max()), 1e-4 * gmax), k
