@@ -92,6 +92,12 @@ def encode(model, onehot, pad):
         raise NotImplementedError("patch_size 1 (the shipped model)")
     model.patch_num = math.ceil(L / model.patch_size)
     pad = None if pad is None else pad.to(dev)
+    # activations the per-step scorer calls of a whole episode would keep (~14 tensors of [B, n, C, D] per step, twice:
+    # decode and merge): beyond a third of the device they run under activation checkpointing too (see decode)
+    import os
+    steps_bytes = 2 * 14 * B * (R * (R + 1) // 2) * L * 64 * 4
+    model._train_ckpt = bool(int(os.environ.get("NNJ_TRAIN_PAIR_CHUNK", "0"))) or \
+        steps_bytes > torch.cuda.get_device_properties(dev).total_memory // 3
     x = _lin(T.Gelu.apply(_lin(x, model.embed[0])), model.embed[2])           # [B,R,C,D]
     x = T.Permute.apply(x, (1, 2, 0, 3))                                       # 'b r c d -> r c b d'
     for layer in model.seq_emb_layers:
@@ -173,9 +179,14 @@ def decode(model, state, pad, info):
     r = torch.arange(n, device=dev, dtype=torch.int64).unsqueeze(0).expand(B, n)
     i_idx = torch.minimum(ip.unsqueeze(1), r).contiguous()                     # sort((i_prev, r))
     j_idx = torch.maximum(ip.unsqueeze(1), r).contiguous()
-    x_i = T.GatherRows.apply(state, i_idx)
-    x_j = T.GatherRows.apply(state, j_idx)
-    new = decode_gg(model, state, x_i, x_j, keep, i_idx, j_idx)               # [B,n]
+    def new_scores(st):
+        return decode_gg(model, st, T.GatherRows.apply(st, i_idx), T.GatherRows.apply(st, j_idx), keep, i_idx, j_idx)
+
+    if getattr(model, "_train_ckpt", False):
+        from torch.utils.checkpoint import checkpoint
+        new = checkpoint(new_scores, state, use_reentrant=False)
+    else:
+        new = new_scores(state)                                                # [B,n]
     table = _cat_last(logits_prev, new)
     idx = torch.as_tensor(score_indices_to_prev).to(dev).to(torch.int64)
     return T.GatherRows.apply(table.unsqueeze(-1), idx).squeeze(-1)           # gather(cat(prev, new), 1, idx)
@@ -227,7 +238,14 @@ def env_step(model, state, ij):
     state = state.contiguous()
     ij = torch.as_tensor(ij).to(dev).to(torch.int64)
     i_idx, j_idx = ij[:, 0:1].contiguous(), ij[:, 1:2].contiguous()
-    new = aggregate(model, state, T.GatherRows.apply(state, i_idx), T.GatherRows.apply(state, j_idx), i_idx, j_idx)
+    def merged(st):
+        return aggregate(model, st, T.GatherRows.apply(st, i_idx), T.GatherRows.apply(st, j_idx), i_idx, j_idx)
+
+    if getattr(model, "_train_ckpt", False):
+        from torch.utils.checkpoint import checkpoint
+        new = checkpoint(merged, state, use_reentrant=False)
+    else:
+        new = merged(state)
     r = torch.arange(n - 1, device=dev, dtype=torch.int64).unsqueeze(0).expand(B, n - 1)
     base = r + (r >= j_idx)                                  # positions of the old rows once j is gone ...
     base = torch.where(r == i_idx, torch.full_like(base, n), base).contiguous()   # ... the merged row (index n) at i
