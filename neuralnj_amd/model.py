@@ -118,7 +118,14 @@ class PhyloATTN(nn.Module):
         129, 164 with eval=False) and back-propagating through them: with gradients enabled the differentiable
         operators of train_model.py run (forward and backward kernels of libnnj_train_hip.so); under no_grad the fused
         inference kernels."""
-        return torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+        want = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+        if want and self.training and not self.__dict__.get("_warned_dropout"):
+            import warnings
+            warnings.warn("PhyloATTN is in train() mode: the reference would apply dropout (p = 0.4) there; the Finetune "
+                          "operators of this package run the eval-mode forward (the mode the reference's Finetune loop is "
+                          "in). Call .eval() to silence this.")
+            self.__dict__["_warned_dropout"] = True
+        return want
 
     def encode_zxr(self, batch_input, batch_seq_mask=None):
         if self._wants_grad():
