@@ -98,7 +98,8 @@ def main():
     # merges: the reference's own Argmax trees of the matching forward fixtures (any valid merge list would do)
     only = sys.argv[1] if len(sys.argv) > 1 else None
     for name, src, layers, pad in (("b2_t8_l128_s0", "synth_b2_t8_l128_s0", 6, 0), ("b2_t6_l48_pad", None, 2, 5),
-                                   ("b1_t20_l256_s1", "synth_b1_t20_l256_s1", 6, 0)):
+                                   ("b1_t20_l256_s1", "synth_b1_t20_l256_s1", 6, 0),
+                                   ("b1_t50_l1024_s0", "synth_b1_t50_l1024_s0", 6, 0)):      # the bench shape (minutes of CPU)
         if only and name != only:
             continue
         if src is not None:

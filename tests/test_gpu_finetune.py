@@ -69,7 +69,7 @@ def test_operators_match_torch():
     _grad_pair(lambda a, b: T.Bmm.apply(a, b, True, 1.0), lambda a, b: a @ b.transpose(1, 2), [R(2, 9, 20000), R(2, 7, 20000)], tol=5e-5)  # long k
 
 
-@pytest.mark.parametrize("name", ["b2_t6_l48_pad", "b2_t8_l128_s0", "b1_t20_l256_s1"])
+@pytest.mark.parametrize("name", ["b2_t6_l48_pad", "b2_t8_l128_s0", "b1_t20_l256_s1", "b1_t50_l1024_s0"])
 def test_finetune_gradients_match_the_reference(name):
     from neuralnj_amd.environment import PhyInferEnv
     from neuralnj_amd.model import PhyloATTN
@@ -103,12 +103,20 @@ def test_finetune_gradients_match_the_reference(name):
     # table alike (the policy and entropy gradients of a table sum to zero): there both sides hold rounding noise,
     # and the check is that ours is noise too (<= 1e-3 of the model's largest gradient: the noise is fp32 rounding of
     # sums of ~1e2..1e4 cancelling terms and moves with the order of summation).
+    # The bench shape (50 x 1024, tables up to |537|, chosen merges with probability near 1) is ill-conditioned in
+    # float32: adv * (onehot - p) turns a 2e-5 relative error of a logit into ~0.5 % of the gradient, and the
+    # reference's own float32 gradients are 4.3e-3 away from the float64 result (tests/golden/gen_grad64.py).  There the
+    # bar is: within 1e-2 of the reference AND within 8e-3 of the float64 gradients (measured: 6.6e-3 and 5.8e-3).
+    p64 = os.path.join(GOLD, f"grad64_{name}.npy")
+    truth = np.load(p64) if os.path.exists(p64) else None
+    tol = 4e-3 if truth is None else 1e-2
     gmax = float(np.abs(ref).max())
     zero = ("row_self_attention.layer.k_proj.bias", "column_self_attention.layer.k_proj.bias", "g_attn_k.bias", "s_out.2.bias")
-    off, worst, bad = 0, 0.0, []
+    off, worst, worst64, bad = 0, 0.0, 0.0, []
     for k, p in agent.state_dict(keep_vars=True).items():
         n = p.numel()
         want_g = ref[off:off + n].reshape(tuple(p.shape))
+        true_g = truth[off:off + n].reshape(tuple(p.shape)) if truth is not None else None
         off += n
         assert p.grad is not None, k
         got_g = p.grad.detach().cpu().numpy()
@@ -120,12 +128,18 @@ def test_finetune_gradients_match_the_reference(name):
         scale = max(float(np.abs(want_g).max()), 1e-7 * gmax)
         err = float(np.abs(got_g - want_g).max()) / scale
         worst = max(worst, err)
-        if err > 4e-3:
+        if err > tol:
             bad.append(f"{k}: {err:.2e} (|g| max {np.abs(want_g).max():.3e})")
+        if true_g is not None:
+            e64 = float(np.abs(got_g - true_g).max()) / max(float(np.abs(true_g).max()), 1e-7 * gmax)
+            worst64 = max(worst64, e64)
+            if e64 > 8e-3:
+                bad.append(f"{k}: {e64:.2e} from the float64 gradient")
     assert off == ref.size
     assert not bad, "gradients differ from the reference's: " + "; ".join(bad[:12])
     print(f"{name}: loss {float(loss.detach()):.6f} (reference {float(z['loss']):.6f}), worst per-tensor gradient error "
-          f"{worst:.2e} of the tensor's own scale (largest gradient of the model {gmax:.3e})")
+          f"{worst:.2e} of the tensor's own scale (largest gradient of the model {gmax:.3e})"
+          + (f"; from the float64 gradients {worst64:.2e}" if truth is not None else ""))
 
 
 def test_finetune_inference_file_to_tree(tmp_path):
