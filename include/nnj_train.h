@@ -76,6 +76,16 @@ int nnjt_axpby(float a, const float* x, float b, const float* y, float* out, int
 /* out[r, :] = x[r, :] * s[r]  -- row scaling (zeroing q at padded sites, axial_attention.py:78-82; masked site sums). */
 int nnjt_rowscale(const float* x, const float* s, float* out, int64_t rows, int32_t cols, void* stream);
 
+/* nn.Dropout(p) in training mode (reference msa_modules.py:104-119 on every sublayer's output, :141-149 after the
+ * feed-forward GELU, axial_attention.py:56,136,233 on the attention probabilities; p = 0.4, model.py:23):
+ *   keep[i] = 1 with probability 1 - p, y[i] = x[i] * keep[i] / (1 - p);  backward dx = dy * keep / (1 - p).
+ * The draw of element i is a pure function of (seed, offset + i) -- a counter-based generator, no device state: the
+ * caller advances `offset` by n per call.  The stream of torch's own generator cannot be reproduced, so parity with the
+ * reference in train() mode is distributional; given the same masks the arithmetic is the reference's. */
+int nnjt_dropout_fwd(const float* x, float* y, uint8_t* keep, int64_t n, float p, uint64_t seed, uint64_t offset,
+                     void* stream);
+int nnjt_dropout_bwd(const float* dy, const uint8_t* keep, float* dx, int64_t n, float p, void* stream);
+
 /* x[r, c] = value where sel[r_map(r), c] != 0: the key-padding fill of the attention logits
  * (axial_attention.py:99-103, 220-224): x is [outer, inner, cols], sel is [outer?, cols] picked by
  * sel_row = (r / inner) % sel_rows.  The backward of masked_fill zeroes the gradient there: call with value = 0. */

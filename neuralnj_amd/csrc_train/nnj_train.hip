@@ -246,6 +246,29 @@ __global__ void k_rowscale(const float* __restrict__ x, const float* __restrict_
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) out[i] = x[i] * s[i / cols];
 }
+// nn.Dropout in training mode.  The keep decision of element i is a pure function of (seed, offset + i): a SplitMix64
+// finaliser of the counter, its top 24 bits against p -- no generator state on the device, any launch shape gives the
+// same mask.  y = x * keep / (1 - p); the byte mask is what the backward needs.
+__device__ __forceinline__ uint32_t mix24(uint64_t seed, uint64_t ctr) {
+  uint64_t z = seed + (ctr + 1) * 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z ^= z >> 31;
+  return (uint32_t)(z >> 40);
+}
+__global__ void k_dropout_fwd(const float* __restrict__ x, float* __restrict__ y, uint8_t* __restrict__ keep, int64_t n,
+                              uint32_t thresh, float scale, uint64_t seed, uint64_t offset) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const bool k = mix24(seed, offset + (uint64_t)i) >= thresh;
+  keep[i] = k ? 1 : 0;
+  y[i] = k ? x[i] * scale : 0.f;
+}
+__global__ void k_dropout_bwd(const float* __restrict__ dy, const uint8_t* __restrict__ keep, float* __restrict__ dx,
+                              int64_t n, float scale) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dx[i] = keep[i] ? dy[i] * scale : 0.f;
+}
 __global__ void k_fill_where(float* x, const uint8_t* __restrict__ sel, float value, int64_t n, int inner, int sel_rows,
                              int cols) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -321,7 +344,7 @@ __global__ void k_permute5(const float* in, float* out, Perm5 p, int64_t n, int 
 }  // namespace
 
 extern "C" {
-int nnjt_abi_version(void) { return 1; }
+int nnjt_abi_version(void) { return 2; }
 const char* nnjt_last_error(void) { return g_err; }
 
 int nnjt_gemm_run(const nnjt_gemm* g, void* stream) {
@@ -412,6 +435,26 @@ int nnjt_axpby(float a, const float* x, float b, const float* y, float* out, int
 int nnjt_rowscale(const float* x, const float* s, float* out, int64_t rows, int32_t cols, void* stream) {
   const int64_t n = rows * cols;
   hipLaunchKernelGGL(k_rowscale, dim3(blocks_for(n, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), x, s, out, n, cols);
+  CHK_LAUNCH();
+  return 0;
+}
+int nnjt_dropout_fwd(const float* x, float* y, uint8_t* keep, int64_t n, float p, uint64_t seed, uint64_t offset,
+                     void* stream) {
+  if (!x || !y || !keep) return fail(-1, "nnjt_dropout_fwd: null");
+  if (!(p >= 0.f && p < 1.f)) return fail(-1, "nnjt_dropout_fwd: p = %g outside [0, 1)", (double)p);
+  if (n <= 0) return 0;
+  const uint32_t thresh = (uint32_t)((double)p * 16777216.0);            // drop when the 24-bit draw is below p * 2^24
+  hipLaunchKernelGGL(k_dropout_fwd, dim3(blocks_for(n, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), x, y, keep, n,
+                     thresh, 1.0f / (1.0f - p), seed, offset);
+  CHK_LAUNCH();
+  return 0;
+}
+int nnjt_dropout_bwd(const float* dy, const uint8_t* keep, float* dx, int64_t n, float p, void* stream) {
+  if (!dy || !dx || !keep) return fail(-1, "nnjt_dropout_bwd: null");
+  if (!(p >= 0.f && p < 1.f)) return fail(-1, "nnjt_dropout_bwd: p = %g outside [0, 1)", (double)p);
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(k_dropout_bwd, dim3(blocks_for(n, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), dy, keep, dx, n,
+                     1.0f / (1.0f - p));
   CHK_LAUNCH();
   return 0;
 }

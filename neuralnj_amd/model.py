@@ -60,7 +60,7 @@ class PhyloATTN(nn.Module):
         self.embed_dim = d = m.embed_dim
         self.num_enc_heads = m.num_enc_heads
         self.num_enc_layers = m.num_enc_layers
-        self.dropout = 0.4                      # identity in eval; kept for parity of the attribute
+        self.dropout = 0.4                      # model.py:23; applied in train() mode with gradients (train_model.encode)
         self.seq_emb_layers = nn.ModuleList([_AxialLayerParams(d, 4 * d) for _ in range(m.num_enc_layers)])
         self.embed = nn.Sequential(nn.Linear(m.vocab_size * m.patch_size, d), nn.GELU(), nn.Linear(d, d))
         self.h_linear_last = nn.Linear(d, d)
@@ -116,16 +116,11 @@ class PhyloATTN(nn.Module):
     def _wants_grad(self):
         """The reference fine-tunes by calling these same methods outside torch.no_grad() (finetune_rl_search.py:113,
         129, 164 with eval=False) and back-propagating through them: with gradients enabled the differentiable
-        operators of train_model.py run (forward and backward kernels of libnnj_train_hip.so); under no_grad the fused
-        inference kernels."""
-        want = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
-        if want and self.training and not self.__dict__.get("_warned_dropout"):
-            import warnings
-            warnings.warn("PhyloATTN is in train() mode: the reference would apply dropout (p = 0.4) there; the Finetune "
-                          "operators of this package run the eval-mode forward (the mode the reference's Finetune loop is "
-                          "in). Call .eval() to silence this.")
-            self.__dict__["_warned_dropout"] = True
-        return want
+        operators of train_model.py run (forward and backward kernels of libnnj_train_hip.so) -- with dropout when the
+        module is in train() mode (train.py:435), without in eval() (the Finetune loop); under no_grad the fused
+        inference kernels, which are the eval-mode forward (every no_grad call site of the reference calls
+        agent.eval() first: finetune_rl_search.py:110, train.py:91,100)."""
+        return torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
 
     def encode_zxr(self, batch_input, batch_seq_mask=None):
         if self._wants_grad():

@@ -4,7 +4,11 @@ gfx950 forward and backward kernels; torch.autograd keeps the graph).  Used by m
 enabled; inference (torch.no_grad) runs the fused kernels of libnnj_hip.so instead.
 
 Dropout: the reference's Finetune loop runs the policy in eval mode -- its first baseline rollout calls agent.eval()
-(finetune_rl_search.py:110,119) and nothing switches back -- so dropout is the identity here too.
+(finetune_rl_search.py:110,119) and nothing switches back -- so dropout is the identity there.  In train() mode (the
+reference's train.py:435) the encoder applies nn.Dropout(model.dropout = 0.4) where the reference does: on the attention
+probabilities (axial_attention.py:56,136,233), after the feed-forward GELU (msa_modules.py:149) and on every sublayer's
+output before the residual add (msa_modules.py:119) -- train_ops.Dropout, a counter-based generator seeded by
+torch.initial_seed().  The pair scorer has no dropout (model.py).
 In grad mode the reference does not chunk the attention (axial_attention.py:127,243: `and not torch.is_grad_enabled()`),
 so padded keys are filled with -10000 once.
 """
@@ -30,7 +34,7 @@ def _f32(t, dev):
 
 
 # ------------------------------------------------------------------------------------------------ encoder
-def row_attention(att, x, pad):
+def row_attention(att, x, pad, p_drop=0.0):
     """RowSelfAttention.forward, tied over rows (axial_attention.py:66-138).  x [R,C,B,D]; pad bool [B,C] or None."""
     R, C, B, D = x.shape
     H = 8
@@ -53,13 +57,13 @@ def row_attention(att, x, pad):
     if pad is not None:
         sel = pad.to(torch.uint8).contiguous()                                # key j of alignment b is padding
         logits = T.FillWhere.apply(logits, sel, -10000.0, H * C, B)
-    probs = T.Softmax.apply(logits, None)
+    probs = T.dropout(T.Softmax.apply(logits, None), p_drop)                  # axial_attention.py:136
     ctx = T.Bmm.apply(probs, vp, False, 1.0)                                  # [B*H, C, R*dh]
     ctx = T.Permute.apply(ctx.view(B, H, C, R, dh), (3, 2, 0, 1, 4)).view(R, C, B, D)
     return _lin(ctx, att.out_proj)
 
 
-def column_attention(att, x, pad):
+def column_attention(att, x, pad, p_drop=0.0):
     """ColumnSelfAttention.compute_attention_update (axial_attention.py:190-240).  x [R,C,B,D]."""
     R, C, B, D = x.shape
     H = 8
@@ -77,7 +81,7 @@ def column_attention(att, x, pad):
         # a padded column: every key gets -10000 (mask [B,R,C] is the site mask repeated over the rows)
         sel = pad.t().to(torch.uint8).unsqueeze(-1).expand(C, B, R).contiguous().view(C * B, R)
         logits = T.FillWhere.apply(logits, sel, -10000.0, H * R, C * B)
-    probs = T.Softmax.apply(logits, None)
+    probs = T.dropout(T.Softmax.apply(logits, None), p_drop)                   # axial_attention.py:233
     ctx = T.Bmm.apply(probs, vp, False, 1.0)                                   # [C*B*H, R, dh]
     ctx = T.Permute.apply(ctx.view(C, B, H, R, dh), (3, 0, 1, 2, 4)).view(R, C, B, D)
     return _lin(ctx, att.out_proj)
@@ -100,14 +104,16 @@ def encode(model, onehot, pad):
         steps_bytes > torch.cuda.get_device_properties(dev).total_memory // 3
     x = _lin(T.Gelu.apply(_lin(x, model.embed[0])), model.embed[2])           # [B,R,C,D]
     x = T.Permute.apply(x, (1, 2, 0, 3))                                       # 'b r c d -> r c b d'
+    pd = float(model.dropout) if model.training else 0.0                        # nn.Dropout: identity in eval mode
     for layer in model.seq_emb_layers:
         blk = layer.row_self_attention
-        x = T.add(x, row_attention(blk.layer, _ln(x, blk.layer_norm), pad))
+        x = T.add(x, T.dropout(row_attention(blk.layer, _ln(x, blk.layer_norm), pad, pd), pd))
         blk = layer.column_self_attention
-        x = T.add(x, column_attention(blk.layer, _ln(x, blk.layer_norm), pad))
+        x = T.add(x, T.dropout(column_attention(blk.layer, _ln(x, blk.layer_norm), pad, pd), pd))
         blk = layer.feed_forward_layer
         y = _ln(x, blk.layer_norm)
-        x = T.add(x, _lin(T.Gelu.apply(_lin(y, blk.layer.fc1)), blk.layer.fc2))
+        y = T.dropout(T.Gelu.apply(_lin(y, blk.layer.fc1)), pd)                # msa_modules.py:148-149
+        x = T.add(x, T.dropout(_lin(y, blk.layer.fc2), pd))                    # msa_modules.py:119
     return T.Permute.apply(x, (2, 0, 1, 3))                                    # 'r c b d -> b r c d'
 
 

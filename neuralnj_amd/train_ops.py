@@ -46,6 +46,8 @@ _SIGS = {
     "nnjt_softmax_bwd": ([_vp, _vp, _vp, _i64, _i32, _vp], C.c_int),
     "nnjt_axpby": ([C.c_float, _vp, C.c_float, _vp, _vp, _i64, _vp], C.c_int),
     "nnjt_rowscale": ([_vp, _vp, _vp, _i64, _i32, _vp], C.c_int),
+    "nnjt_dropout_fwd": ([_vp, _vp, _vp, _i64, C.c_float, C.c_uint64, C.c_uint64, _vp], C.c_int),
+    "nnjt_dropout_bwd": ([_vp, _vp, _vp, _i64, C.c_float, _vp], C.c_int),
     "nnjt_fill_where": ([_vp, _vp, C.c_float, _i64, _i32, _i32, _i32, _vp], C.c_int),
     "nnjt_gather_rows": ([_vp, _vp, _vp, _i32, _i32, _i32, _i64, _vp], C.c_int),
     "nnjt_scatter_rows_add": ([_vp, _vp, _vp, _i32, _i32, _i32, _i64, _vp], C.c_int),
@@ -214,6 +216,61 @@ class Gelu(torch.autograd.Function):
         dx = torch.empty_like(x)
         _chk(load_library().nnjt_gelu_bwd(_p(dy), _p(x), _p(dx), x.numel(), _st(x)))
         return dx
+
+
+class _DropoutState:
+    """Counter of the dropout generator: the seed follows torch.initial_seed() (torch.manual_seed sets it), the offset
+    restarts when the seed changes and advances by the element count of every call.  `tape`, when a list, receives the
+    keep mask of every call in order; `replay`, when a list, supplies them instead of the generator (uint8 device
+    tensors, consumed front to back) -- a recorded run, or the masks of a reference run, reproduced exactly."""
+    seed = None
+    offset = 0
+    tape = None
+    replay = None
+
+    @classmethod
+    def take(cls, n):
+        seed = torch.initial_seed() & 0xFFFFFFFFFFFFFFFF
+        if seed != cls.seed:
+            cls.seed, cls.offset = seed, 0
+        off = cls.offset
+        cls.offset += n
+        return seed, off
+
+
+class Dropout(torch.autograd.Function):
+    """nn.Dropout(p) in training mode (reference msa_modules.py:119,149; axial_attention.py:56,136,233)."""
+
+    @staticmethod
+    def forward(ctx, x, p):
+        _need(x)
+        y = torch.empty_like(x)
+        if _DropoutState.replay is not None:
+            keep = _DropoutState.replay.pop(0)
+            if keep.dtype != torch.uint8 or keep.numel() != x.numel() or keep.device != x.device or not keep.is_contiguous():
+                raise RuntimeError("dropout replay: the next recorded mask does not fit this call")
+            _chk(load_library().nnjt_dropout_bwd(_p(x), _p(keep), _p(y), x.numel(), float(p), _st(x)))   # x * keep / (1 - p)
+        else:
+            keep = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
+            seed, off = _DropoutState.take(x.numel())
+            _chk(load_library().nnjt_dropout_fwd(_p(x), _p(y), _p(keep), x.numel(), float(p), seed, off, _st(x)))
+        if _DropoutState.tape is not None:
+            _DropoutState.tape.append(keep)
+        ctx.save_for_backward(keep)
+        ctx.p = float(p)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (keep,) = ctx.saved_tensors
+        dy = _need(dy.contiguous())
+        dx = torch.empty_like(dy)
+        _chk(load_library().nnjt_dropout_bwd(_p(dy), _p(keep), _p(dx), dy.numel(), ctx.p, _st(dy)))
+        return dx, None
+
+
+def dropout(x, p):
+    return Dropout.apply(x, p) if p > 0.0 else x
 
 
 class Gate(torch.autograd.Function):

@@ -24,7 +24,16 @@ def _ln(x, sd, name):
     return F.layer_norm(x, (x.shape[-1],), sd[name + ".weight"], sd[name + ".bias"], 1e-5)    # msa_modules.py:107
 
 
-def row_attention(x, sd, pre, pad):
+def _keep(x, drop, kind):
+    """nn.Dropout in train() mode with a GIVEN mask: drop(kind, shape) returns (keep mask, p) -- tests hand the masks the
+    device path drew -- or None in eval mode."""
+    if drop is None:
+        return x
+    m, p = drop(kind, tuple(x.shape))
+    return x * m.to(x.dtype) / (1.0 - p)
+
+
+def row_attention(x, sd, pre, pad, drop=None):
     """axial_attention.py:66-138 (grad mode: no chunking).  x [R,C,B,D]; pad bool [B,C]."""
     R, C, B, D = x.shape
     H, dh = 8, D // 8
@@ -36,12 +45,12 @@ def row_attention(x, sd, pre, pad):
     w = torch.einsum("rinhd,rjnhd->hnij", q, k)                                                   # :97
     if pad is not None:
         w = w.masked_fill(pad[None, :, None, :], -10000.0)                                        # :99-103
-    p = w.softmax(-1)
+    p = _keep(w.softmax(-1), drop, "row_probs")                                                   # :135-136
     ctx = torch.einsum("hnij,rjnhd->rinhd", p, v).reshape(R, C, B, D)                             # :114
     return _lin(ctx, sd, pre + ".out_proj")
 
 
-def column_attention(x, sd, pre, pad):
+def column_attention(x, sd, pre, pad, drop=None):
     """axial_attention.py:190-240."""
     R, C, B, D = x.shape
     H, dh = 8, D // 8
@@ -51,21 +60,24 @@ def column_attention(x, sd, pre, pad):
     w = torch.einsum("icnhd,jcnhd->hcnij", q, k)                                                  # :216
     if pad is not None:
         w = w.masked_fill(pad.t()[None, :, :, None, None], -10000.0)                              # :220-224
-    p = w.softmax(-1)
+    p = _keep(w.softmax(-1), drop, "col_probs")                                                   # :232-233
     ctx = torch.einsum("hcnij,jcnhd->icnhd", p, v).reshape(R, C, B, D)                            # :234
     return _lin(ctx, sd, pre + ".out_proj")
 
 
-def encode(sd, onehot, pad, layers):
-    """model.py:67-88 + msa_modules.py:62-125 (dropout = identity: eval mode)."""
+def encode(sd, onehot, pad, layers, drop=None):
+    """model.py:67-88 + msa_modules.py:62-125.  drop None: eval mode (dropout = identity); else see _keep."""
     x = _lin(F.gelu(_lin(onehot, sd, "embed.0")), sd, "embed.2")                                  # model.py:39-43
     x = x.permute(1, 2, 0, 3)
     for l in range(layers):
         pre = f"seq_emb_layers.{l}."
-        x = x + row_attention(_ln(x, sd, pre + "row_self_attention.layer_norm"), sd, pre + "row_self_attention.layer", pad)
-        x = x + column_attention(_ln(x, sd, pre + "column_self_attention.layer_norm"), sd, pre + "column_self_attention.layer", pad)
+        y = row_attention(_ln(x, sd, pre + "row_self_attention.layer_norm"), sd, pre + "row_self_attention.layer", pad, drop)
+        x = x + _keep(y, drop, "out")                                                              # msa_modules.py:119-120
+        y = column_attention(_ln(x, sd, pre + "column_self_attention.layer_norm"), sd, pre + "column_self_attention.layer", pad, drop)
+        x = x + _keep(y, drop, "out")
         y = _ln(x, sd, pre + "feed_forward_layer.layer_norm")
-        x = x + _lin(F.gelu(_lin(y, sd, pre + "feed_forward_layer.layer.fc1")), sd, pre + "feed_forward_layer.layer.fc2")
+        y = _keep(F.gelu(_lin(y, sd, pre + "feed_forward_layer.layer.fc1")), drop, "act")          # msa_modules.py:148-149
+        x = x + _keep(_lin(y, sd, pre + "feed_forward_layer.layer.fc2"), drop, "out")
     return x.permute(2, 0, 1, 3)
 
 
@@ -98,14 +110,15 @@ def _rows(state, idx):
     return torch.gather(state, 1, idx[:, :, None, None].expand(-1, -1, state.shape[2], state.shape[3]))
 
 
-def reinforce_loss(sd, onehot, pad, merges, tree_scores, baseline, temperature, strength, layers, dtype=torch.float64):
+def reinforce_loss(sd, onehot, pad, merges, tree_scores, baseline, temperature, strength, layers, dtype=torch.float64,
+                   drop=None):
     """The loop of reinforce_rollout with eval=False (finetune_rl_search.py:78-189) on forced actions and the loss of
     RL_finetuning (:292-307).  sd: {name: tensor requiring grad}.  Returns (loss, tables)."""
     from neuralnj_amd import utils
     onehot = torch.as_tensor(onehot).to(dtype)
     pad = torch.as_tensor(pad).bool()
     B, T, L, _ = onehot.shape
-    state = encode(sd, onehot, pad, layers)
+    state = encode(sd, onehot, pad, layers, drop)
     keep = (~pad).to(dtype)
     merges = np.asarray(merges)
     table, tables, selected, ents = None, [], [], []

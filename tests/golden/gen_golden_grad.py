@@ -29,8 +29,9 @@ import gen_golden as gg  # noqa: E402
 
 
 def run_case(name, codes, mask, merges, wseed, style, layers, ref, tree_scores, baseline=0.25, temperature=1.0,
-             strength=0.01):
+             strength=0.01, train=False):
     import torch
+    import torch.nn.functional as F
     from neuralnj_amd import synth, weights
 
     frs, utils_mod, PGPI, PhyInferEnv = ref
@@ -39,6 +40,21 @@ def run_case(name, codes, mask, merges, wseed, style, layers, ref, tree_scores, 
     st = weights.seeded_state(cfgs, wseed, style)
     agent.load_state_dict({k: torch.from_numpy(v) for k, v in st.items()}, strict=True)
     agent.eval()                                   # the mode the reference's Finetune loop is in (see train_model.py)
+    masks, real_dropout = [], F.dropout
+    if train:
+        # train() mode (reference train.py:435): nn.Dropout draws from torch's generator, whose stream is not part of
+        # the contract -- so the masks are drawn HERE (seeded) and recorded, by standing in for the one function
+        # nn.Dropout.forward calls; the reference's modules decide where, in which order and with which p it is called.
+        agent.train()
+        gen = torch.Generator().manual_seed(20240)
+
+        def recorded(x, p=0.5, training=True, inplace=False):
+            if not training or p == 0.0:
+                return x
+            m = torch.rand(x.shape, generator=gen) >= p
+            masks.append((m.numpy().reshape(-1).copy(), float(p)))
+            return x * m.to(x.dtype) / (1.0 - p)
+        F.dropout = recorded
     B, T, L = codes.shape
     onehot = torch.from_numpy(synth.codes_to_onehot(codes))
     seqs = [synth.codes_to_seqs(codes[b]) for b in range(B)]
@@ -76,15 +92,21 @@ def run_case(name, codes, mask, merges, wseed, style, layers, ref, tree_scores, 
     loss = policy_loss + entropy_reg * strength
     agent.zero_grad()
     loss.backward()
+    F.dropout = real_dropout
     grads = np.concatenate([p.grad.detach().numpy().reshape(-1) for p in agent.state_dict(keep_vars=True).values()])
     out = os.path.join(HERE, f"grad_{name}.npz")
+    extra = {}
+    if train:
+        assert masks and len({p for _, p in masks}) == 1
+        extra = dict(drop_bits=np.packbits(np.concatenate([m for m, _ in masks])),
+                     drop_sizes=np.array([m.size for m, _ in masks], dtype=np.int64), drop_p=np.float32(masks[0][1]))
     np.savez_compressed(out, codes=codes, mask=mask, merges=merges, tree_scores=tree_scores.astype(np.float32),
                         baseline=np.float32(baseline), temperature=np.float32(temperature), strength=np.float32(strength),
                         wseed=np.int64(wseed), style=np.array(style), layers=np.int64(layers), loss=np.float32(loss.item()),
                         policy_loss=np.float32(policy_loss.item()), entropy_reg=np.float32(entropy_reg.item()),
                         grads=grads.astype(np.float32), enc=enc[:, :, ::8].astype(np.float32),
                         tables=np.concatenate([t.reshape(B, -1) for t in tables], axis=1).astype(np.float32),
-                        selected=selected.detach().numpy().astype(np.float32))
+                        selected=selected.detach().numpy().astype(np.float32), **extra)
     print(f"{name}: loss {loss.item():.6f}  |grad| max {np.abs(grads).max():.3e}  {grads.size} values -> {out}")
 
 
@@ -99,7 +121,8 @@ def main():
     only = sys.argv[1] if len(sys.argv) > 1 else None
     for name, src, layers, pad in (("b2_t8_l128_s0", "synth_b2_t8_l128_s0", 6, 0), ("b2_t6_l48_pad", None, 2, 5),
                                    ("b1_t20_l256_s1", "synth_b1_t20_l256_s1", 6, 0),
-                                   ("b1_t50_l1024_s0", "synth_b1_t50_l1024_s0", 6, 0)):      # the bench shape (minutes of CPU)
+                                   ("b1_t50_l1024_s0", "synth_b1_t50_l1024_s0", 6, 0),       # the bench shape (minutes of CPU)
+                                   ("train_b2_t6_l48_pad", None, 2, 5)):                     # train() mode: dropout 0.4
         if only and name != only:
             continue
         if src is not None:
@@ -118,7 +141,7 @@ def main():
                     merges[b, s] = (i, j)
             wseed, style = 17, "plain"
         scores = np.array([0.8, -0.4], dtype=np.float32)[:codes.shape[0]]
-        run_case(name, codes, mask, merges, wseed, style, layers, ref, scores)
+        run_case(name, codes, mask, merges, wseed, style, layers, ref, scores, train=name.startswith("train_"))
 
 
 if __name__ == "__main__":

@@ -120,3 +120,27 @@ def free_run_verdict(free_merges, free_tables, ref_merges, ref_tables, ref_newic
                             f"separates the two picks by {gap64:.3e} > fp32 noise {noise:.3e}")
     assert row["pick_is_ref_runner_up"], f"step {s}: the pick is not the reference's runner-up"
     return row
+
+
+def recorded_dropout(z):
+    """The dropout masks stored with a train()-mode gradient fixture (tests/golden/gen_golden_grad.py: drop_bits /
+    drop_sizes / drop_p, in the reference's call order), as the callable oracle/grad_oracle.py takes:
+    drop(kind, shape) -> (keep mask, p).  None for an eval-mode fixture."""
+    import numpy as np
+    import torch
+    if "drop_bits" not in z:
+        return None
+    sizes = [int(v) for v in z["drop_sizes"]]
+    bits = np.unpackbits(z["drop_bits"])[:sum(sizes)].astype(bool)
+    p, pos = float(z["drop_p"]), [0, 0]
+
+    def drop(kind, shape):
+        n = int(np.prod(shape))
+        assert pos[0] < len(sizes) and sizes[pos[0]] == n, (kind, shape, pos[0])
+        m = torch.from_numpy(bits[pos[1]:pos[1] + n].reshape(shape))
+        pos[0] += 1
+        pos[1] += n
+        return m, p
+    drop.calls = lambda: pos[0]
+    drop.expected = len(sizes)
+    return drop

@@ -371,3 +371,172 @@ def test_chunked_all_pairs_step_gives_the_same_gradients(monkeypatch):
         if k.endswith(zero):
             continue
         assert float(np.abs(g1[k] - g0[k]).max()) <= 2e-3 * max(float(np.abs(g0[k]).max()), 1e-4 * gmax), k
+
+
+# ------------------------------------------------------------------------------------------------ train() mode: dropout
+def test_dropout_operator():
+    """nnjt_dropout_fwd / _bwd: keep rate, scaling, reproducibility by (seed, offset), no serial correlation."""
+    import neuralnj_amd.train_ops as T
+    d = _dev()
+    n, p = 1 << 22, 0.4
+    x = torch.randn(n, device=d).requires_grad_(True)
+    torch.manual_seed(77)
+    T._DropoutState.seed, T._DropoutState.tape = None, []
+    y = T.Dropout.apply(x, p)
+    keep = T._DropoutState.tape[0].bool()
+    rate = float(keep.float().mean())
+    sigma = (p * (1 - p) / n) ** 0.5
+    assert abs(rate - (1 - p)) < 5 * sigma, rate
+    both = float((keep[1:] & keep[:-1]).float().mean())                       # neighbours are independent draws
+    assert abs(both - (1 - p) ** 2) < 6 * ((1 - p) ** 2 * (1 - (1 - p) ** 2) / n) ** 0.5 + 1e-4, both
+    byte = keep.view(-1, 8).float().sum(1)                                    # and so are runs of 8: binomial variance
+    assert abs(float(byte.var()) - 8 * p * (1 - p)) < 0.02, float(byte.var())
+    assert torch.equal(y.detach(), torch.where(keep, x.detach() * (1.0 / (1.0 - p)), torch.zeros_like(x.detach())))
+    dy = torch.randn(n, device=d)
+    y.backward(dy)
+    assert torch.equal(x.grad, torch.where(keep, dy * (1.0 / (1.0 - p)), torch.zeros_like(dy)))
+    y2 = T.Dropout.apply(x.detach(), p)                                       # the counter moved on: another mask
+    assert not torch.equal(T._DropoutState.tape[1], T._DropoutState.tape[0])
+    torch.manual_seed(77)                                                     # same seed, counter restarts: same mask
+    T._DropoutState.seed = None
+    y3 = T.Dropout.apply(x.detach(), p)
+    assert torch.equal(T._DropoutState.tape[2], T._DropoutState.tape[0]) and torch.equal(y3, y.detach())
+    torch.manual_seed(78)
+    T.Dropout.apply(x.detach(), p)
+    assert not torch.equal(T._DropoutState.tape[3], T._DropoutState.tape[0])
+    T._DropoutState.tape = None
+    assert T.dropout(x, 0.0) is x
+    del y2
+
+
+def _train_mode_case(z):
+    from neuralnj_amd.environment import PhyInferEnv
+    from neuralnj_amd.model import PhyloATTN
+    cfgs = utils.shipped_config()
+    cfgs.model.num_enc_layers = int(z["layers"])
+    agent = PhyloATTN(cfgs)
+    sd = weights.seeded_state(cfgs, int(z["wseed"]), str(z["style"]))
+    agent.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    agent = agent.to(_dev())
+    codes, mask = z["codes"], z["mask"]
+    B, T_, L = codes.shape
+    batch = {"data": torch.from_numpy(synth.codes_to_onehot(codes)), "seqs": [synth.codes_to_seqs(codes[b]) for b in range(B)],
+             "seq_keys": [[f"taxon{i + 1}" for i in range(T_)] for _ in range(B)],
+             "seq_weights": torch.from_numpy((~mask).astype(np.float32))}
+    return cfgs, agent, batch, PhyInferEnv(cfgs, _dev()), sd
+
+
+def _check_grads(agent, ref, tol, what):
+    gmax = float(np.abs(ref).max())
+    zero = ("row_self_attention.layer.k_proj.bias", "column_self_attention.layer.k_proj.bias", "g_attn_k.bias", "s_out.2.bias")
+    off, worst, bad = 0, 0.0, []
+    for k, p in agent.state_dict(keep_vars=True).items():
+        n = p.numel()
+        want_g = ref[off:off + n].reshape(tuple(p.shape))
+        off += n
+        got_g = p.grad.detach().cpu().numpy()
+        if k.endswith(zero):
+            if float(np.abs(got_g).max()) > 1e-3 * gmax:
+                bad.append(f"{k}: should vanish, max {np.abs(got_g).max():.2e}")
+            continue
+        err = float(np.abs(got_g - want_g).max()) / max(float(np.abs(want_g).max()), 1e-7 * gmax)
+        worst = max(worst, err)
+        if err > tol:
+            bad.append(f"{k}: {err:.2e}")
+    assert off == ref.size
+    assert not bad, f"gradients differ from {what}: " + "; ".join(bad[:12])
+    return worst
+
+
+def test_train_mode_gradients_match_the_reference_given_its_masks():
+    """train() mode (reference train.py:435: dropout 0.4 on attention probabilities, activations and sublayer
+    outputs).  The fixture holds the reference's gradients together with the masks its nn.Dropout modules were handed;
+    replayed here in the reference's call order (re-laid out: its probabilities are [H,B,..], ours [B,H,..])."""
+    import neuralnj_amd.train_ops as T
+    from neuralnj_amd.rollout import reinforce_loss
+    z = np.load(os.path.join(GOLD, "grad_train_b2_t6_l48_pad.npz"), allow_pickle=True)
+    cfgs, agent, batch, env, _ = _train_mode_case(z)
+    agent.train()
+    B, R, L = z["codes"].shape
+    H = 8
+    bits = np.unpackbits(z["drop_bits"])
+    masks, pos = [], 0
+    for i, n in enumerate(int(v) for v in z["drop_sizes"]):
+        m = torch.from_numpy(bits[pos:pos + n].copy())
+        pos += n
+        kind = i % 6                                          # per layer: row probs, out, column probs, out, act, out
+        if kind == 0:
+            m = m.view(H, B, L, L).permute(1, 0, 2, 3)
+        elif kind == 2:
+            m = m.view(H, L, B, R, R).permute(1, 2, 0, 3, 4)
+        masks.append(m.contiguous().reshape(-1).to(torch.uint8).to(_dev()))
+    assert abs(float(z["drop_p"]) - agent.dropout) < 1e-7
+    T._DropoutState.replay = masks
+    try:
+        loss, tables = reinforce_loss(batch, agent, env, z["merges"], z["tree_scores"], float(z["baseline"]),
+                                      float(z["temperature"]), float(z["strength"]))
+    finally:
+        T._DropoutState.replay = None
+    assert not masks                                           # every recorded mask was consumed, in order
+    got_tables = torch.cat([t.detach().reshape(B, -1) for t in tables], dim=1).cpu().numpy()
+    assert np.abs(got_tables - z["tables"]).max() <= 1e-4 * np.abs(z["tables"]).max()
+    assert abs(float(loss.detach()) - float(z["loss"])) <= 2e-4 * max(1.0, abs(float(z["loss"])))
+    agent.zero_grad()
+    loss.backward()
+    worst = _check_grads(agent, z["grads"], 4e-3, "the reference's (train mode, same masks)")
+    print(f"train mode: loss {float(loss.detach()):.6f} (reference {float(z['loss']):.6f}), worst per-tensor gradient error {worst:.2e}")
+
+
+def test_train_mode_own_masks_match_the_fp64_oracle_and_eval_mode_is_untouched():
+    """The masks of the counter-based generator, recorded and replayed through the float64 oracle; eval() and p = 0 give
+    the deterministic forward; two seeds give two losses, one seed the same loss."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(GOLD), "..", "oracle"))
+    import grad_oracle
+    import neuralnj_amd.train_ops as T
+    from neuralnj_amd.rollout import reinforce_loss
+    z = np.load(os.path.join(GOLD, "grad_train_b2_t6_l48_pad.npz"), allow_pickle=True)
+    cfgs, agent, batch, env, sd = _train_mode_case(z)
+    B, R, L = z["codes"].shape
+    H = 8
+    args = (z["merges"], z["tree_scores"], float(z["baseline"]), float(z["temperature"]), float(z["strength"]))
+
+    def run(seed):
+        torch.manual_seed(seed)
+        T._DropoutState.seed = None
+        return reinforce_loss(batch, agent, env, *args)[0]
+    agent.train()
+    T._DropoutState.tape = []
+    loss = run(5)
+    tape, T._DropoutState.tape = T._DropoutState.tape, None
+    assert len(tape) == 6 * int(z["layers"])
+    agent.zero_grad()
+    loss.backward()
+    it = iter(tape)
+
+    def drop(kind, shape):
+        m = next(it).cpu().bool()
+        if kind == "row_probs":
+            m = m.view(B, H, L, L).permute(1, 0, 2, 3)
+        elif kind == "col_probs":
+            m = m.view(L, B, H, R, R).permute(2, 0, 1, 3, 4)
+        return m.reshape(shape), agent.dropout
+    sd64 = {k: torch.from_numpy(v).double().requires_grad_(True) for k, v in sd.items()}
+    want, _ = grad_oracle.reinforce_loss(sd64, synth.codes_to_onehot(z["codes"]), z["mask"], *args, int(z["layers"]),
+                                         torch.float64, drop=drop)
+    want.backward()
+    assert abs(float(loss.detach()) - float(want.detach())) <= 2e-4 * max(1.0, abs(float(want.detach())))
+    ref = np.concatenate([p.grad.numpy().reshape(-1) for p in sd64.values()]).astype(np.float32)
+    worst = _check_grads(agent, ref, 4e-3, "the float64 oracle's (train mode, our masks)")
+    l5, l6 = float(run(5).detach()), float(run(6).detach())
+    assert l5 == float(loss.detach()) and l6 != l5
+    agent.eval()
+    e1, e2 = float(run(5).detach()), float(run(6).detach())
+    assert e1 == e2
+    ev = np.load(os.path.join(GOLD, "grad_b2_t6_l48_pad.npz"), allow_pickle=True)      # same inputs, eval-mode fixture
+    assert abs(e1 - float(ev["loss"])) <= 2e-4
+    agent.train()
+    agent.dropout = 0.0
+    assert float(run(5).detach()) == e1
+    print(f"train mode, own masks: loss {float(loss.detach()):.6f} (float64 oracle {float(want.detach()):.6f}), worst gradient error {worst:.2e}; "
+          f"eval-mode loss {e1:.6f}")

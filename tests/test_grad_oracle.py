@@ -12,7 +12,9 @@ sys.path.insert(0, os.path.join(HERE, "..", "oracle"))
 
 
 @pytest.mark.parametrize("name,dtype,tol", [("b2_t6_l48_pad", torch.float32, 2e-3), ("b2_t6_l48_pad", torch.float64, 4e-3),
-                                            ("b2_t8_l128_s0", torch.float64, 2e-3)])
+                                            ("b2_t8_l128_s0", torch.float64, 2e-3),
+                                            # train() mode, dropout 0.4 with the masks the fixture recorded
+                                            ("train_b2_t6_l48_pad", torch.float32, 2e-3), ("train_b2_t6_l48_pad", torch.float64, 4e-3)])
 def test_gradient_oracle_reproduces_the_reference(name, dtype, tol):
     import grad_oracle
     from neuralnj_amd import synth, utils, weights
@@ -21,9 +23,12 @@ def test_gradient_oracle_reproduces_the_reference(name, dtype, tol):
     cfgs.model.num_enc_layers = int(z["layers"])
     st = weights.seeded_state(cfgs, int(z["wseed"]), str(z["style"]))
     sd = {k: torch.from_numpy(v).to(dtype).requires_grad_(True) for k, v in st.items()}
+    import helpers
+    drop = helpers.recorded_dropout(z)
     loss, tables = grad_oracle.reinforce_loss(sd, synth.codes_to_onehot(z["codes"]), z["mask"], z["merges"], z["tree_scores"],
                                               float(z["baseline"]), float(z["temperature"]), float(z["strength"]),
-                                              int(z["layers"]), dtype)
+                                              int(z["layers"]), dtype, drop=drop)
+    assert drop is None or drop.calls() == drop.expected
     assert abs(float(loss.detach()) - float(z["loss"])) <= 2e-4 * max(1.0, abs(float(z["loss"])))
     got_t = torch.cat([t.detach().reshape(t.shape[0], -1) for t in tables], 1).numpy()
     assert np.abs(got_t - z["tables"]).max() <= 1e-4 * np.abs(z["tables"]).max()
