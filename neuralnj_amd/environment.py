@@ -184,7 +184,8 @@ class PhyInferEnv:
             if agent is None:
                 raise NotImplementedError("the mean-aggregate fallback (agent=None) is not part of the hot path")
             dev = self.state_tensor.device
-            ij_t = torch.tensor(ij, dtype=torch.long, device=dev)
+            from . import utils
+            ij_t = utils.upload(ij, torch.long, dev)
             if hasattr(agent, "_wants_grad") and agent._wants_grad():
                 # Finetune mode: the same step with gradients (train_model.env_step: differentiable gathers,
                 # aggregate, concatenation)

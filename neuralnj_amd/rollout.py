@@ -205,14 +205,17 @@ def reinforce_loss(batch, agent, env, forced_merges, tree_scores, baseline, temp
         n = env.state_tensor.shape[1]
         idx = None
         if ij_prev is not None:
-            idx = torch.from_numpy(np.array(utils.get_score_indices_to_prev(ij_prev, env, n, B))).to(device)
+            idx = utils.upload(utils.get_score_indices_to_prev(merges[:, step - 1], env, n, B), torch.int64, device)
         logits = agent.decode_zxr(env.state_tensor, mask, (ij_prev, idx, logits_prev))["logits"]
         tables.append(logits)
         log_p = torch.log_softmax(logits / temperature, dim=-1)
         ij = [tuple(int(v) for v in merges[b, step]) for b in range(B)]
-        actions = torch.tensor([env.action_indices_dict[n][p] for p in ij], device=device)
-        ij_prev = torch.tensor(ij, dtype=torch.int32, device=device)
-        if env.step(actions, [(None, None)] * B, branch_optimize=False, agent=agent):
+        # the actions are known on the host (forced): the environment gets the host copy (its bookkeeping reads them
+        # back), the gather below the device copy -- no step of the loop waits for the device
+        actions_host = torch.tensor([env.action_indices_dict[n][p] for p in ij])
+        actions = utils.upload(actions_host, torch.int64, device)
+        ij_prev = utils.upload(ij, torch.int32, device)
+        if env.step(actions_host, [(None, None)] * B, branch_optimize=False, agent=agent):
             break
         step += 1
         selected.append(torch.gather(log_p, 1, actions.unsqueeze(1)))

@@ -86,7 +86,10 @@ def _p(t):
 
 
 def _st(t):
-    return _vp(torch.cuda.current_stream(t.device).cuda_stream)
+    # the raw handle of torch's current stream (torch.cuda.current_stream builds a Stream object per call: 11 ms of an
+    # episode's 7000 operator calls)
+    idx = t.device.index
+    return _vp(torch._C._cuda_getCurrentRawStream(torch.cuda.current_device() if idx is None else idx))
 
 
 def _need(t):

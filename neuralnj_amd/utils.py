@@ -162,6 +162,19 @@ def get_score_indices_to_prev(actions_ij_prev, env, nb_seq, batch_size):
     return index_map_batch(int(nb_seq), a)
 
 
+def upload(values, dtype, device):
+    """Small host data (per-step index lists) to the device WITHOUT draining the stream: a copy from pageable host
+    memory blocks the host until everything queued before it has finished -- once per NJ step that makes the host and the
+    device take turns.  Staged through pinned memory (torch's caching host allocator keeps the block until the copy has
+    run) the copy is just another entry of the stream."""
+    import torch
+    t = torch.as_tensor(values, dtype=dtype)
+    device = torch.device(device)
+    if device.type != "cuda":
+        return t.to(device)
+    return t.pin_memory().to(device, non_blocking=True)
+
+
 def newick_to_merges(newick: str, keys):
     """A binary (or root-trifurcating) Newick tree over the taxa `keys` -> (merges int32 [T-1,2], brlen float32
     [T-1,2]) in the convention of the NJ loop (environment.py:764-768: the merged subtree takes position i, position j
