@@ -184,14 +184,15 @@ class PhyInferEnv:
             if agent is None:
                 raise NotImplementedError("the mean-aggregate fallback (agent=None) is not part of the hot path")
             dev = self.state_tensor.device
-            from . import utils
-            ij_t = utils.upload(ij, torch.long, dev)
             if hasattr(agent, "_wants_grad") and agent._wants_grad():
+                from . import utils
+                ij_t = utils.upload(ij, torch.long, dev)          # no wait for the queued device work (utils.upload)
                 # Finetune mode: the same step with gradients (train_model.env_step: differentiable gathers,
                 # aggregate, concatenation)
                 from . import train_model
                 self.state_tensor = train_model.env_step(agent, self.state_tensor, ij_t)
                 return done
+            ij_t = torch.tensor(ij, dtype=torch.long, device=dev)
             if hasattr(agent, "_context") and getattr(agent, "batch_input", None) is self.state_tensor:
                 # this package's PhyloATTN: aggregate + compaction as ONE device call (nnj_env_step).  When the state
                 # is the tensor the preceding decode_zxr scored, the library continues its session: merged row in
