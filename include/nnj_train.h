@@ -23,7 +23,8 @@ extern "C" {
 int nnjt_abi_version(void);
 const char* nnjt_last_error(void);
 
-/* C[b1,b2][m,n] = alpha * sum_k A[b1,b2][m,k] * B[b1,b2][k,n] + beta * C[b1,b2][m,n]   (beta = 0: C is not read)
+/* C[b1,b2][m,n] = alpha * sum_k A[b1,b2][m,k] * B[b1,b2][k,n] + bias[n] + beta * C[b1,b2][m,n]
+ * (beta = 0: C is not read; bias may be NULL -- the bias of nn.Linear, added in the epilogue instead of a second pass)
  * Every operand is addressed by element strides: X[b1,b2][r,c] = X + b1*sXb1 + b2*sXb2 + r*sXr + c*sXc.
  * This one kernel is every contraction of the model: nn.Linear forward (reference msa_modules.py / model.py) and its
  * two backward products, the tied row-attention einsums (axial_attention.py:97,114), the column-attention einsums
@@ -35,6 +36,7 @@ typedef struct nnjt_gemm {
   int64_t sBk, sBn, sBb1, sBb2;
   int64_t sCm, sCn, sCb1, sCb2;
   float alpha, beta;
+  const float* bias;
 } nnjt_gemm;
 int nnjt_gemm_run(const nnjt_gemm* g, void* stream);
 

@@ -131,7 +131,9 @@ __global__ __launch_bounds__(256) void k_gemm(nnjt_gemm g) {
       const int m = m0 + 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * kh, n = n0 + 32 * t + l31;
       if (m < g.M && n < g.N) {
         float* c = C + (int64_t)m * g.sCm + (int64_t)n * g.sCn;
-        *c = g.beta == 0.f ? g.alpha * acc[t][r] : g.alpha * acc[t][r] + g.beta * *c;
+        float v = g.alpha * acc[t][r];
+        if (g.bias) v += g.bias[n];
+        *c = g.beta == 0.f ? v : v + g.beta * *c;
       }
     }
 }
@@ -141,14 +143,27 @@ __global__ void k_add_bias(float* y, const float* __restrict__ bias, int64_t n, 
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) y[i] += bias[i % cols];
 }
-// out[c] += sum_r x[r, c]: a workgroup owns 64 rows, thread = column (cols <= 256), one atomic per column and block
-__global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ x, float* out, int64_t rows, int cols) {
-  const int c = threadIdx.x;
-  if (c >= cols) return;
-  const int64_t r0 = (int64_t)blockIdx.x * 64, r1 = r0 + 64 < rows ? r0 + 64 : rows;
+// out[c] += sum_r x[r, c] (cols <= 256): a workgroup owns `rows_per_block` rows; its 256 threads are 256 / cols row groups
+// x cols columns, so every iteration reads 256 consecutive floats; the groups meet in LDS and the workgroup adds ONE
+// atomic per column (the first version -- 64 rows per workgroup, thread = column -- spent 0.5 ms of atomics on the
+// same 64 addresses for the 1.25 M token rows of the encoder's bias gradients).
+__global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ x, float* out, int64_t rows, int cols,
+                                                int64_t rows_per_block) {
+  __shared__ float part[256];
+  const int G = 256 / cols;
+  const int c = threadIdx.x % cols, rg = threadIdx.x / cols;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  const int64_t r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
   float s = 0.f;
-  for (int64_t r = r0; r < r1; ++r) s += x[r * cols + c];
-  atomicAdd(out + c, s);
+  if (rg < G)
+    for (int64_t r = r0 + rg; r < r1; r += G) s += x[r * cols + c];
+  part[threadIdx.x] = s;
+  __syncthreads();
+  if ((int)threadIdx.x < cols) {
+    float t = 0.f;
+    for (int g2 = 0; g2 < G; ++g2) t += part[g2 * cols + threadIdx.x];
+    atomicAdd(out + threadIdx.x, t);
+  }
 }
 
 // out[c] = sum_r x[r, c] for any number of columns (thread = column, rows walked in order: deterministic): the second
@@ -365,8 +380,14 @@ int nnjt_add_bias(float* y, const float* bias, int64_t rows, int32_t cols, void*
   return 0;
 }
 int nnjt_colsum(const float* x, float* out, int64_t rows, int32_t cols, void* stream) {
-  if (!x || !out || cols > 256) return fail(-1, "nnjt_colsum: null or more than 256 columns");
-  hipLaunchKernelGGL(k_colsum, dim3(blocks_for(rows, 64)), dim3(256), 0, static_cast<hipStream_t>(stream), x, out, rows, cols);
+  if (!x || !out || cols <= 0 || cols > 256) return fail(-1, "nnjt_colsum: null, or not 1..256 columns");
+  if (rows <= 0) return 0;
+  const int G = 256 / cols;
+  int64_t per = (rows + 1023) / 1024;                       // at most ~1024 workgroups, at least 8 rows per row group
+  if (per < 8 * G) per = 8 * G;
+  per = (per + G - 1) / G * G;
+  hipLaunchKernelGGL(k_colsum, dim3((unsigned)((rows + per - 1) / per)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), x, out, rows, cols, per);
   CHK_LAUNCH();
   return 0;
 }

@@ -26,7 +26,7 @@ class Gemm(C.Structure):
                 ("sAm", _i64), ("sAk", _i64), ("sAb1", _i64), ("sAb2", _i64),
                 ("sBk", _i64), ("sBn", _i64), ("sBb1", _i64), ("sBb2", _i64),
                 ("sCm", _i64), ("sCn", _i64), ("sCb1", _i64), ("sCb2", _i64),
-                ("alpha", C.c_float), ("beta", C.c_float)]
+                ("alpha", C.c_float), ("beta", C.c_float), ("bias", _vp)]
 
 
 _SIGS = {
@@ -99,10 +99,10 @@ def _need(t):
 
 
 # ---------------------------------------------------------------------------------------------------- GEMM plumbing
-def gemm(A, B, Cout, M, N, K, sA, sB, sC, nb=(1, 1), bA=(0, 0), bB=(0, 0), bC=(0, 0), alpha=1.0, beta=0.0):
-    """Cout[b1,b2][m,n] = alpha * sum_k A[..][m,k] B[..][k,n] + beta * Cout; sX = (row stride, column stride)."""
+def gemm(A, B, Cout, M, N, K, sA, sB, sC, nb=(1, 1), bA=(0, 0), bB=(0, 0), bC=(0, 0), alpha=1.0, beta=0.0, bias=None):
+    """Cout[b1,b2][m,n] = alpha * sum_k A[..][m,k] B[..][k,n] + bias[n] + beta * Cout; sX = (row stride, column stride)."""
     g = Gemm(_p(A), _p(B), _p(Cout), M, N, K, nb[0], nb[1], sA[0], sA[1], bA[0], bA[1], sB[0], sB[1], bB[0], bB[1],
-             sC[0], sC[1], bC[0], bC[1], alpha, beta)
+             sC[0], sC[1], bC[0], bC[1], alpha, beta, _p(bias))
     _chk(load_library().nnjt_gemm_run(C.byref(g), _st(Cout)))
 
 
@@ -149,9 +149,9 @@ class Linear(torch.autograd.Function):
         Mo = W.shape[0]
         rows = x.numel() // K
         y = torch.empty(x.shape[:-1] + (Mo,), dtype=torch.float32, device=x.device)
-        gemm(x, W, y, rows, Mo, K, (K, 1), (1, K), (Mo, 1))
         if b is not None:
-            _chk(load_library().nnjt_add_bias(_p(y), _p(b), rows, Mo, _st(y)))
+            _need(b)
+        gemm(x, W, y, rows, Mo, K, (K, 1), (1, K), (Mo, 1), bias=b)            # bias added in the GEMM's epilogue
         ctx.save_for_backward(x, W)
         ctx.has_bias = b is not None
         return y

@@ -47,6 +47,12 @@ def test_operators_match_torch():
     F = torch.nn.functional
     _grad_pair(lambda x, w, b: T.Linear.apply(x, w, b), lambda x, w, b: F.linear(x, w, b), [R(3, 70, 64), R(48, 64), R(48)])
     _grad_pair(lambda x, w, b: T.Linear.apply(x, w, b), lambda x, w, b: F.linear(x, w, b), [R(9000, 4), R(64, 4), R(64)])  # long k in dW
+    # bias gradients (nnjt_colsum) at one output (s_out.2), 256 (fc1), a width that does not divide 256, many rows
+    _grad_pair(lambda x, w, b: T.Linear.apply(x, w, b), lambda x, w, b: F.linear(x, w, b), [R(5001, 64), R(1, 64), R(1)])
+    _grad_pair(lambda x, w, b: T.Linear.apply(x, w, b), lambda x, w, b: F.linear(x, w, b), [R(777, 64), R(256, 64), R(256)])
+    _grad_pair(lambda x, w, b: T.Linear.apply(x, w, b), lambda x, w, b: F.linear(x, w, b), [R(1300, 64), R(48, 64), R(48)])
+    _grad_pair(lambda x, w, b: T.Linear.apply(x, w, b), lambda x, w, b: F.linear(x, w, b), [R(300001, 64), R(64, 64), R(64)], tol=5e-5)
+    _grad_pair(lambda x, w: T.Linear.apply(x, w, None), lambda x, w: F.linear(x, w), [R(70, 64), R(64, 64)])
     _grad_pair(lambda x, w, b: T.LayerNorm.apply(x, w, b), lambda x, w, b: F.layer_norm(x, (64,), w, b, 1e-5), [R(5, 33, 64), R(64), R(64)])
     _grad_pair(lambda x: T.Gelu.apply(x), lambda x: F.gelu(x), [R(1000) * 3])
     _grad_pair(lambda h, a, b: T.Gate.apply(h, a, b), lambda h, a, b: torch.sigmoid(h) * a + (1 - torch.sigmoid(h)) * b, [R(7, 64), R(7, 64), R(7, 64)])
