@@ -44,7 +44,7 @@ int nnjt_gemm_run(const nnjt_gemm* g, void* stream);
 int nnjt_add_bias(float* y, const float* bias, int64_t rows, int32_t cols, void* stream);
 int nnjt_colsum(const float* x, float* out, int64_t rows, int32_t cols, void* stream);
 
-/* out[c] = sum_r x[r, c] (rows x cols, any number of columns; rows added in order): the second step of a contraction
+/* out[c] = sum_r x[r, c] (rows x cols, any number of columns; a fixed order of additions): the second step of a contraction
  * that was cut into pieces along k (weight gradients over millions of tokens, attention logits over sites x features). */
 int nnjt_sum_rows(const float* x, float* out, int64_t rows, int64_t cols, void* stream);
 

@@ -166,14 +166,29 @@ __global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ x, flo
   }
 }
 
-// out[c] = sum_r x[r, c] for any number of columns (thread = column, rows walked in order: deterministic): the second
-// step of a contraction cut into pieces
-__global__ void k_sum_rows(const float* __restrict__ x, float* __restrict__ out, int64_t rows, int64_t cols) {
-  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= cols) return;
-  float s = 0.f;
-  for (int64_t r = 0; r < rows; ++r) s += x[r * cols + c];
-  out[c] = s;
+// out[c] = sum_r x[r, c] for any number of columns: the second step of a contraction cut into pieces.  A workgroup owns
+// 64 columns; its four waves each add every fourth row (four loads in flight per lane), then the four partial sums
+// meet in LDS in a fixed order -- deterministic.  (First version: one thread per column walking all rows alone, 40 us
+// for the 256 pieces of a weight gradient: 22 % of a Finetune episode's GPU time.)
+__global__ __launch_bounds__(256) void k_sum_rows(const float* __restrict__ x, float* __restrict__ out, int64_t rows,
+                                                  int64_t cols) {
+  __shared__ float part[4][64];
+  const int lane = threadIdx.x & 63, rg = threadIdx.x >> 6;
+  const int64_t c = (int64_t)blockIdx.x * 64 + lane;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (c < cols) {
+    int64_t r = rg;
+    for (; r + 12 < rows; r += 16) {
+      s0 += x[r * cols + c];
+      s1 += x[(r + 4) * cols + c];
+      s2 += x[(r + 8) * cols + c];
+      s3 += x[(r + 12) * cols + c];
+    }
+    for (; r < rows; r += 4) s0 += x[r * cols + c];
+  }
+  part[rg][lane] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (rg == 0 && c < cols) out[c] = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
 }
 
 // ------------------------------------------------------------------ LayerNorm over 64 features: one wavefront per row
@@ -383,8 +398,8 @@ int nnjt_colsum(const float* x, float* out, int64_t rows, int32_t cols, void* st
   if (!x || !out || cols <= 0 || cols > 256) return fail(-1, "nnjt_colsum: null, or not 1..256 columns");
   if (rows <= 0) return 0;
   const int G = 256 / cols;
-  int64_t per = (rows + 1023) / 1024;                       // at most ~1024 workgroups, at least 8 rows per row group
-  if (per < 8 * G) per = 8 * G;
+  int64_t per = (rows + 1023) / 1024;                       // at most ~1024 workgroups (64 K atomics on the largest input),
+  if (per < 64 * G) per = 64 * G;                           // at least 64 rows per row group: few atomics on the small ones
   per = (per + G - 1) / G * G;
   hipLaunchKernelGGL(k_colsum, dim3((unsigned)((rows + per - 1) / per)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), x, out, rows, cols, per);
@@ -393,7 +408,7 @@ int nnjt_colsum(const float* x, float* out, int64_t rows, int32_t cols, void* st
 }
 int nnjt_sum_rows(const float* x, float* out, int64_t rows, int64_t cols, void* stream) {
   if (!x || !out || rows <= 0 || cols <= 0) return fail(-1, "nnjt_sum_rows: bad argument");
-  hipLaunchKernelGGL(k_sum_rows, dim3(blocks_for(cols, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), x, out, rows, cols);
+  hipLaunchKernelGGL(k_sum_rows, dim3(blocks_for(cols, 64)), dim3(256), 0, static_cast<hipStream_t>(stream), x, out, rows, cols);
   CHK_LAUNCH();
   return 0;
 }
