@@ -33,7 +33,11 @@ inline unsigned blocks_for(int64_t n, int per) { return (unsigned)((n + per - 1)
 // their transposes and the head-strided attention operands are all read in contiguous pieces.  A first version of
 // this kernel did the products on the vector pipe (4 x 4 outputs per thread): 85 % of a Finetune episode's GPU time.
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-constexpr int TM = 128, TN = 64, TK = 16;
+constexpr int TM = 128, TN = 64;
+// TK = k-extent of one LDS stage: 16 (12.5 KB of LDS).  A 64-long stage for the short contractions (k = 64 of every
+// nn.Linear: one barrier pair instead of four) was measured and dropped: 50 KB of LDS per workgroup and the four-row
+// scatter of the k-fast operand into LDS made every shape slower (GEMM time of an episode 62 -> 88 ms).
+template <int TK>
 __global__ __launch_bounds__(256) void k_gemm(nnjt_gemm g) {
   __shared__ __attribute__((aligned(16))) float As[TK][TM + 4];
   __shared__ __attribute__((aligned(16))) float Bs[TK][TN + 4];
@@ -58,8 +62,8 @@ __global__ __launch_bounds__(256) void k_gemm(nnjt_gemm g) {
   for (int k0 = 0; k0 < g.K; k0 += TK) {
     if (a_vec) {
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int e = tid + 256 * i;                         // 512 groups of four
+      for (int i = 0; i < TM * TK / 4 / 256; ++i) {
+        const int e = tid + 256 * i;                         // TM * TK / 4 groups of four
         if (a_kfast) {                                       // four consecutive k of one row
           const int m = e / (TK / 4), k = 4 * (e % (TK / 4));
           f4 v = {0.f, 0.f, 0.f, 0.f};
@@ -78,7 +82,7 @@ __global__ __launch_bounds__(256) void k_gemm(nnjt_gemm g) {
       }
     } else {
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
+      for (int i = 0; i < TM * TK / 256; ++i) {
         const int e = tid + 256 * i;
         const int m = a_kfast ? e / TK : e % TM, k = a_kfast ? e % TK : e / TM;
         const bool ok = m0 + m < g.M && k0 + k < g.K;
@@ -86,25 +90,28 @@ __global__ __launch_bounds__(256) void k_gemm(nnjt_gemm g) {
       }
     }
     if (b_vec) {
-      const int e = tid;                                     // 256 groups of four
-      if (b_kfast) {
-        const int n = e / (TK / 4), k = 4 * (e % (TK / 4));
-        f4 v = {0.f, 0.f, 0.f, 0.f};
-        if (n0 + n < g.N && k0 + k + 3 < g.K) v = *reinterpret_cast<const f4*>(B + (int64_t)(n0 + n) * g.sBn + (k0 + k));
-        else if (n0 + n < g.N)
-          for (int t = 0; t < 4; ++t) if (k0 + k + t < g.K) v[t] = B[(int64_t)(n0 + n) * g.sBn + (k0 + k + t)];
-        Bs[k][n] = v[0]; Bs[k + 1][n] = v[1]; Bs[k + 2][n] = v[2]; Bs[k + 3][n] = v[3];
-      } else {
-        const int n = 4 * (e % (TN / 4)), k = e / (TN / 4);
-        f4 v = {0.f, 0.f, 0.f, 0.f};
-        if (k0 + k < g.K && n0 + n + 3 < g.N) v = *reinterpret_cast<const f4*>(B + (int64_t)(k0 + k) * g.sBk + (n0 + n));
-        else if (k0 + k < g.K)
-          for (int t = 0; t < 4; ++t) if (n0 + n + t < g.N) v[t] = B[(int64_t)(k0 + k) * g.sBk + (n0 + n + t)];
-        *reinterpret_cast<f4*>(&Bs[k][n]) = v;
+#pragma unroll
+      for (int i = 0; i < TN * TK / 4 / 256; ++i) {
+        const int e = tid + 256 * i;                         // TN * TK / 4 groups of four
+        if (b_kfast) {
+          const int n = e / (TK / 4), k = 4 * (e % (TK / 4));
+          f4 v = {0.f, 0.f, 0.f, 0.f};
+          if (n0 + n < g.N && k0 + k + 3 < g.K) v = *reinterpret_cast<const f4*>(B + (int64_t)(n0 + n) * g.sBn + (k0 + k));
+          else if (n0 + n < g.N)
+            for (int t = 0; t < 4; ++t) if (k0 + k + t < g.K) v[t] = B[(int64_t)(n0 + n) * g.sBn + (k0 + k + t)];
+          Bs[k][n] = v[0]; Bs[k + 1][n] = v[1]; Bs[k + 2][n] = v[2]; Bs[k + 3][n] = v[3];
+        } else {
+          const int n = 4 * (e % (TN / 4)), k = e / (TN / 4);
+          f4 v = {0.f, 0.f, 0.f, 0.f};
+          if (k0 + k < g.K && n0 + n + 3 < g.N) v = *reinterpret_cast<const f4*>(B + (int64_t)(k0 + k) * g.sBk + (n0 + n));
+          else if (k0 + k < g.K)
+            for (int t = 0; t < 4; ++t) if (n0 + n + t < g.N) v[t] = B[(int64_t)(k0 + k) * g.sBk + (n0 + n + t)];
+          *reinterpret_cast<f4*>(&Bs[k][n]) = v;
+        }
       }
     } else {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < TN * TK / 256; ++i) {
         const int e = tid + 256 * i;
         const int n = b_kfast ? e / TK : e % TN, k = b_kfast ? e % TK : e / TN;
         const bool ok = n0 + n < g.N && k0 + k < g.K;
@@ -114,7 +121,7 @@ __global__ __launch_bounds__(256) void k_gemm(nnjt_gemm g) {
     __syncthreads();
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
-    for (int kk = 0; kk < TK; kk += 2) {
+    for (int kk = 0; kk < TK; kk += 2) {                     // (rows of the stage beyond K hold zeros)
       const float a = As[kk + kh][32 * wave + l31];          // A[m = lane & 31][k = lane >> 5]
       const float bl = Bs[kk + kh][l31], bh = Bs[kk + kh][32 + l31];
       acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bl, acc[0], 0, 0, 0);
@@ -154,9 +161,18 @@ __global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ x, flo
   const int c = threadIdx.x % cols, rg = threadIdx.x / cols;
   const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
   const int64_t r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
-  float s = 0.f;
-  if (rg < G)
-    for (int64_t r = r0 + rg; r < r1; r += G) s += x[r * cols + c];
+  float s = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (rg < G) {
+    int64_t r = r0 + rg;
+    for (; r + 3 * G < r1; r += 4 * G) {                     // four loads in flight per lane
+      s += x[r * cols + c];
+      s1 += x[(r + G) * cols + c];
+      s2 += x[(r + 2 * G) * cols + c];
+      s3 += x[(r + 3 * G) * cols + c];
+    }
+    for (; r < r1; r += G) s += x[r * cols + c];
+    s = (s + s1) + (s2 + s3);
+  }
   part[threadIdx.x] = s;
   __syncthreads();
   if ((int)threadIdx.x < cols) {
@@ -383,7 +399,7 @@ int nnjt_gemm_run(const nnjt_gemm* g, void* stream) {
   const int64_t nb = (int64_t)g->nb1 * g->nb2;
   if (nb > 65535) return fail(-1, "nnjt_gemm_run: more than 65535 batch entries (%lld)", (long long)nb);
   const dim3 grid((g->N + TN - 1) / TN, (g->M + TM - 1) / TM, (unsigned)nb);
-  hipLaunchKernelGGL(k_gemm, grid, dim3(256), 0, static_cast<hipStream_t>(stream), *g);
+  hipLaunchKernelGGL(k_gemm<16>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), *g);
   CHK_LAUNCH();
   return 0;
 }
@@ -399,7 +415,7 @@ int nnjt_colsum(const float* x, float* out, int64_t rows, int32_t cols, void* st
   if (rows <= 0) return 0;
   const int G = 256 / cols;
   int64_t per = (rows + 1023) / 1024;                       // at most ~1024 workgroups (64 K atomics on the largest input),
-  if (per < 64 * G) per = 64 * G;                           // at least 64 rows per row group: few atomics on the small ones
+  if (per < 16 * G) per = 16 * G;                           // at least 16 rows per row group
   per = (per + G - 1) / G * G;
   hipLaunchKernelGGL(k_colsum, dim3((unsigned)((rows + per - 1) / per)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), x, out, rows, cols, per);
