@@ -54,6 +54,7 @@ _SIGS = {
     "nnjt_permute5": ([_vp, _vp, C.POINTER(_i64), C.POINTER(_i64), _i32, _vp], C.c_int),
 }
 _lib = None
+ABI_VERSION = 2                                          # include/nnj_train.h as of this file (nnjt_abi_version)
 
 
 def exported_symbols():
@@ -72,6 +73,9 @@ def load_library(path: str = LIB_PATH):
         fn = getattr(lib, name)
         fn.argtypes = argt
         fn.restype = rest
+    if lib.nnjt_abi_version() != ABI_VERSION:           # e.g. nnjt_gemm grew a field: a stale build must not be called
+        raise RuntimeError(f"{path} has ABI version {lib.nnjt_abi_version()}, this package binds version {ABI_VERSION}: "
+                           "rebuild it with `python -m neuralnj_amd.build`")
     _lib = lib
     return lib
 

@@ -37,7 +37,7 @@ def test_train_library_exports_its_header(repo_root):
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/nnj_train.h but not exported"
     assert set(train_ops.exported_symbols()) == set(names)
-    assert lib.nnjt_abi_version() == 2
+    assert lib.nnjt_abi_version() == train_ops.ABI_VERSION == 2
 
 
 def test_param_count_and_argument_errors():
