@@ -73,6 +73,9 @@ def exported_symbols():
     return sorted(_SIGS)
 
 
+ABI_VERSION = 1                                          # include/nnj.h as of this file (nnj_abi_version)
+
+
 def load_library(path: str = LIB_PATH):
     """dlopen the HIP library and bind every symbol of include/nnj.h (no compute call)."""
     global _lib
@@ -87,6 +90,9 @@ def load_library(path: str = LIB_PATH):
         fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
         fn.argtypes = argt
         fn.restype = rest
+    if lib.nnj_abi_version() != ABI_VERSION:
+        raise RuntimeError(f"{path} has ABI version {lib.nnj_abi_version()}, this package binds version {ABI_VERSION}: "
+                           "rebuild it with `python -m neuralnj_amd.build`")
     _lib = lib
     return lib
 
