@@ -410,7 +410,8 @@ def main():
                      "the reference's own fp32 tables, profiles/r02/parity_margin.json)",
         "config": {"workload": f"Batch={B} synthetic {T}x{L} MSAs per GPU, Argmax rollout (BASELINE configs[2]; "
                                f"configs[3] when sharded over 8 GPUs)",
-                   "batch_per_gpu": B, "taxa": T, "sites": L, "gap_frac": 0.2, "model": "dim64 heads8 layers6 patch1",
+                   "batch_per_gpu": B, "taxa": T, "sites": L, "gap_frac": 0.2,
+                   "hyperparameters": "embed_dim 64, 8 heads, 6 layers, patch 1 (the reference's shipped configuration)",
                    "weights": "seeded random (no checkpoint ships with the reference)"},
     }
     if per_rank is not None:
