@@ -413,6 +413,17 @@ def test_dropout_operator():
     T._DropoutState.tape = None
     assert T.dropout(x, 0.0) is x
     del y2
+    # replay: a recorded mask reproduces the call; a mask that does not fit is refused
+    T._DropoutState.replay = [keep.to(torch.uint8)]
+    try:
+        assert torch.equal(T.Dropout.apply(x.detach(), p), y.detach())
+        T._DropoutState.replay = [keep[:-1].to(torch.uint8)]
+        with pytest.raises(RuntimeError):
+            T.Dropout.apply(x.detach(), p)
+    finally:
+        T._DropoutState.replay = None
+    with pytest.raises(RuntimeError):
+        T.Dropout.apply(x.detach(), 1.0)                                      # p outside [0, 1)
 
 
 def _train_mode_case(z):
