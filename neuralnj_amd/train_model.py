@@ -102,6 +102,7 @@ def encode(model, onehot, pad):
     steps_bytes = 2 * 14 * B * (R * (R + 1) // 2) * L * 64 * 4
     model._train_ckpt = bool(int(os.environ.get("NNJ_TRAIN_PAIR_CHUNK", "0"))) or \
         steps_bytes > torch.cuda.get_device_properties(dev).total_memory // 3
+    model.__dict__["_train_keys"] = None                                       # (keys of an earlier episode's states)
     x = _lin(T.Gelu.apply(_lin(x, model.embed[0])), model.embed[2])           # [B,R,C,D]
     x = T.Permute.apply(x, (1, 2, 0, 3))                                       # 'b r c d -> r c b d'
     pd = float(model.dropout) if model.training else 0.0                        # nn.Dropout: identity in eval mode
@@ -118,6 +119,22 @@ def encode(model, onehot, pad):
 
 
 # ------------------------------------------------------------------------------------------------ scorer
+def _state_keys(model, state):
+    """g_attn_k(state) [B,n,C,D] (model.py:117).  The reference transforms every row of the state in each aggregate call
+    -- twice per NJ step (decode_zxr, env.step), although a step changes one row.  nn.Linear acts on rows, so the keys
+    of the next state are the gathered keys of this one plus the transformed merged row (env_step); autograd carries
+    the gradient through the gathers exactly as through the state itself.  The cache is keyed on the state TENSOR
+    (the caller hands env.state_tensor back, as the reference's loop does); any other tensor is transformed afresh."""
+    cache = model.__dict__.get("_train_keys")
+    if cache is not None and cache[0] is state and cache[2] == state._version:
+        return cache[1]
+    k = _lin(state, model.g_attn_k)
+    # (under activation checkpointing the closures recompute from the state: nothing is carried over)
+    if not getattr(model, "_train_ckpt", False) and not model.__dict__.get("_train_nocache"):
+        model.__dict__["_train_keys"] = (state, k, state._version)
+    return k
+
+
 def aggregate(model, state, x_i, x_j, i_idx, j_idx):
     """PhyloATTN.aggregate (model.py:102-155).  state [B,n,C,D] (the stashed batch_input); x_i, x_j [B,p,C,D];
     i_idx, j_idx int64 [B,p]: the rows excluded from each pair's context."""
@@ -128,7 +145,7 @@ def aggregate(model, state, x_i, x_j, i_idx, j_idx):
     if n <= 2:
         return x
     q = _lin(x, model.g_attn_q)
-    k = _lin(state, model.g_attn_k)
+    k = _state_keys(model, state)
     alpha = T.Bmm.apply(q.view(B, p, C * D), k.view(B, n, C * D), True, 1.0 / math.sqrt(model.embed_dim * model.patch_num))
     r = torch.arange(n, device=state.device).view(1, 1, n)
     keep = ((r != i_idx.unsqueeze(-1)) & (r != j_idx.unsqueeze(-1))).to(torch.uint8).contiguous()
@@ -177,9 +194,13 @@ def decode(model, state, pad, info):
             return decode_gg(model, st, T.GatherRows.apply(st, i_idx), T.GatherRows.apply(st, j_idx), keep, i_idx, j_idx)
 
         out = None
-        for lo in range(0, P, chunk):
-            piece = checkpoint(part, state, lo, min(P, lo + chunk), use_reentrant=False)
-            out = piece if out is None else _cat_last(out, piece)
+        model.__dict__["_train_nocache"], model.__dict__["_train_keys"] = True, None
+        try:
+            for lo in range(0, P, chunk):
+                piece = checkpoint(part, state, lo, min(P, lo + chunk), use_reentrant=False)
+                out = piece if out is None else _cat_last(out, piece)
+        finally:
+            model.__dict__["_train_nocache"] = False
         return out
     ip = torch.as_tensor(actions_ij_prev).to(dev)[:, 0].to(torch.int64)
     r = torch.arange(n, device=dev, dtype=torch.int64).unsqueeze(0).expand(B, n)
@@ -255,7 +276,15 @@ def env_step(model, state, ij):
     r = torch.arange(n - 1, device=dev, dtype=torch.int64).unsqueeze(0).expand(B, n - 1)
     base = r + (r >= j_idx)                                  # positions of the old rows once j is gone ...
     base = torch.where(r == i_idx, torch.full_like(base, n), base).contiguous()   # ... the merged row (index n) at i
-    return T.GatherRows.apply(_CatRows.apply(state, new), base)
+    out = T.GatherRows.apply(_CatRows.apply(state, new), base)
+    cache = model.__dict__.get("_train_keys")
+    if cache is not None and cache[0] is state and cache[2] == state._version and n - 1 > 2:
+        # keys of the next state: the old rows' keys move with their rows, the merged row is transformed alone
+        keys = T.GatherRows.apply(_CatRows.apply(cache[1], _lin(new, model.g_attn_k)), base)
+        model.__dict__["_train_keys"] = (out, keys, out._version)
+    else:
+        model.__dict__["_train_keys"] = None
+    return out
 
 
 class ExpandBatch(torch.autograd.Function):
