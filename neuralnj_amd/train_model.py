@@ -126,13 +126,22 @@ def _state_keys(model, state):
     the gradient through the gathers exactly as through the state itself.  The cache is keyed on the state TENSOR
     (the caller hands env.state_tensor back, as the reference's loop does); any other tensor is transformed afresh."""
     cache = model.__dict__.get("_train_keys")
-    if cache is not None and cache[0] is state and cache[2] == state._version:
+    if _keys_valid(model, cache, state):
         return cache[1]
     k = _lin(state, model.g_attn_k)
     # (under activation checkpointing the closures recompute from the state: nothing is carried over)
     if not getattr(model, "_train_ckpt", False) and not model.__dict__.get("_train_nocache"):
-        model.__dict__["_train_keys"] = (state, k, state._version)
+        model.__dict__["_train_keys"] = (state, k, _keys_stamp(model, state))
     return k
+
+
+def _keys_stamp(model, state):
+    # version counters: an in-place write to the state, or to the weights (optimizer.step, load_state_dict), outdates the keys
+    return (state._version, model.g_attn_k.weight._version, model.g_attn_k.bias._version)
+
+
+def _keys_valid(model, cache, state):
+    return cache is not None and cache[0] is state and cache[2] == _keys_stamp(model, state)
 
 
 def aggregate(model, state, x_i, x_j, i_idx, j_idx):
@@ -278,10 +287,10 @@ def env_step(model, state, ij):
     base = torch.where(r == i_idx, torch.full_like(base, n), base).contiguous()   # ... the merged row (index n) at i
     out = T.GatherRows.apply(_CatRows.apply(state, new), base)
     cache = model.__dict__.get("_train_keys")
-    if cache is not None and cache[0] is state and cache[2] == state._version and n - 1 > 2:
+    if _keys_valid(model, cache, state) and n - 1 > 2:
         # keys of the next state: the old rows' keys move with their rows, the merged row is transformed alone
         keys = T.GatherRows.apply(_CatRows.apply(cache[1], _lin(new, model.g_attn_k)), base)
-        model.__dict__["_train_keys"] = (out, keys, out._version)
+        model.__dict__["_train_keys"] = (out, keys, _keys_stamp(model, out))
     else:
         model.__dict__["_train_keys"] = None
     return out

@@ -557,3 +557,34 @@ def test_train_mode_own_masks_match_the_fp64_oracle_and_eval_mode_is_untouched()
     assert float(run(5).detach()) == e1
     print(f"train mode, own masks: loss {float(loss.detach()):.6f} (float64 oracle {float(want.detach()):.6f}), worst gradient error {worst:.2e}; "
           f"eval-mode loss {e1:.6f}")
+
+
+def test_carried_state_keys_follow_the_weights_and_the_state():
+    """train_model._state_keys carries g_attn_k(state) from call to call for the SAME state tensor; a change of the
+    weights (optimizer step) or an in-place write to the state must outdate it."""
+    from neuralnj_amd.model import PhyloATTN
+    cfgs = utils.shipped_config()
+    cfgs.model.num_enc_layers = 2
+    agent = PhyloATTN(cfgs)
+    agent.load_state_dict({k: torch.from_numpy(v) for k, v in weights.seeded_state(cfgs, 3, "sharp").items()}, strict=True)
+    agent = agent.to(_dev()).eval()
+    codes = synth.synth_codes_tree(2, 6, 48, seed=9)
+    mask = torch.zeros((2, 48), dtype=torch.bool, device=_dev())
+    with torch.no_grad():
+        state = agent.encode_zxr(torch.from_numpy(synth.codes_to_onehot(codes)).to(_dev()), mask).clone()
+
+    def table(st, fresh=False):
+        if fresh:
+            agent.__dict__["_train_keys"] = None
+        return agent.decode_zxr(st, mask, (None, None, None))["logits"].detach().clone()
+    t1 = table(state)
+    assert agent.__dict__["_train_keys"] is not None and agent.__dict__["_train_keys"][0] is state
+    assert torch.equal(table(state), t1)                                       # served from the carried keys
+    with torch.no_grad():
+        agent.g_attn_k.weight.mul_(1.5)                                        # what an optimizer step does: in place
+    t2 = table(state)
+    assert not torch.equal(t2, t1) and torch.equal(t2, table(state, fresh=True))
+    with torch.no_grad():
+        state.add_(0.01)                                                       # the caller writes to the state
+    t3 = table(state)
+    assert not torch.equal(t3, t2) and torch.equal(t3, table(state, fresh=True))
