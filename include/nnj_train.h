@@ -40,6 +40,12 @@ typedef struct nnjt_gemm {
 } nnjt_gemm;
 int nnjt_gemm_run(const nnjt_gemm* g, void* stream);
 
+/* Weight gradient of a 64 -> 64 nn.Linear over `rows` tokens: parts[p][m * 64 + n] = sum over the tokens of block p of
+ * dy[token][m] * x[token][n]  (dy, x: [rows, 64] contiguous; block p = tokens [p * per_block, (p + 1) * per_block),
+ * per_block a multiple of 8; parts: [ceil(rows / per_block), 4096]).  nnjt_sum_rows over the parts gives dW (the
+ * weight gradients of nn.Linear, reference msa_modules.py / model.py under torch.autograd). */
+int nnjt_wgrad64(const float* dy, const float* x, float* parts, int64_t rows, int64_t per_block, void* stream);
+
 /* y[r, :] += bias (rows x cols, in place) -- the bias of nn.Linear; colsum: out[c] += sum_r x[r, c] (its gradient). */
 int nnjt_add_bias(float* y, const float* bias, int64_t rows, int32_t cols, void* stream);
 int nnjt_colsum(const float* x, float* out, int64_t rows, int32_t cols, void* stream);

@@ -145,6 +145,75 @@ __global__ __launch_bounds__(256) void k_gemm(nnjt_gemm g) {
     }
 }
 
+// ------------------------------------------------------------------ weight gradient of a 64 -> 64 nn.Linear
+// dW[m][n] = sum_tokens dy[token][m] x[token][n]: a 64 x 64 output and a contraction over up to millions of tokens --
+// in a batch of Finetune episodes 45 % of the GEMM time went here, through the general kernel's LDS stages with one
+// workgroup per CU.  Both operands lie token-major with 64 contiguous features, which is exactly what
+// v_mfma_f32_32x32x2_f32 wants lane by lane (lane & 31 = feature, lane >> 5 = which of the step's two tokens): every
+// lane loads its four operand values (two feature halves of dy, two of x) straight from global memory, 128-byte
+// segments per half wave, no LDS and no barrier in the loop.  A workgroup owns `per_block` tokens, a quarter per wave;
+// the four waves' tiles are added in LDS in wave order (deterministic) and written as one part; nnjt_sum_rows adds the
+// parts.
+__global__ __launch_bounds__(256) void k_wgrad64(const float* __restrict__ dy, const float* __restrict__ x,
+                                                 float* __restrict__ parts, int64_t rows, int64_t per_block) {
+  __shared__ float red[64 * 64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, kh = lane >> 5;
+  const int64_t b0 = (int64_t)blockIdx.x * per_block;
+  const int64_t b1 = b0 + per_block < rows ? b0 + per_block : rows;
+  const int64_t per_wave = ((per_block / 4) + 1) & ~(int64_t)1;          // even: a step takes two tokens
+  const int64_t k0 = b0 + wave * per_wave;
+  const int64_t k1 = k0 + per_wave < b1 ? k0 + per_wave : b1;
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int U = 8;                                       // token pairs in flight per lane
+  for (int64_t t = k0; t < k1; t += 2 * U) {
+    float a0[U], a1[U], c0[U], c1[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t tok = t + 2 * u + kh;
+      const bool ok = tok < k1;
+      const float* dp = dy + (ok ? tok : k0) * 64 + l31;
+      const float* xp = x + (ok ? tok : k0) * 64 + l31;
+      a0[u] = ok ? dp[0] : 0.f;
+      a1[u] = ok ? dp[32] : 0.f;
+      c0[u] = ok ? xp[0] : 0.f;
+      c1[u] = ok ? xp[32] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[u], c0[u], acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[u], c1[u], acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[u], c0[u], acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[u], c1[u], acc[1][1], 0, 0, 0);
+    }
+  }
+#endif
+  // C/D layout: register r of a lane = row (r & 3) + 8 (r >> 2) + 4 (lane >> 5), column lane & 31
+  for (int w = 0; w < 4; ++w) {
+    if (wave == w) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int m = 32 * i + (r & 3) + 8 * (r >> 2) + 4 * kh, n = 32 * j + l31;
+            if (w == 0) red[m * 64 + n] = acc[i][j][r];
+            else red[m * 64 + n] += acc[i][j][r];
+          }
+    }
+    __syncthreads();
+  }
+  float* out = parts + (int64_t)blockIdx.x * 4096;
+  for (int e = tid; e < 4096; e += 256) out[e] = red[e];
+}
+
 // ------------------------------------------------------------------ bias, column sums
 __global__ void k_add_bias(float* y, const float* __restrict__ bias, int64_t n, int cols) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -400,6 +469,16 @@ int nnjt_gemm_run(const nnjt_gemm* g, void* stream) {
   if (nb > 65535) return fail(-1, "nnjt_gemm_run: more than 65535 batch entries (%lld)", (long long)nb);
   const dim3 grid((g->N + TN - 1) / TN, (g->M + TM - 1) / TM, (unsigned)nb);
   hipLaunchKernelGGL(k_gemm<16>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), *g);
+  CHK_LAUNCH();
+  return 0;
+}
+int nnjt_wgrad64(const float* dy, const float* x, float* parts, int64_t rows, int64_t per_block, void* stream) {
+  if (!dy || !x || !parts) return fail(-1, "nnjt_wgrad64: null");
+  if (rows <= 0 || per_block < 8 || per_block % 8 != 0) return fail(-1, "nnjt_wgrad64: per_block must be a positive multiple of 8");
+  const int64_t nparts = (rows + per_block - 1) / per_block;
+  if (nparts > 65535 * 16) return fail(-1, "nnjt_wgrad64: too many parts");
+  hipLaunchKernelGGL(k_wgrad64, dim3((unsigned)nparts), dim3(256), 0, static_cast<hipStream_t>(stream), dy, x, parts, rows,
+                     per_block);
   CHK_LAUNCH();
   return 0;
 }

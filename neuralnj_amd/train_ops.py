@@ -33,6 +33,7 @@ _SIGS = {
     "nnjt_abi_version": ([], C.c_int),
     "nnjt_last_error": ([], C.c_char_p),
     "nnjt_gemm_run": ([C.POINTER(Gemm), _vp], C.c_int),
+    "nnjt_wgrad64": ([_vp, _vp, _vp, _i64, _i64, _vp], C.c_int),
     "nnjt_add_bias": ([_vp, _vp, _i64, _i32, _vp], C.c_int),
     "nnjt_colsum": ([_vp, _vp, _i64, _i32, _vp], C.c_int),
     "nnjt_sum_rows": ([_vp, _vp, _i64, _i64, _vp], C.c_int),
@@ -173,7 +174,17 @@ class Linear(torch.autograd.Function):
             gemm(dy, W, dx, rows, K, Mo, (Mo, 1), (K, 1), (K, 1))
         if ctx.needs_input_grad[1]:
             dW = torch.empty_like(W)
-            gemm_longk(dy, x, dW, Mo, K, rows, (1, Mo), (K, 1), (K, 1))          # dW = dy^T x
+            if Mo == 64 and K == 64 and rows >= 4096:
+                # the 64 -> 64 layers over many tokens (most of the model): operands straight from global memory into
+                # the MFMA lanes, ~512 workgroups, parts added in order
+                per = max(256, -(-rows // 512))
+                per = -(-per // 8) * 8
+                parts = torch.empty((-(-rows // per), 4096), dtype=torch.float32, device=x.device)
+                lib = load_library()
+                _chk(lib.nnjt_wgrad64(_p(dy), _p(x), _p(parts), rows, per, _st(x)))
+                _chk(lib.nnjt_sum_rows(_p(parts), _p(dW), parts.shape[0], 4096, _st(x)))
+            else:
+                gemm_longk(dy, x, dW, Mo, K, rows, (1, Mo), (K, 1), (K, 1))      # dW = dy^T x
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = torch.zeros(Mo, dtype=torch.float32, device=x.device)
             _chk(load_library().nnjt_colsum(_p(dy), _p(db), rows, Mo, _st(dy)))
