@@ -514,7 +514,22 @@ class Bmm(torch.autograd.Function):
 
 def _bgemm(A, B, Cout, nb, M, N, K, sA, sB, sC, bsA, bsB, bsC, alpha):
     """batched product with a long-contraction path and the 65535-entry grid limit handled here"""
-    if nb <= 64 and _piece(M, N, K, nb):
+    piece = _piece(M, N, K, nb) if nb <= 64 else 0
+    if piece and sC == (N, 1) and bsC == M * N and Cout.is_contiguous():
+        # long contractions of a small batch (the pair scorer's logits over sites x features, one entry per alignment
+        # or replica): ALL entries' pieces in one launch -- parts [piece, entry, M, N] through the kernel's two batch
+        # dimensions -- and one nnjt_sum_rows over the pieces
+        nfull = K // piece
+        tail = K - nfull * piece
+        parts = torch.empty((nfull + (1 if tail else 0), nb, M, N), dtype=torch.float32, device=Cout.device)
+        gemm(A, B, parts, M, N, piece, sA, sB, (N, 1), nb=(nfull, nb), bA=(piece * sA[1], bsA), bB=(piece * sB[0], bsB),
+             bC=(nb * M * N, M * N), alpha=alpha)
+        if tail:
+            gemm(A.reshape(-1)[nfull * piece * sA[1]:], B.reshape(-1)[nfull * piece * sB[0]:], parts[nfull], M, N, tail,
+                 sA, sB, (N, 1), nb=(nb, 1), bA=(bsA, 0), bB=(bsB, 0), bC=(M * N, 0), alpha=alpha)
+        _chk(load_library().nnjt_sum_rows(_p(parts), _p(Cout), parts.shape[0], nb * M * N, _st(Cout)))
+        return
+    if piece:
         for b in range(nb):
             gemm_longk(A[b], B[b], Cout[b], M, N, K, sA, sB, sC, alpha=alpha)
         return
