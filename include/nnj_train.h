@@ -40,6 +40,12 @@ typedef struct nnjt_gemm {
 } nnjt_gemm;
 int nnjt_gemm_run(const nnjt_gemm* g, void* stream);
 
+/* C[b][m, n] = alpha * sum_k A[b][m, k] * B[b][k, n] for 1 <= M, K <= 64 and a long N (a multiple of 64): the pair scorer's
+ * x_g = alpha_rows x state over sites x features (reference model.py:148) and its gradient with respect to the state.
+ * A[b][m, k] = A + b * bsA + m * sAm + k * sAk (either orientation); B[b] is [K, N] and C[b] is [M, N], both contiguous. */
+int nnjt_skinny_gemm(const float* A, int64_t sAm, int64_t sAk, int64_t bsA, const float* B, int64_t bsB, float* C,
+                     int64_t bsC, int32_t nb, int32_t M, int32_t K, int64_t N, float alpha, void* stream);
+
 /* Weight gradient of a 64 -> 64 nn.Linear over `rows` tokens: parts[p][m * 64 + n] = sum over the tokens of block p of
  * dy[token][m] * x[token][n]  (dy, x: [rows, 64] contiguous; block p = tokens [p * per_block, (p + 1) * per_block),
  * per_block a multiple of 8; parts: [ceil(rows / per_block), 4096]).  nnjt_sum_rows over the parts gives dW (the

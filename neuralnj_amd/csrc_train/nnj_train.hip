@@ -214,6 +214,73 @@ __global__ __launch_bounds__(256) void k_wgrad64(const float* __restrict__ dy, c
   for (int e = tid; e < 4096; e += 256) out[e] = red[e];
 }
 
+// ------------------------------------------------------------------ skinny products: C[M, N] = alpha A[M, K] B[K, N]
+// M, K <= 64 and N = sites x features (65,536 at 1024 sites): the pair scorer's x_g = alpha_rows x state (model.py:148)
+// and its gradient with respect to the state.  Bound by streaming B in and C out; the general kernel's 128 x 64 tile is
+// mostly empty here (1.2 TB/s).  A (a few thousand floats, any strides) sits in LDS as [k][m]; B goes from global memory
+// straight into the MFMA lanes (lane & 31 = column: 128-byte segments; lane >> 5 = which of the step's two k); a wave
+// owns 64 columns, a workgroup 256.  MT = 1 when M <= 32.
+template <int MT>
+__global__ __launch_bounds__(256) void k_skinny(const float* __restrict__ A, int64_t sAm, int64_t sAk, int64_t bsA,
+                                                const float* __restrict__ B, int64_t bsB, float* __restrict__ C,
+                                                int64_t bsC, int M, int K, int64_t N, float alpha) {
+  __shared__ float As[64][64];                               // [k][m], zero beyond (K, M)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, kh = lane >> 5;
+  const int64_t b = blockIdx.y;
+  A += b * bsA;
+  B += b * bsB;
+  C += b * bsC;
+  for (int e = tid; e < 64 * 64; e += 256) {
+    const int k = e >> 6, m = e & 63;
+    As[k][m] = (k < K && m < M) ? A[(int64_t)m * sAm + (int64_t)k * sAk] : 0.f;
+  }
+  __syncthreads();
+  const int64_t col0 = ((int64_t)blockIdx.x * 4 + wave) * 64;
+  if (col0 >= N) return;
+  f32x16 acc[MT][2];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int U = 8;                                       // k pairs in flight per lane
+  for (int k0 = 0; k0 < K; k0 += 2 * U) {
+    float b0[U], b1[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int k = k0 + 2 * u + kh;
+      const bool ok = k < K;
+      const float* bp = B + (int64_t)(ok ? k : 0) * N + col0 + l31;
+      b0[u] = ok ? bp[0] : 0.f;
+      b1[u] = ok ? bp[32] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int k = k0 + 2 * u + kh;                         // (< 64 + 16: As rows beyond K are never read: k < K or b = 0)
+      const int kc = k < 64 ? k : 63;
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        const float a = As[kc][32 * i + l31];
+        acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0[u], acc[i][0], 0, 0, 0);
+        acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1[u], acc[i][1], 0, 0, 0);
+      }
+    }
+  }
+#endif
+  // C/D layout: register r of a lane = row (r & 3) + 8 (r >> 2) + 4 (lane >> 5), column lane & 31
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = 32 * i + (r & 3) + 8 * (r >> 2) + 4 * kh;
+        if (m < M) C[(int64_t)m * N + col0 + 32 * j + l31] = alpha * acc[i][j][r];
+      }
+}
+
 // ------------------------------------------------------------------ bias, column sums
 __global__ void k_add_bias(float* y, const float* __restrict__ bias, int64_t n, int cols) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -469,6 +536,18 @@ int nnjt_gemm_run(const nnjt_gemm* g, void* stream) {
   if (nb > 65535) return fail(-1, "nnjt_gemm_run: more than 65535 batch entries (%lld)", (long long)nb);
   const dim3 grid((g->N + TN - 1) / TN, (g->M + TM - 1) / TM, (unsigned)nb);
   hipLaunchKernelGGL(k_gemm<16>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), *g);
+  CHK_LAUNCH();
+  return 0;
+}
+int nnjt_skinny_gemm(const float* A, int64_t sAm, int64_t sAk, int64_t bsA, const float* B, int64_t bsB, float* C,
+                     int64_t bsC, int32_t nb, int32_t M, int32_t K, int64_t N, float alpha, void* stream) {
+  if (!A || !B || !C) return fail(-1, "nnjt_skinny_gemm: null");
+  if (nb <= 0 || nb > 65535 || M <= 0 || M > 64 || K <= 0 || K > 64 || N <= 0 || N % 64 != 0)
+    return fail(-1, "nnjt_skinny_gemm: needs 1 <= M, K <= 64 and N a multiple of 64 (M %d, K %d, N %lld)", M, K, (long long)N);
+  const dim3 grid((unsigned)((N + 255) / 256), (unsigned)nb);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (M <= 32) hipLaunchKernelGGL(k_skinny<1>, grid, dim3(256), 0, st, A, sAm, sAk, bsA, B, bsB, C, bsC, M, K, N, alpha);
+  else hipLaunchKernelGGL(k_skinny<2>, grid, dim3(256), 0, st, A, sAm, sAk, bsA, B, bsB, C, bsC, M, K, N, alpha);
   CHK_LAUNCH();
   return 0;
 }

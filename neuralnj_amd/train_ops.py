@@ -33,6 +33,7 @@ _SIGS = {
     "nnjt_abi_version": ([], C.c_int),
     "nnjt_last_error": ([], C.c_char_p),
     "nnjt_gemm_run": ([C.POINTER(Gemm), _vp], C.c_int),
+    "nnjt_skinny_gemm": ([_vp, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _i32, _i32, _i32, _i64, C.c_float, _vp], C.c_int),
     "nnjt_wgrad64": ([_vp, _vp, _vp, _i64, _i64, _vp], C.c_int),
     "nnjt_add_bias": ([_vp, _vp, _i64, _i32, _vp], C.c_int),
     "nnjt_colsum": ([_vp, _vp, _i64, _i32, _vp], C.c_int),
@@ -514,6 +515,12 @@ class Bmm(torch.autograd.Function):
 
 def _bgemm(A, B, Cout, nb, M, N, K, sA, sB, sC, bsA, bsB, bsC, alpha):
     """batched product with a long-contraction path and the 65535-entry grid limit handled here"""
+    if M <= 64 and K <= 64 and N >= 4096 and N % 64 == 0 and nb <= 65535 and sB == (N, 1) and sC == (N, 1) \
+            and bsB == K * N and bsC == M * N:
+        # few rows times sites x features (x_g of the pair scorer, and the state's gradient through it)
+        _chk(load_library().nnjt_skinny_gemm(_p(A), sA[0], sA[1], bsA, _p(B), bsB, _p(Cout), bsC, nb, M, K, N, alpha,
+                                             _st(Cout)))
+        return
     piece = _piece(M, N, K, nb) if nb <= 64 else 0
     if piece and sC == (N, 1) and bsC == M * N and Cout.is_contiguous():
         # long contractions of a small batch (the pair scorer's logits over sites x features, one entry per alignment

@@ -73,6 +73,12 @@ def test_operators_match_torch():
     _grad_pair(lambda a, b: T.Bmm.apply(a, b, True, 0.3), lambda a, b: 0.3 * a @ b.transpose(1, 2), [R(6, 70, 40), R(6, 33, 40)])
     _grad_pair(lambda a, b: T.Bmm.apply(a, b, False, 1.0), lambda a, b: a @ b, [R(6, 70, 33), R(6, 33, 40)])
     _grad_pair(lambda a, b: T.Bmm.apply(a, b, True, 1.0), lambda a, b: a @ b.transpose(1, 2), [R(2, 9, 20000), R(2, 7, 20000)], tol=5e-5)  # long k
+    # few rows times sites x features (nnjt_skinny_gemm forward and for the second operand's gradient; the first
+    # operand's gradient is a long contraction of a small batch)
+    _grad_pair(lambda a, b: T.Bmm.apply(a, b, False, 0.7), lambda a, b: 0.7 * a @ b, [R(3, 50, 26), R(3, 26, 8192)], tol=5e-5)
+    _grad_pair(lambda a, b: T.Bmm.apply(a, b, False, 1.0), lambda a, b: a @ b, [R(2, 7, 33), R(2, 33, 4096)], tol=5e-5)
+    _grad_pair(lambda a, b: T.Bmm.apply(a, b, False, 1.0), lambda a, b: a @ b, [R(5, 64, 64), R(5, 64, 4160)], tol=5e-5)
+    _grad_pair(lambda a, b: T.Bmm.apply(a, b, False, 1.0), lambda a, b: a @ b, [R(1, 1, 3), R(1, 3, 4096)], tol=5e-5)
 
 
 @pytest.mark.parametrize("name", ["b2_t6_l48_pad", "b2_t8_l128_s0", "b1_t20_l256_s1", "b1_t50_l1024_s0"])
