@@ -113,10 +113,10 @@ def gemm(A, B, Cout, M, N, K, sA, sB, sC, nb=(1, 1), bA=(0, 0), bB=(0, 0), bC=(0
 
 
 def _piece(M, N, K, nb=1):
-    """length of the pieces a contraction of length K is cut into: enough pieces that the launch has a few hundred
+    """length of the pieces a contraction of length K is cut into: enough pieces that the launch has about a thousand
     workgroups (one 128 x 64 output tile per piece and batch entry), none shorter than 64; 0 = do not cut"""
     tiles = ((M + 127) // 128) * ((N + 63) // 64) * nb
-    want = max(1, 256 // tiles)
+    want = max(1, 1024 // tiles)                             # four workgroups per CU: each is a chain of load -> LDS -> barrier
     if want == 1 or K < 128:
         return 0
     piece = max(64, -(-K // want))
