@@ -1410,9 +1410,7 @@ int lik_eval(nnj_handle* h, const uint8_t* codes, int nA, const LikModel& md, co
 int lik_common(nnj_handle* h, const uint8_t* codes, int nA, const uint8_t* mask, const int32_t* merges, const float* brlen_in,
                const nnj_subst_model* model, int B, int T, int L, void* ws, size_t ws_bytes, LikModel& md, LikWs& w,
                double*& base, hipStream_t st) {
-  if (!h) return fail(nullptr, NNJ_ERR_ARG, "null handle");
-  DevGuard dev_guard;
-  HIPCHK(h, hipSetDevice(h->cfg.device));
+  // (the caller holds the DevGuard and has selected the handle's device: it covers every launch of the entry point)
   if (!codes || !merges || !model || B <= 0 || T < 2 || T > 256 || L <= 0 || (nA != 1 && nA != B))
     return fail(h, NNJ_ERR_ARG, "tree likelihood: bad argument (2 <= T <= 256, n_align = 1 or B)");
   if (int rc = build_model(model, md, h->err)) return rc;
@@ -1446,6 +1444,9 @@ int nnj_tree_loglik(nnj_handle* h, const uint8_t* codes, int32_t n_align, const 
                     void* ws, size_t ws_bytes, void* stream) {
   LikModel md; LikWs w; double* base = nullptr;
   hipStream_t st = static_cast<hipStream_t>(stream);
+  if (!h) return fail(nullptr, NNJ_ERR_ARG, "null handle");
+  DevGuard dev_guard;                                      // for the whole call: every launch below goes to the handle's device
+  HIPCHK(h, hipSetDevice(h->cfg.device));
   if (!loglik_out) return fail(h, NNJ_ERR_ARG, "nnj_tree_loglik: null output");
   if (int rc = lik_common(h, codes, n_align, mask, merges, brlen, model, B, T, L, ws, ws_bytes, md, w, base, st)) return rc;
   lik_eval(h, codes, n_align, md, w, base, base + w.brlen, loglik_out, B, T, L, st);
@@ -1458,10 +1459,16 @@ int nnj_tree_optimize(nnj_handle* h, const uint8_t* codes, int32_t n_align, cons
                       float* brlen_out, double* loglik_out, void* ws, size_t ws_bytes, void* stream) {
   LikModel md; LikWs w; double* base = nullptr;
   hipStream_t st = static_cast<hipStream_t>(stream);
+  if (!h) return fail(nullptr, NNJ_ERR_ARG, "null handle");
+  DevGuard dev_guard;                                      // for the whole call: every launch below goes to the handle's device
+  HIPCHK(h, hipSetDevice(h->cfg.device));
   if (!loglik_out || sweeps < 0) return fail(h, NNJ_ERR_ARG, "nnj_tree_optimize: bad argument");
   if (int rc = lik_common(h, codes, n_align, mask, merges, brlen_in, model, B, T, L, ws, ws_bytes, md, w, base, st)) return rc;
   const int NN = 2 * T - 2;
   const int* prog = reinterpret_cast<const int*>(base + w.prog);
+  // the two child edges of the last join are one edge of the unrooted tree: folded for the sweeps, split on export
+  if (sweeps > 0)
+    hipLaunchKernelGGL(k_lik_root_fold, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, st, prog, base + w.brlen, B, T, 0);
   lik_eval(h, codes, n_align, md, w, base, base + w.brlen, base + w.ll, B, T, L, st);
   for (int sw = 0; sw < sweeps; ++sw) {
     // partials on both sides of every edge from the current lengths (pmat and down are current), then one
@@ -1469,7 +1476,7 @@ int nnj_tree_optimize(nnj_handle* h, const uint8_t* codes, int32_t n_align, cons
     hipLaunchKernelGGL(k_lik_outer, dim3((unsigned)((L + 127) / 128), (unsigned)B), dim3(128), 0, st, codes, n_align, prog,
                        (const double*)(base + w.pmat), md, (const double*)(base + w.down), base + w.outer, T, L);
     hipLaunchKernelGGL(k_lik_newton, dim3((unsigned)NN, (unsigned)B), dim3(256), 0, st, codes, n_align,
-                       (const double*)(base + w.inv), (const double*)(base + w.down), (const double*)(base + w.outer), md,
+                       (const double*)(base + w.inv), (const double*)(base + w.down), (const double*)(base + w.outer), md, prog,
                        (const double*)(base + w.brlen), base + w.brlen_new, T, L, 12);
     // a simultaneous update of all edges can overshoot: take the full step if the likelihood does not drop, else
     // half of it, a quarter, an eighth (per tree, decided on the device)
@@ -1486,6 +1493,8 @@ int nnj_tree_optimize(nnj_handle* h, const uint8_t* codes, int32_t n_align, cons
   HIPCHK(h, hipMemcpyAsync(loglik_out, base + w.ll, (size_t)B * sizeof(double), hipMemcpyDeviceToDevice, st));
   if (brlen_out) {
     const int ne = B * (T - 1) * 2;
+    if (sweeps > 0)
+      hipLaunchKernelGGL(k_lik_root_fold, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, st, prog, base + w.brlen, B, T, 1);
     hipLaunchKernelGGL(k_lik_brlen_export, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, st, prog,
                        (const double*)(base + w.brlen), brlen_out, B, T);
   }

@@ -67,6 +67,21 @@ __global__ void k_lik_brlen_export(const int* __restrict__ prog, const double* _
   brlen_merge[i] = (float)brlen[(size_t)b * (2 * T - 2) + prog[i]];
 }
 
+// The two child edges of the last join are ONE edge of the unrooted tree (pulley principle: under a reversible model
+// the likelihood depends on their sum only).  Optimised as two edges by a Jacobi sweep, each is solved with the other
+// held at its old value -- t1' = s* - t2, t2' = s* - t1 -- and the sum is mirrored about the optimum (2 s* - s)
+// instead of converging.  So the pair is kept FOLDED while lengths are optimised (all of the sum on the first child,
+// 1e-8 on the second, which k_lik_newton leaves alone) and split evenly when lengths are exported.
+__global__ void k_lik_root_fold(const int* __restrict__ prog, double* __restrict__ brlen, int B, int T, int split) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const int* pr = prog + ((size_t)b * (T - 1) + (T - 2)) * 2;
+  double* t = brlen + (size_t)b * (2 * T - 2);
+  const double s = t[pr[0]] + t[pr[1]];
+  if (split) { t[pr[0]] = 0.5 * s; t[pr[1]] = 0.5 * s; }
+  else { t[pr[0]] = fmax(s - 1e-8, 1e-8); t[pr[1]] = 1e-8; }
+}
+
 // P(t) = U diag(exp(lam * rate_c * t)) Uinv for every (tree, node, category)
 __global__ void k_lik_pmats(const double* __restrict__ brlen, LikModel md, double* __restrict__ pmat, int total) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;     // (b, v, c)
@@ -235,11 +250,16 @@ __global__ __launch_bounds__(128) void k_lik_outer(const uint8_t* __restrict__ c
 __global__ __launch_bounds__(256) void k_lik_newton(const uint8_t* __restrict__ codes, int n_align,
                                                     const double* __restrict__ inv, const double* __restrict__ down,
                                                     const double* __restrict__ outer, LikModel md,
+                                                    const int* __restrict__ prog,
                                                     const double* __restrict__ brlen, double* __restrict__ brlen_new,
                                                     int T, int L, int iters) {
   __shared__ double red[2][256];
   const int v = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
   const int nc = md.ncat, NN = 2 * T - 2;
+  if (v == prog[((size_t)b * (T - 1) + (T - 2)) * 2 + 1]) {     // second child of the last join: folded into the first (k_lik_root_fold)
+    if (tid == 0) brlen_new[(size_t)b * NN + v] = brlen[(size_t)b * NN + v];
+    return;
+  }
   const uint8_t* cdb = codes + (size_t)(n_align == 1 ? 0 : b) * T * L;
   const double* ivb = inv + (size_t)(n_align == 1 ? 0 : b) * L;
   const double* Db = down + (size_t)b * (T - 1) * nc * 4 * L;

@@ -107,18 +107,30 @@ def load_pi_instance(path):
     }
 
 
+_PHY_UNKNOWN = str.maketrans({"?": "N", ".": "N"})
+
+
 def load_phy_file(file_path):
-    """Reference phydata.py:478-496: sequential PHYLIP, one 'name sequence' line per taxon ('?' and '.' read as N)."""
+    """Strictly sequential PHYLIP -- every record on ONE line, `name` then the sequence (blanks inside it allowed) --
+    with the character policy of the reference's reader of that format (phydata.py:478-496): upper case, '?' and '.'
+    read as N, nothing else rewritten (load_phy_file_multirow, which the drivers use, maps every symbol outside the
+    alphabet to a gap instead).  A taxon name that occurs again replaces the earlier record but keeps its place.
+    Raises AssertionError, like the reference, when the header's counts do not match the records."""
+    order, seq_of = [], {}
     with open(file_path, "r") as f:
-        lines = [ln for ln in f.readlines() if ln.strip()]
-    num_sequences, sequence_length = map(int, lines[0].split())
-    sequences = {}
-    for line in lines[1:]:
-        parts = line.split()
-        sequences[parts[0]] = "".join(parts[1:]).upper().replace("?", "N").replace(".", "N")
-    assert num_sequences == len(sequences)
-    assert sequence_length == len(next(iter(sequences.values())))
-    return list(sequences.values()), list(sequences.keys()), num_sequences, sequence_length
+        want_taxa, want_sites = (int(tok) for tok in f.readline().split()[:2])
+        for record in f:
+            fields = record.split()
+            if not fields:
+                continue
+            name = fields[0]
+            if name not in seq_of:
+                order.append(name)
+            seq_of[name] = "".join(fields[1:]).upper().translate(_PHY_UNKNOWN)
+    seqs = [seq_of[name] for name in order]
+    assert len(order) == want_taxa, f"{file_path}: header says {want_taxa} taxa, file holds {len(order)}"
+    assert seqs and len(seqs[0]) == want_sites, f"{file_path}: header says {want_sites} sites"
+    return seqs, order, want_taxa, want_sites
 
 
 def load_tree_file(file_path, device=None, pos=5):

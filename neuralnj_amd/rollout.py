@@ -176,7 +176,7 @@ def search_inference(cfgs, test_dir, write_dir, stop_step=100, device="cuda", mo
 
 
 def reinforce_loss(batch, agent, env, forced_merges, tree_scores, baseline, temperature=1.0, entropy_reg_strength=0.01,
-                   device=None):
+                   device=None, replicas=None):
     """One episode of the reference's RL_finetuning with gradients (finetune_rl_search.py:78-189 with eval=False, and
     the loss of :292-307): the model / environment calls of the reference's loop, differentiable (train_model.py: every
     operator a HIP forward + backward kernel), then
@@ -185,15 +185,30 @@ def reinforce_loss(batch, agent, env, forced_merges, tree_scores, baseline, temp
     business: sample with Nnj.rollout_sample and pass the merges here); `tree_scores` [B] are the rewards (the
     reference's raxml-ng log-likelihoods; likelihood.tree_optimize here).  The few table-sized operations of the
     reference's own driver (log_softmax, gather, the sums of the loss) are torch operations, as they are there.
+    `replicas`: True = the batch is B copies of ONE alignment (the caller built it: rl_finetuning), False = it is not,
+    None = find out by comparing the rows (2 (B-1) device comparisons, each a host synchronisation).
     Returns (loss, per-step tables)."""
-    device = device or next(agent.parameters()).device
+    device = torch.device(device or next(agent.parameters()).device)
+    if device.type == "cuda":
+        # the operator kernels of libnnj_train_hip.so launch on the CURRENT device (train_ops._st checks it)
+        with torch.cuda.device(device):
+            return _reinforce_loss(batch, agent, env, forced_merges, tree_scores, baseline, temperature,
+                                   entropy_reg_strength, device, replicas)
+    return _reinforce_loss(batch, agent, env, forced_merges, tree_scores, baseline, temperature, entropy_reg_strength,
+                           device, replicas)
+
+
+def _reinforce_loss(batch, agent, env, forced_merges, tree_scores, baseline, temperature, entropy_reg_strength, device,
+                    replicas):
     arr = batch["data"].to(device)
     mask = batch["seq_weights"].to(device) == 0
     env.init_states(batch["seqs"], batch["seq_keys"], arr)
     merges = np.asarray(forced_merges)
     B = merges.shape[0]
-    if B > 1 and agent._wants_grad() and all(torch.equal(arr[0], arr[b]) for b in range(1, B)) \
-            and all(torch.equal(mask[0], mask[b]) for b in range(1, B)):
+    if replicas is None:
+        replicas = B > 1 and all(torch.equal(arr[0], arr[b]) for b in range(1, B)) \
+            and all(torch.equal(mask[0], mask[b]) for b in range(1, B))
+    if B > 1 and replicas and agent._wants_grad():
         # replicas of ONE alignment (the batch of the reference's Search / Finetune loops): encoded once, the gradient
         # of the shared encoding is the sum over the replicas
         from .train_model import ExpandBatch
@@ -225,6 +240,7 @@ def reinforce_loss(batch, agent, env, forced_merges, tree_scores, baseline, temp
     scores = torch.as_tensor(tree_scores, dtype=torch.float32, device=device)
     policy_loss = (-(selected.sum(dim=1)) * (scores - baseline)).mean()
     entropy_reg = -sum([-torch.sum(torch.exp(lp) * lp, dim=1).mean() for lp in log_ps])
+    agent.__dict__["_train_keys"] = None          # (the key cache of train_model holds the last state: the graph keeps what it needs)
     return policy_loss + entropy_reg * entropy_reg_strength, tables
 
 
@@ -234,8 +250,9 @@ def rl_finetuning(cfgs, batch, agent, optimizer, env, stop_step=20, seed=0, mode
     sampled rollout of the current policy (nnj_rollout_sample: the fused inference kernels), its tree scored by
     log-likelihood on the GPU (likelihood.tree_optimize where the reference calls raxml-ng), the episode replayed with
     gradients (reinforce_loss), loss.backward(); after `cfgs.num_episodes` episodes the gradients are clipped by value
-    and the optimizer steps.  Baseline as in the reference: the first epoch's is one greedy (Argmax) rollout's score,
-    later ones the running maximum of the epoch means.  The reference's replay buffer re-injects nothing (its `sample`
+    and the optimizer steps.  Baseline as in the reference (finetune_rl_search.py:265-279): the first epoch's is the
+    score of ONE SAMPLED rollout of the policy (its reinforce_rollout(eval=True) leaves argmax=False), later ones the
+    running maximum of the epoch means.  The reference's replay buffer re-injects nothing (its `sample`
     returns None, utils.py:99), so every action here is sampled too; utils.ReplayBuffer keeps the same surface.
     `dist` (an initialised torch.distributed, one process per GPU): the episodes of an epoch are split over the ranks
     (every rank samples with its own stream), the gradients are summed by one all-reduce of one flat bucket per
@@ -258,11 +275,12 @@ def rl_finetuning(cfgs, batch, agent, optimizer, env, stop_step=20, seed=0, mode
         return ll.to(torch.float32), br
 
     with torch.no_grad():
-        greedy = ctx.rollout_argmax(codes, mask)["merges"]
-        baseline_val = float(score(greedy)[0][0])
+        u0 = torch.from_numpy(rng.random((1, T - 1)).astype(np.float32))
+        first = ctx.rollout_sample(codes, mask, u0, temperature=temperature, replicas=1)["merges"]
+        baseline_val = float(score(first)[0][0])
     best_tree, best_score, losses, batch_scores, step_cur = None, -np.inf, [], [], 0
     lo, hi = sharding.shard_bounds(int(cfgs.num_episodes), world, rank)
-    E = max(hi - lo, 1)                      # (a rank without an episode still runs one: every rank joins the all-reduce)
+    E = hi - lo                              # a rank without an episode samples nothing: it joins the all-reduce with zeros
     reps = {k: (v[:1] * E if isinstance(v, list) else v[:1].expand(E, *v.shape[1:])) for k, v in batch.items()}
     for epoch in range(1, int(cfgs.num_epoch) + 1):
         if epoch > 1 and batch_scores:
@@ -273,13 +291,21 @@ def rl_finetuning(cfgs, batch, agent, optimizer, env, stop_step=20, seed=0, mode
         # their gradients up (loss.backward() per episode, one optimizer step per epoch).  Here they run as ONE batch of
         # E replicas: sampled together, scored together, replayed with gradients together (the alignment encoded
         # once); E x the batch-mean loss is the sum of the E episode losses.
+        if E == 0:                           # (allreduce_gradients zero-fills parameters without a gradient)
+            step_cur += int(cfgs.num_episodes)
+            sharding.allreduce_gradients(agent.parameters(), dist)
+            torch.nn.utils.clip_grad_value_(agent.parameters(), clip_value=float(cfgs.clip_value))
+            optimizer.step()
+            if step_cur >= int(stop_step):
+                break
+            continue
         with torch.no_grad():
             u = torch.from_numpy(rng.random((E, T - 1)).astype(np.float32))
             merges = agent._context().rollout_sample(codes, mask, u, temperature=temperature, replicas=E)["merges"]
             agent._context().check_numeric()
             sc, br = score(merges)
         loss, _ = reinforce_loss(reps, agent, env, merges.cpu().numpy(), sc, baseline_val, temperature,
-                                 float(cfgs.entropy_reg_strength), device)
+                                 float(cfgs.entropy_reg_strength), device, replicas=True)
         (loss * E).backward()
         losses.append(float(loss.detach()))
         batch_scores.extend(float(v) for v in sc)

@@ -95,7 +95,13 @@ def _st(t):
     # the raw handle of torch's current stream (torch.cuda.current_stream builds a Stream object per call: 11 ms of an
     # episode's 7000 operator calls)
     idx = t.device.index
-    return _vp(torch._C._cuda_getCurrentRawStream(torch.cuda.current_device() if idx is None else idx))
+    cur = torch.cuda.current_device()
+    if idx is not None and idx != cur:
+        # the nnjt_* kernels launch on the current device: a tensor elsewhere would be computed on the wrong GPU, on a
+        # stream of another device.  rollout.reinforce_loss selects the device for the whole episode.
+        raise RuntimeError(f"libnnj_train_hip: tensor on cuda:{idx} but the current device is cuda:{cur}; "
+                           f"wrap the call in torch.cuda.device({idx})")
+    return _vp(torch._C._cuda_getCurrentRawStream(cur if idx is None else idx))
 
 
 def _need(t):

@@ -199,3 +199,17 @@ def test_reference_driver_import_lines_resolve():
         "print('ok')\n") % (repo, os.path.join(repo, "neuralnj_amd", "compat"))
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stderr[-2000:]
+
+
+def test_load_phy_file_sequential_policy(tmp_path):
+    """phydata.load_phy_file: one record per line, '?' and '.' read as N, upper case, a repeated name replaces the
+    earlier record in place, header mismatches raise AssertionError (reference phydata.py:478-496)."""
+    from neuralnj_amd import phydata
+    p = tmp_path / "a.phy"
+    p.write_text("3 8\nt1 acgt ac?.\nt2 ACGTAC-N\n\nt3 TTTTTTTT\nt2 GGGGGGGG\n")
+    seqs, keys, n, L = phydata.load_phy_file(str(p))
+    assert (keys, n, L) == (["t1", "t2", "t3"], 3, 8)
+    assert seqs == ["ACGTACNN", "GGGGGGGG", "TTTTTTTT"]
+    p.write_text("4 8\nt1 ACGTACGT\nt2 ACGTACGT\n")
+    with pytest.raises(AssertionError):
+        phydata.load_phy_file(str(p))

@@ -125,3 +125,53 @@ def test_hip_branch_length_optimisation():
     llw, _ = lk.tree_optimize(g, codes, wrong[None], None, m, sweeps=3)
     assert lls[-1] > llw.item() + 10
     g.close()
+
+
+@pytest.mark.gpu
+def test_hip_root_edge_is_one_edge():
+    """The two child edges of the last join are one edge of the unrooted tree.  Two taxa under JC69: with p the share
+    of differing sites the ML distance is -3/4 ln(1 - 4p/3) in closed form; the optimiser must reach it after ONE
+    sweep and stay there (a Jacobi update of the two halves mirrors the sum about the optimum instead), from a
+    symmetric and from a lopsided start, and the exported halves must add up to it.  Then the same on the root edge of
+    a four-taxon tree against scipy."""
+    from scipy.optimize import minimize_scalar
+    from neuralnj_amd import likelihood as lk, utils
+    from neuralnj_amd._lib import Nnj
+    rng = np.random.default_rng(3)
+    L = 2000
+    a = rng.integers(0, 4, size=L)
+    b = a.copy()
+    flip = rng.random(L) < 0.2
+    b[flip] = (a[flip] + rng.integers(1, 4, size=int(flip.sum()))) % 4
+    codes = np.stack([a, b]).astype(np.uint8)[None]
+    p = float((a != b).mean())
+    d = -0.75 * np.log(1.0 - 4.0 * p / 3.0)
+    g = Nnj(utils.shipped_config(), "cuda:0")
+    m = lk.subst_model(**JC)
+    merges = np.array([[[0, 1]]], np.int32)
+    want = LO.tree_loglik(codes[0], merges[0], np.array([[0.5 * d, 0.5 * d]]), JC)
+    for start in ([[0.1, 0.1]], [[0.9, 0.02]], [[0.01, 0.01]]):
+        for sweeps in (1, 3):
+            ll, br = lk.tree_optimize(g, codes, merges, np.array([start], np.float32), m, sweeps=sweeps)
+            br = br.cpu().numpy()[0, 0].astype(np.float64)
+            assert abs(br.sum() - d) < 2e-5 * d, (start, sweeps, br, d)
+            assert abs(ll.item() - want) < 1e-6, (start, sweeps, ll.item(), want)
+    # four taxa, GTR+I+G: all lengths but the root pair's held at their values, the sum of the pair scanned by scipy
+    T = 4
+    codes4 = rng.integers(0, 4, size=(1, T, 600)).astype(np.uint8)
+    codes4[0, 1] = np.where(rng.random(600) < 0.8, codes4[0, 0], codes4[0, 1])
+    codes4[0, 3] = np.where(rng.random(600) < 0.7, codes4[0, 2], codes4[0, 3])
+    mg = np.array([[[0, 1], [1, 2], [0, 1]]], np.int32)
+    mod = dict(GTR)
+    ll1, br1 = lk.tree_optimize(g, codes4, mg, None, lk.subst_model(**mod), sweeps=1)
+    ll6, br6 = lk.tree_optimize(g, codes4, mg, None, lk.subst_model(**mod), sweeps=8)
+    brn = br6.cpu().numpy()[0].astype(np.float64)
+
+    def neg(s):
+        bb = brn.copy()
+        bb[-1] = [0.5 * s, 0.5 * s]
+        return -LO.tree_loglik(codes4[0], mg[0], bb, mod)
+    best = minimize_scalar(neg, bounds=(1e-6, 3.0), method="bounded", options=dict(xatol=1e-9))
+    assert abs(brn[-1].sum() - best.x) < 1e-3 * max(best.x, 1e-2), (brn[-1], best.x)
+    assert ll6.item() >= ll1.item() - 1e-9
+    g.close()
