@@ -18,6 +18,7 @@
 #include "nnj_scorer.hpp"
 #include "nnj_scorer16.hpp"
 #include "nnj_scorer_wide.hpp"
+#include "nnj_step2.hpp"
 #include "nnj_likelihood.hpp"
 
 namespace {
@@ -25,13 +26,13 @@ namespace {
 enum ProfKind {
   PK_EMBED = 0, PK_TOK1, PK_FFN, PK_ROW_XF, PK_PAIR_ALPHA, PK_ALPHA_SOFTMAX,
   PK_PAIR_SCORE, PK_ASSEMBLE, PK_AGG_ALPHA, PK_AGG_FINISH, PK_MISC, PK_PAIR_ALPHA_INCR, PK_PAIR_SCORE_INCR,
-  PK_ROW_QKV, PK_ROW_S, PK_ROW_PV,
+  PK_ROW_QKV, PK_ROW_S, PK_ROW_PV, PK_STEP_SMALL,
   PK_COUNT
 };
 const char* const kProfNames[PK_COUNT] = {
     "k_embed", "k_tok1", "k_ffn", "k_row_xf", "k_pair_alpha", "k_alpha_softmax",
     "k_pair_score", "k_assemble_argmax", "k_agg_alpha", "k_agg_finish", "misc", "k_pair_alpha_incr",
-    "k_pair_score_incr", "k_qkv6", "k_row_s", "k_row_pv"};
+    "k_pair_score_incr", "k_qkv6", "k_row_s", "k_row_pv", "k_step_small"};
 
 char g_err[512] = "";
 
@@ -56,6 +57,8 @@ struct nnj_handle {
   int num_cu = 256;              // compute units of the device (persistent-kernel grid size)
   int* d_flag = nullptr;         // sticky "a pair score was not finite" flag (nnj_numeric_status)
   int concurrency = 2;           // sub-batches of a rollout that run on streams of their own (nnj_set_concurrency)
+  int two_pass = 1;              // rollouts run the two-pass NJ step (nnj_step2.hpp); NNJ_TWO_PASS=0 selects the four-pass kernels
+  int two_pass_cand = 1;         // ... and carry the candidate pair's logits along (NNJ_TWO_PASS_CAND=0: fallback pass instead)
   // small batches: the ~370 launches of a rollout are captured once into a hipGraph and replayed while the call's
   // arguments stay the same (launch-bound regime: BASELINE configs[1], one alignment per rollout)
   struct GraphKey {
@@ -241,19 +244,26 @@ PairGeom pair_geom(int mode, int n, int B, int C) {
   return g;
 }
 
+// beta partials per row: one per 32 sites from k_row_xf / k_agg_finish, one per workgroup from k_step_alpha (which
+// may run more workgroups per alignment than there are 32-site tiles when the batch is small); unused entries are 0
+int beta_stride(int B, int C) {
+  const int nt32 = (C + 31) / 32;
+  return std::max(nt32, pair_geom(PAIRS_INCR, 2, B, C).blocks);
+}
+
 // workspace regions of the NJ loop (after the state/slots buffer), in floats
 struct LoopWs {
-  size_t U, Kp, beta, alpha_part, alpha, score_part, full, agg_part, logits0, logits1, merged, live, ij, zmask, end;
+  size_t U, Kp, beta, alpha_part, alpha, score_part, full, agg_part, logits0, logits1, merged, live, ij, zmask;
+  size_t lam, beta_tot, acand, Xc, am, need, cand, cand_run, end;      // the two-pass step (nnj_step2.hpp)
 };
 LoopWs loop_ws(int B, int T, int C) {
   LoopWs w;
   const size_t rows = (size_t)B * T * C * 64;
-  const int nt32 = (C + 31) / 32;
   size_t o = 0;
   auto take = [&](size_t n) { size_t r = o; o += align_up(n, 64); return r; };
   w.U = take(rows);
   w.Kp = take(rows);
-  w.beta = take((size_t)B * T * nt32);
+  w.beta = take((size_t)B * T * beta_stride(B, C));
   size_t ap = 0, al = 0, sp = 0, fu = 0;
   const int Tn = std::min(T, 64);                                  // the 64-row kernels
   for (int mode = 0; mode < 2; ++mode)
@@ -285,6 +295,14 @@ LoopWs loop_ws(int B, int T, int C) {
   w.live = take((size_t)2 * B * T);            // two lists (current / next step)
   w.ij = take((size_t)B * 2 + 2);
   w.zmask = take(((size_t)B * C + 3) / 4);       // all-false site mask for callers that pass none (bytes)
+  w.lam = take((size_t)B * 4096);
+  w.beta_tot = take((size_t)B * 64);
+  w.acand = take((size_t)B * pair_geom(PAIRS_INCR, 2, B, C).blocks * 64);
+  w.Xc = take((size_t)B * C * 64);
+  w.am = take((size_t)B * 64);
+  w.need = take((size_t)B);
+  w.cand = take((size_t)B * 4);                  // two lists of (a, b): this step's candidate / the next one's
+  w.cand_run = take((size_t)B);
   w.end = o;
   return w;
 }
@@ -462,11 +480,13 @@ int run_encoder(nnj_handle* h, const uint8_t* codes, const uint8_t* mask, float*
 // ------------------------------------------------------------------ NJ-loop launches
 int launch_row_xf(nnj_handle* h, const float* S, float* U, float* Kp, float* beta, long bstride, int slots,
                   int rows, int B, int C, hipStream_t st) {
+  // (beta entries beyond the 32-site tiles of a row stay 0: see beta_stride)
+  HIPCHK(h, hipMemsetAsync(beta, 0, (size_t)B * slots * beta_stride(B, C) * sizeof(float), st));
   Scope sc(h, st, PK_ROW_XF);
   const int nt32 = (C + 31) / 32;
   const size_t lds = 2 * 4096 * sizeof(float);
   hipLaunchKernelGGL(k_row_xf, dim3((unsigned)((nt32 + 3) / 4), (unsigned)rows, (unsigned)B), dim3(256), lds, st, S,
-                     U, Kp, beta, scorer_ptrs(h), bstride, slots, C, nt32);
+                     U, Kp, beta, scorer_ptrs(h), bstride, slots, C, nt32, beta_stride(B, C));
   return NNJ_OK;
 }
 
@@ -566,27 +586,27 @@ int launch_pair_scores(nnj_handle* h, const RowSet& rs, const int* ij_prev, cons
         if (has_ctx) {
           if (int rc = set_lds(h, k_inc_score16<1, true>, lds)) return rc;
           hipLaunchKernelGGL((k_inc_score16<1, true>), grid, blk16, lds, st, rs, sw, ij_prev, base + w.alpha, mask,
-                             base + w.score_part, n, C, g.cs);
+                             base + w.score_part, n, C, g.cs, 0);
         } else {
           if (int rc = set_lds(h, k_inc_score16<1, false>, lds)) return rc;
           hipLaunchKernelGGL((k_inc_score16<1, false>), grid, blk16, lds, st, rs, sw, ij_prev, base + w.alpha, mask,
-                             base + w.score_part, n, C, g.cs);
+                             base + w.score_part, n, C, g.cs, 0);
         }
       } else if (n > 32 && n <= 48) {                      // three 16-row tiles: 48 instead of 64 padded pairs,
         const size_t lds = (size_t)(3 * IMG64 + 8 * (64 * 48 * NPL / 2) + SCORER_CONSTS + 3 * 1024) * sizeof(float);   // one wave per site; + alpha pieces
         if (int rc = set_lds(h, k_inc_score_w<3, true>, lds)) return rc;
         hipLaunchKernelGGL((k_inc_score_w<3, true>), grid, dim3(512), lds, st, rs, sw, ij_prev, base + w.alpha, mask,
-                           base + w.score_part, n, C, g.cs);
+                           base + w.score_part, n, C, g.cs, 0);
       } else if (n > 32) {
         const size_t lds = (size_t)(3 * IMG64 + 4 * b6_floats(64, 64) + 16 + SCORER_CONSTS) * sizeof(float);
         if (int rc = set_lds(h, k_inc_score<2, true>, lds)) return rc;
         hipLaunchKernelGGL((k_inc_score<2, true>), grid, dim3(512), lds, st, rs, sw, ij_prev, base + w.alpha, mask,
-                           base + w.score_part, n, C, g.cs, h->d_flag);
+                           base + w.score_part, n, C, g.cs, h->d_flag, 0);
       } else {                                             // 17..32: the 32-pair kernel (k_inc_score_w<2> with 8 or 12 waves measured 2-3 ms per rollout slower)
         const size_t lds = (size_t)(3 * IMG64 + 8 * b6_floats(64, 32) + 16 + SCORER_CONSTS) * sizeof(float);
         if (int rc = set_lds(h, k_inc_score<1, true>, lds)) return rc;
         hipLaunchKernelGGL((k_inc_score<1, true>), grid, dim3(512), lds, st, rs, sw, ij_prev, base + w.alpha, mask,
-                           base + w.score_part, n, C, g.cs, h->d_flag);
+                           base + w.score_part, n, C, g.cs, h->d_flag, 0);
       }
     }
     return NNJ_OK;
@@ -612,6 +632,104 @@ int launch_pair_scores(nnj_handle* h, const RowSet& rs, const int* ij_prev, cons
     if (int rc = set_lds(h, k_pair_score<1, 8>, lds)) return rc;
     hipLaunchKernelGGL((k_pair_score<1, 8>), grid, dim3(512), lds, st, rs, sw, ij_prev, base + w.alpha, mask,
                        base + w.score_part, mode, n, C, g.npairs, g.ppad, g.cs, has_ctx, g.nsc, g.pg, B);
+  }
+  return NNJ_OK;
+}
+
+// ---- the two-pass NJ step (nnj_step2.hpp).  `rs` lists the rows AFTER the merge of `ij` (n rows, merged row at
+// position ij[0], whose slot still holds S_i); live_old = the list before it.  Produces the merged row in place and
+// the score partials of the n-1 new pairs (q numbering) in w.score_part.
+struct Step2 {
+  bool fallback;      // the previous table kernel may have left `need` set: launch the per-alignment fallback
+  bool cand;          // carry the candidate pair's logits along
+  int* cand_cur;      // [B][2]
+};
+int launch_step2(nnj_handle* h, RowSet rs, const int* live_old, const int* ij, const uint8_t* mask, float* base,
+                 const LoopWs& w, const Step2& o, int n, int B, int C, PairGeom& g, hipStream_t st) {
+  const ScorerW sw = scorer_ptrs(h);
+  float* S_w = const_cast<float*>(rs.S);
+  float* U_w = const_cast<float*>(rs.U);
+  g = pair_geom(PAIRS_INCR, n, B, C);
+  g.score_src = base + w.score_part;
+  int* need = reinterpret_cast<int*>(base + w.need);
+  int* cand_run = reinterpret_cast<int*>(base + w.cand_run);
+  const int T = rs.live_stride;
+  if (o.fallback) {
+    // weights of the merge for the alignments whose pick was neither a pair of the last step nor the candidate
+    Scope sc(h, st, PK_STEP_SMALL);
+    RowSet ro = rs;
+    ro.live = live_old;
+    const size_t lds = (size_t)IMG64 * sizeof(float);
+    hipLaunchKernelGGL(k_pair_xp, dim3((unsigned)((C + 127) / 128), (unsigned)B), dim3(256), lds, st, rs.S, rs.U, rs.bstride,
+                       live_old, T, sw, ij, (const int*)need, base + w.merged, n + 1, C);
+    const int nch = (C + 15) / 16, rp = T > 128 ? 256 : (T > 64 ? 128 : 64);
+    hipLaunchKernelGGL(k_agg_dot, dim3((unsigned)nch, (unsigned)B), dim3(256), 0, st, ro, (const float*)(base + w.merged),
+                       (const int*)need, base + w.agg_part, n + 1, C, rp);
+    hipLaunchKernelGGL(k_agg_am, dim3((unsigned)B), dim3(64), 0, st, ro, sw, ij, (const int*)need,
+                       (const float*)(base + w.agg_part), nch, rp, rs.ntile32, base + w.am, n + 1, C);
+  }
+  const bool cand = o.cand && n > 2;
+  if (cand) {
+    Scope sc(h, st, PK_STEP_SMALL);
+    const size_t lds = (size_t)IMG64 * sizeof(float);
+    hipLaunchKernelGGL(k_pair_xp, dim3((unsigned)((C + 127) / 128), (unsigned)B), dim3(256), lds, st, rs.S, rs.U, rs.bstride,
+                       rs.live, T, sw, (const int*)o.cand_cur, (const int*)cand_run, base + w.Xc, n, C);
+  }
+  StepIO io;
+  io.ij = ij; io.live_old = live_old; io.am = base + w.am; io.alpha_part = base + w.alpha_part;
+  io.S_w = S_w; io.U_w = U_w; io.beta_w = const_cast<float*>(rs.beta_part); io.beta_n = rs.ntile32;
+  io.cand = cand ? o.cand_cur : nullptr; io.Xc = base + w.Xc; io.acand_part = base + w.acand;
+  const int np = n - 1;                                    // pairs = rows other than the merged one
+  const int ng = np > 48 ? 4 : (np > 32 ? 3 : (np > 16 ? 2 : 1));
+  const dim3 grid((unsigned)g.blocks, (unsigned)B);
+  {
+    Scope sc(h, st, PK_PAIR_ALPHA_INCR);
+#define NNJ_SA(NG, NW)                                                                                          \
+  case NG: {                                                                                                    \
+    const size_t lds = (size_t)(3 * IMG64 + NW * 1024 + (NW / NG) * (64 * NG + 64 * 6) + 16 + SCORER_CONSTS +   \
+                                (NW / NG) * 66 + 16) * sizeof(float);                                           \
+    if (int rc = set_lds(h, (k_step_alpha<NG, NW>), lds)) return rc;                                            \
+    hipLaunchKernelGGL((k_step_alpha<NG, NW>), grid, dim3(64 * NW), lds, st, rs, sw, io, n, C, g.cs, h->d_flag); \
+  } break;
+    switch (ng) { NNJ_SA(1, 12) NNJ_SA(2, 12) NNJ_SA(3, 12) NNJ_SA(4, 12) }
+#undef NNJ_SA
+  }
+  const bool has_ctx = n > 2;
+  if (has_ctx) {
+    Scope sc(h, st, PK_ALPHA_SOFTMAX);
+    hipLaunchKernelGGL(k_step_softmax, dim3(16, (unsigned)B), dim3(256), 0, st, rs, sw, ij, (const float*)(base + w.alpha_part),
+                       base + w.alpha, base + w.lam, base + w.beta_tot, rs.ntile32, n, C, g.blocks);
+  }
+  {
+    Scope sc(h, st, PK_PAIR_SCORE_INCR);
+    const dim3 blk16(64 * T16_WAVES);
+    if (np <= 16) {
+      const size_t lds = (size_t)(3 * IMG64 + T16_WAVES * 512 * NPL + 16 + SCORER_CONSTS) * sizeof(float);
+      if (has_ctx) {
+        if (int rc = set_lds(h, k_inc_score16<1, true>, lds)) return rc;
+        hipLaunchKernelGGL((k_inc_score16<1, true>), grid, blk16, lds, st, rs, sw, ij, base + w.alpha, mask,
+                           base + w.score_part, n, C, g.cs, 1);
+      } else {
+        if (int rc = set_lds(h, k_inc_score16<1, false>, lds)) return rc;
+        hipLaunchKernelGGL((k_inc_score16<1, false>), grid, blk16, lds, st, rs, sw, ij, base + w.alpha, mask,
+                           base + w.score_part, n, C, g.cs, 1);
+      }
+    } else if (np > 32 && np <= 48) {
+      const size_t lds = (size_t)(3 * IMG64 + 8 * (64 * 48 * NPL / 2) + SCORER_CONSTS + 3 * 1024) * sizeof(float);
+      if (int rc = set_lds(h, k_inc_score_w<3, true>, lds)) return rc;
+      hipLaunchKernelGGL((k_inc_score_w<3, true>), grid, dim3(512), lds, st, rs, sw, ij, base + w.alpha, mask,
+                         base + w.score_part, n, C, g.cs, 1);
+    } else if (np > 32) {
+      const size_t lds = (size_t)(3 * IMG64 + 4 * b6_floats(64, 64) + 16 + SCORER_CONSTS) * sizeof(float);
+      if (int rc = set_lds(h, k_inc_score<2, true>, lds)) return rc;
+      hipLaunchKernelGGL((k_inc_score<2, true>), grid, dim3(512), lds, st, rs, sw, ij, base + w.alpha, mask,
+                         base + w.score_part, n, C, g.cs, h->d_flag, 1);
+    } else {
+      const size_t lds = (size_t)(3 * IMG64 + 8 * b6_floats(64, 32) + 16 + SCORER_CONSTS) * sizeof(float);
+      if (int rc = set_lds(h, k_inc_score<1, true>, lds)) return rc;
+      hipLaunchKernelGGL((k_inc_score<1, true>), grid, dim3(512), lds, st, rs, sw, ij, base + w.alpha, mask,
+                         base + w.score_part, n, C, g.cs, h->d_flag, 1);
+    }
   }
   return NNJ_OK;
 }
@@ -650,7 +768,7 @@ RowSet dense_rowset(nnj_handle* h, const float* state, float* base, const LoopWs
                     hipStream_t st) {
   RowSet rs;
   rs.S = state; rs.U = base + w.U; rs.Kp = base + w.Kp; rs.beta_part = base + w.beta;
-  rs.bstride = (long)n * C * 64; rs.live = nullptr; rs.live_stride = 0; rs.ntile32 = (C + 31) / 32;
+  rs.bstride = (long)n * C * 64; rs.live = nullptr; rs.live_stride = 0; rs.ntile32 = beta_stride(B, C);
   launch_row_xf(h, state, base + w.U, base + w.Kp, base + w.beta, rs.bstride, n, n, B, C, st);
   return rs;
 }
@@ -684,7 +802,7 @@ SessView sess_view(void* ws, int B, int T0, int C) {
   v.live = reinterpret_cast<int*>(v.base + v.w.live);
   v.ijs = reinterpret_cast<int*>(v.base + v.w.ij);
   v.rs.S = v.S; v.rs.U = v.base + v.w.U; v.rs.Kp = v.base + v.w.Kp; v.rs.beta_part = v.base + v.w.beta;
-  v.rs.bstride = (long)T0 * C * 64; v.rs.live = v.live; v.rs.live_stride = T0; v.rs.ntile32 = (C + 31) / 32;
+  v.rs.bstride = (long)T0 * C * 64; v.rs.live = v.live; v.rs.live_stride = T0; v.rs.ntile32 = beta_stride(B, C);
   return v;
 }
 // start a session from a dense tensor of T0 rows: copy into the slots, identity live list, row transforms
@@ -746,6 +864,8 @@ int nnj_create(const nnj_config* cfg, nnj_handle** out) {
     return fail(nullptr, NNJ_ERR_NO_DEVICE, "device %d is %s; libnnj_hip.so is built for gfx950 only", cfg->device, prop.gcnArchName);
   nnj_handle* h = new nnj_handle();
   h->cfg = *cfg;
+  if (const char* e = getenv("NNJ_TWO_PASS")) h->two_pass = atoi(e);
+  if (const char* e = getenv("NNJ_TWO_PASS_CAND")) h->two_pass_cand = atoi(e);
   h->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   if (hipSetDevice(cfg->device) != hipSuccess || hipMalloc(&h->d_flag, sizeof(int)) != hipSuccess ||
       hipMemset(h->d_flag, 0, sizeof(int)) != hipSuccess) {
@@ -898,7 +1018,7 @@ int nnj_pair_scores_full(nnj_handle* h, const float* state, const uint8_t* mask,
     hipLaunchKernelGGL(k_assemble_argmax, dim3((unsigned)B), dim3(256), 0, st, g.score_src, g.nsc, g.ppad,
                        (const float*)nullptr, (const int*)nullptr, logits_out, (float*)nullptr, 0L, (const int*)nullptr,
                        0L, (int*)nullptr, 0L, (float*)nullptr, 0L, v.ijs, (int)PAIRS_FULL, n, (const float*)nullptr, 0L, 1.0f,
-                       h->d_flag, (const int*)nullptr, (int*)nullptr, 0);
+                       h->d_flag, (const int*)nullptr, (int*)nullptr, 0, 0, StepOut{});
   }
   HIPCHK(h, hipGetLastError());
   sess_set(h, ws, state, B, n, L, n);
@@ -927,7 +1047,7 @@ int nnj_pair_scores_incr(nnj_handle* h, const float* state, const uint8_t* mask,
     hipLaunchKernelGGL(k_assemble_argmax, dim3((unsigned)B), dim3(256), 0, st, g.score_src, g.nsc, g.ppad,
                        logits_prev, ij_prev, logits_out, (float*)nullptr, 0L, (const int*)nullptr, 0L, (int*)nullptr, 0L,
                        (float*)nullptr, 0L, v.ijs, (int)PAIRS_INCR, n, (const float*)nullptr, 0L, 1.0f, h->d_flag,
-                       (const int*)nullptr, (int*)nullptr, 0);
+                       (const int*)nullptr, (int*)nullptr, 0, 0, StepOut{});
   }
   HIPCHK(h, hipGetLastError());
   if (cont) sess_set(h, ws, state, B, T0, L, n);
@@ -1052,7 +1172,7 @@ int nnj_step(nnj_handle* h, const float* state, const uint8_t* mask, const int32
   }
   RowSet rs;
   rs.S = S; rs.U = base + w.U; rs.Kp = base + w.Kp; rs.beta_part = base + w.beta;
-  rs.bstride = (long)T0 * C * 64; rs.live = live; rs.live_stride = T0; rs.ntile32 = (C + 31) / 32;
+  rs.bstride = (long)T0 * C * 64; rs.live = live; rs.live_stride = T0; rs.ntile32 = beta_stride(B, C);
   HIPCHK(h, hipMemcpyAsync(ijs, ij, (size_t)B * 2 * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
   // env.step (environment.py:760-835): merged row into slot(i), position j leaves the list
   if (int rc = launch_aggregate(h, rs, ijs, base, w, S, base + w.U, base + w.Kp, base + w.beta, rs.bstride, T0, 1, n + 1,
@@ -1070,7 +1190,7 @@ int nnj_step(nnj_handle* h, const float* state, const uint8_t* mask, const int32
     hipLaunchKernelGGL(k_assemble_argmax, dim3((unsigned)B), dim3(256), 0, st, g.score_src, g.nsc, g.ppad, logits_prev,
                        (const int*)ijs, logits_out, (float*)nullptr, 0L, forced_next, 2L, (int*)nullptr, 0L, top2_gap, 1L,
                        chosen_ij, (int)PAIRS_INCR, n, (const float*)nullptr, 0L, 1.0f, h->d_flag, (const int*)nullptr,
-                       (int*)nullptr, 0);
+                       (int*)nullptr, 0, 0, StepOut{});
   }
   {
     Scope sc(h, st, PK_MISC);
@@ -1114,16 +1234,49 @@ static int rollout_core(nnj_handle* h, const uint8_t* codes, const uint8_t* mask
   launch_row_xf(h, S, base + w.U, base + w.Kp, base + w.beta, (long)T * C * 64, T, T, B, C, st);
   RowSet rs;
   rs.S = S; rs.U = base + w.U; rs.Kp = base + w.Kp; rs.beta_part = base + w.beta;
-  rs.bstride = (long)T * C * 64; rs.live = livebuf[0]; rs.live_stride = T; rs.ntile32 = (C + 31) / 32;
+  rs.bstride = (long)T * C * 64; rs.live = livebuf[0]; rs.live_stride = T; rs.ntile32 = beta_stride(B, C);
   size_t total = 0;
   for (int n = T; n >= 2; --n) total += (size_t)n * (n - 1) / 2;
   float* lg[2] = {base + w.logits0, base + w.logits1};
   size_t off = 0;
+  // The two-pass step (nnj_step2.hpp) runs whenever at most 64 rows are left after a merge: the merge picked from a
+  // table of n + 1 rows happens INSIDE the next step's alpha pass, not behind the table kernel.
+  const bool two_pass = h->two_pass != 0;
+  const bool use_cand = two_pass && h->two_pass_cand != 0;
+  int* candbuf[2] = {reinterpret_cast<int*>(base + w.cand), reinterpret_cast<int*>(base + w.cand) + 2 * (size_t)B};
+  bool prev_gave_am = false;                               // did the previous table kernel write am / need?
+  bool prev_lam = false;
   for (int step = 0, n = T; n >= 2; ++step, --n) {
     const int mode = step == 0 ? PAIRS_FULL : PAIRS_INCR;
     PairGeom g;
     rs.live = livebuf[step & 1];
-    if (int rc = launch_pair_scores(h, rs, ij, mask, base, w, mode, n, B, C, g, st)) return rc;   // :121-126
+    const bool v2 = two_pass && step >= 1 && n <= 64 && prev_gave_am;
+    if (v2) {
+      Step2 o;
+      // without forced / sampled picks the pick of a step >= 1 of this kind is always covered (a new pair or the
+      // candidate); the first such step follows a table whose kernels carry no logits
+      o.fallback = !prev_lam || forced != nullptr || uniforms != nullptr || !use_cand;
+      o.cand = use_cand;
+      o.cand_cur = candbuf[step & 1];
+      if (int rc = launch_step2(h, rs, livebuf[(step + 1) & 1], ij, mask, base, w, o, n, B, C, g, st)) return rc;
+    } else {
+      if (int rc = launch_pair_scores(h, rs, ij, mask, base, w, mode, n, B, C, g, st)) return rc;   // :121-126
+    }
+    // does the NEXT step run as a two-pass step?  then this table kernel supplies the weights of its merge
+    const bool next_v2 = two_pass && n - 1 >= 2 && n - 1 <= 64;
+    StepOut so{};
+    if (next_v2) {
+      so.lam = (v2 && n > 2) ? base + w.lam : nullptr;
+      so.beta_tot = base + w.beta_tot;
+      so.acand_part = (v2 && use_cand && n > 2) ? base + w.acand : nullptr;
+      so.nblk = g.blocks;
+      so.cand_cur = (v2 && use_cand && n > 2) ? candbuf[step & 1] : nullptr;
+      so.am = base + w.am;
+      so.need = reinterpret_cast<int*>(base + w.need);
+      so.cand_next = use_cand ? candbuf[(step + 1) & 1] : nullptr;
+      so.cand_run = reinterpret_cast<int*>(base + w.cand_run);
+      so.inv_scale = 1.0f / sqrtf(64.0f * (float)C);
+    }
     {
       Scope sc(h, st, PK_ASSEMBLE);                                                                 // :140-160
       hipLaunchKernelGGL(k_assemble_argmax, dim3((unsigned)B), dim3(256), 0, st, g.score_src, g.nsc, g.ppad,
@@ -1131,10 +1284,12 @@ static int rollout_core(nnj_handle* h, const uint8_t* codes, const uint8_t* mask
                          (long)total, forced ? forced + 2 * step : nullptr, (long)(T - 1) * 2, merges_out + 2 * step,
                          (long)(T - 1) * 2, gap ? gap + step : nullptr, (long)(T - 1), ij, mode, n,
                          uniforms ? uniforms + step : nullptr, (long)(T - 1), inv_temp, h->d_flag,
-                         (const int*)livebuf[step & 1], n > 2 ? livebuf[(step + 1) & 1] : (int*)nullptr, T);
+                         (const int*)livebuf[step & 1], n > 2 ? livebuf[(step + 1) & 1] : (int*)nullptr, T, v2 ? 1 : 0, so);
     }
     off += (size_t)n * (n - 1) / 2;
-    if (n > 2) {                                                                                    // env.step :164
+    prev_gave_am = next_v2;
+    prev_lam = so.lam != nullptr;
+    if (n > 2 && !next_v2) {                                                                        // env.step :164
       if (int rc = launch_aggregate(h, rs, ij, base, w, S, base + w.U, base + w.Kp, base + w.beta, rs.bstride, T, 1, n,
                                     B, C, st)) return rc;
     }

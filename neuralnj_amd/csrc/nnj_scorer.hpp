@@ -33,12 +33,15 @@ struct RowSet {                // where the rows of one call live
   long bstride;                // floats between batch elements (slots*C*64)
   const int* live;             // [B][live_stride] position -> slot, or nullptr = identity
   int live_stride;
-  int ntile32;                 // ceil(C/32)
+  int ntile32;                 // beta partials per row (>= ceil(C/32); entries not written by the row's producer are 0)
 };
 
 __device__ __forceinline__ int slot_of(const RowSet& rs, int b, int pos) {
   return rs.live ? rs.live[b * rs.live_stride + pos] : pos;
 }
+// The two-pass step (nnj_step2.hpp) numbers the n-1 rows OTHER than the freshly merged row m as q = 0..n-2 (pairs,
+// image rows, alpha planes, score partials); position in the list:
+__device__ __forceinline__ int q_to_r(int q, int m) { return q + (q >= m ? 1 : 0); }
 
 // The per-feature vectors of the scorer (b_h, b_g, s_out.0 bias, s_out.2 weight: 4 x 64 floats) live in LDS for the
 // lifetime of a workgroup: read from global memory inside the site loop they were one L2 round trip each, several of
@@ -400,17 +403,18 @@ struct IncLane {
 };
 template <int NT>
 __device__ __forceinline__ IncLane inc_lane(const RowSet& rs, const int* ij_prev, int b, int n, int lane,
-                                            int r0 = 0) {
+                                            int r0 = 0, int qn = 0) {
   IncLane L;
   L.m = min(max(ij_prev[2 * b], 0), n - 1);
   L.slot_m = slot_of(rs, b, L.m);
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
-    const int r = r0 + 32 * nt + (lane & 31);
+    const int r = r0 + 32 * nt + (lane & 31);             // qn: q, the row's index among the rows other than m
     L.r[nt] = r;
-    L.valid[nt] = r < n && r != L.m;
-    L.slot_r[nt] = slot_of(rs, b, r < n ? r : 0);
-    L.r_first[nt] = r < L.m;
+    L.valid[nt] = qn ? r < n - 1 : (r < n && r != L.m);
+    const int pos = qn ? q_to_r(r, L.m) : r;
+    L.slot_r[nt] = slot_of(rs, b, pos < n ? pos : 0);
+    L.r_first[nt] = r < L.m;                               // (q < m <=> r < m)
   }
   return L;
 }
@@ -488,7 +492,7 @@ __global__ __launch_bounds__(512) void k_inc_score(RowSet rs, ScorerW w, const i
                                                    const float* __restrict__ alpha,
                                                    const uint8_t* __restrict__ mask,
                                                    float* __restrict__ score_part, int n, int C, int cs,
-                                                   int* __restrict__ status) {
+                                                   int* __restrict__ status, int qn) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Wg_l = smem;                                      // operand images
   float* S0_l = smem + IMG64;
@@ -511,7 +515,7 @@ __global__ __launch_bounds__(512) void k_inc_score(RowSet rs, ScorerW w, const i
   if (tid < NSLOT) reinterpret_cast<int*>(smem + 3 * IMG64 + NSLOT * IMG)[tid] = 0;
   __syncthreads();
   int epoch = 0;
-  const IncLane L = inc_lane<1>(rs, ij_prev, b, n, lane, 32 * tl);
+  const IncLane L = inc_lane<1>(rs, ij_prev, b, n, lane, 32 * tl, qn);
   const int r = L.r[0];
   const size_t bo = (size_t)b * rs.bstride;
   // position of column r in an image row (the r' order of stage_weight_b6)
@@ -655,7 +659,7 @@ __device__ __forceinline__ void row_transforms(const f32x16 (&s)[1][2], const fl
 // k_row_xf: transforms of existing rows. grid (ceil(C/128), rows, B); wave = 32 sites.
 __global__ __launch_bounds__(256) void k_row_xf(const float* __restrict__ S, float* __restrict__ U,
                                                 float* __restrict__ Kp, float* __restrict__ beta_part,
-                                                ScorerW w, long bstride, int slots, int C, int ntile32) {
+                                                ScorerW w, long bstride, int slots, int C, int ntile32, int bstr) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Wh_l = smem;
   float* A_l = smem + 4096;
@@ -670,7 +674,7 @@ __global__ __launch_bounds__(256) void k_row_xf(const float* __restrict__ S, flo
   const size_t roff = (size_t)b * bstride + (size_t)row * C * 64;
   f32x16 s[1][2];
   load_token64(s[0], S + roff + (size_t)(valid ? c : 0) * 64, valid, lane >> 5);
-  row_transforms(s, Wh_l, A_l, w, U + roff, Kp + roff, beta_part + ((size_t)b * slots + row) * ntile32 + tile,
+  row_transforms(s, Wh_l, A_l, w, U + roff, Kp + roff, beta_part + ((size_t)b * slots + row) * bstr + tile,
                  c, valid, lane);
 }
 
@@ -898,6 +902,22 @@ __global__ __launch_bounds__(256) void k_agg_finish(RowSet rs, ScorerW w, const 
                    beta_out + ((size_t)b * out_slots + oslot) * rs.ntile32 + tile, c, valid, lane);
 }
 
+// What the two-pass step (nnj_step2.hpp) needs from the table kernel besides the pick: the attention weights of the
+// NEXT merge (the merged pair's logits exist already when the pick is one of this step's new pairs or the candidate
+// named one step ago) and the candidate of the next step.  All null for the callers that do not use it.
+struct StepOut {
+  const float* lam;           // [B][64 q][64 q'] summed logits of this step's new pairs (k_step_softmax), or null
+  const float* beta_tot;      // [B][64] summed beta partials of the rows of this table, by position
+  const float* acand_part;    // [B][nblk][64] logits of the candidate against the rows (k_step_alpha), or null
+  int nblk;
+  const int* cand_cur;        // [B][2] the candidate those logits belong to, positions of THIS table; (-1,-1) = none
+  float* am;                  // out [B][64]: weights of the merge just picked, by position AFTER it (0 at i)
+  int* need;                  // out [B]: 1 = no source applied, the fallback kernels must compute `am`
+  int* cand_next;             // out [B][2]: best entry of this table without rows i, j, by position after the merge
+  int* cand_run;              // out [B]: 1 = that pair is not the one whose x' row exists (k_pair_xp must run)
+  float inv_scale;            // 1 / sqrt(64 C)
+};
+
 // ------------------------------------------------------------------ table assemble + argmax
 // One workgroup per batch element.  new/first scores = fixed-order sum of score parts;
 // table via the old->new index map (utils.py:227-247) from logits_prev; argmax with
@@ -915,9 +935,9 @@ __global__ __launch_bounds__(256) void k_assemble_argmax(const float* __restrict
                                                          const float* __restrict__ uniforms, long u_bstride,
                                                          float inv_temp, int* __restrict__ nonfinite,
                                                          const int* __restrict__ live_cur, int* __restrict__ live_next,
-                                                         int live_stride) {
+                                                         int live_stride, int qn, StepOut so) {
   __shared__ float newsc[256];
-  __shared__ int picked_j;
+  __shared__ int picked_j, picked_i;
   // the rollout keeps two live lists: this kernel also writes the NEXT one (the current list without position j:
   // environment.py:764-768), which used to be a launch of its own per step (k_update_live; 5 us of the 100 us of a
   // step at batch 1).  The current entries are loaded here, their latency hides behind the table pass.
@@ -934,9 +954,11 @@ __global__ __launch_bounds__(256) void k_assemble_argmax(const float* __restrict
   if (mode == PAIRS_INCR) {
     ip = ij_prev[2 * b]; jp = ij_prev[2 * b + 1];
     if (tid < n) {
+      // qn: the partials are indexed by q, the partner's index among the rows other than the merged one (nnj_step2.hpp)
+      const int src = qn ? tid - (tid > ip ? 1 : 0) : tid;
       float s = 0.f;
 #pragma unroll 8
-      for (int sc = 0; sc < nsc; ++sc) s += score_part[((size_t)b * nsc + sc) * ppad + tid];
+      for (int sc = 0; sc < nsc; ++sc) s += score_part[((size_t)b * nsc + sc) * ppad + src];
       newsc[tid] = s;
     }
     __syncthreads();
@@ -1040,10 +1062,93 @@ __global__ __launch_bounds__(256) void k_assemble_argmax(const float* __restrict
     }
     ij_cur[2 * b] = ci; ij_cur[2 * b + 1] = cj;
     picked_j = min(max(cj, 1), n - 1);
+    picked_i = min(max(ci, 0), n - 2);
   }
   if (live_next) {
     __syncthreads();
     if (tid < n - 1) live_next[(size_t)b * live_stride + tid] = tid >= picked_j ? lv1 : lv0;
+  }
+  if (!so.am) return;
+  // ---- the two-pass step: weights of the merge just picked, candidate of the next step
+  __syncthreads();
+  const int pi_ = picked_i, pj_ = picked_j;
+  if (tid < 64) {
+    // source of the merged pair's logits a_r (nnj_step2.hpp): 1 = a pair scored in this step, 2 = the candidate
+    int src = 0, qs = 0;
+    if (mode == PAIRS_INCR && so.lam && (pi_ == ip || pj_ == ip)) {
+      src = 1;
+      const int rs_ = pi_ == ip ? pj_ : pi_;
+      qs = rs_ - (rs_ > ip ? 1 : 0);
+    } else if (so.acand_part && so.cand_cur && so.cand_cur[2 * b] == pi_ && so.cand_cur[2 * b + 1] == pj_) {
+      src = 2;
+    }
+    const int r = tid;
+    const bool in = src != 0 && n > 2 && r < n && r != pi_ && r != pj_;
+    float v = -INFINITY;
+    if (in) {
+      float a = 0.f;
+      if (src == 1) {
+        a = so.lam[((size_t)b * 64 + qs) * 64 + (r - (r > ip ? 1 : 0))];
+      } else {
+        const int col = (mode == PAIRS_INCR && r == ip) ? 63 : r - ((mode == PAIRS_INCR && r > ip) ? 1 : 0);
+        for (int k = 0; k < so.nblk; ++k) a += so.acand_part[((size_t)b * so.nblk + k) * 64 + col];
+      }
+      v = (a + so.beta_tot[(size_t)b * 64 + r]) * so.inv_scale;
+    }
+    float mx = v;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    const float e = in ? expf(v - mx) : 0.f;
+    float se = e;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) se += __shfl_xor(se, o);
+    so.am[(size_t)b * 64 + tid] = 0.f;
+    __builtin_amdgcn_wave_barrier();
+    if (in) so.am[(size_t)b * 64 + (r - (r > pj_ ? 1 : 0))] = se > 0.f ? e / se : 0.f;
+    if (tid == 0) so.need[b] = (src == 0 && n > 2) ? 1 : 0;
+  }
+  if (!so.cand_next) return;
+  // best entry of this table that survives the merge (first maximal index: the order of the surviving pairs is the
+  // order of the next table's old part) -- the only OLD pair the next argmax can pick
+  float cb = -INFINITY;
+  int cbi = 0x7fffffff;
+  for (int p = tid; p < np; p += 256) {
+    int ii, jj;
+    pair_from_index(n, p, ii, jj);
+    if (ii == pi_ || ii == pj_ || jj == pi_ || jj == pj_) continue;
+    const float v = logits_out[(size_t)b * np + p];
+    if (v > cb) { cb = v; cbi = p; }
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    const float b2 = __shfl_xor(cb, o);
+    const int i2 = __shfl_xor(cbi, o);
+    if (b2 > cb || (b2 == cb && i2 < cbi)) { cb = b2; cbi = i2; }
+  }
+  __syncthreads();                                          // (red_v / red_i of the argmax are dead)
+  if ((tid & 63) == 0) { red_v[tid >> 6] = cb; red_i[tid >> 6] = cbi; }
+  __syncthreads();
+  if (tid == 0) {
+    cb = red_v[0]; cbi = red_i[0];
+#pragma unroll
+    for (int wv = 1; wv < 4; ++wv)
+      if (red_v[wv] > cb || (red_v[wv] == cb && red_i[wv] < cbi)) { cb = red_v[wv]; cbi = red_i[wv]; }
+    int na = -1, nb = -1;
+    if (cbi >= 0 && cbi < np) {
+      int a_, b_;
+      pair_from_index(n, cbi, a_, b_);
+      na = a_ - (a_ > pj_ ? 1 : 0);
+      nb = b_ - (b_ > pj_ ? 1 : 0);
+    }
+    // the x' row of the candidate stays valid while the candidate is the same pair of rows
+    int keep = 0;
+    if (so.cand_cur && na >= 0) {
+      const int ca = so.cand_cur[2 * b], cc = so.cand_cur[2 * b + 1];
+      if (ca >= 0 && ca != pi_ && ca != pj_ && cc != pi_ && cc != pj_)
+        keep = (ca - (ca > pj_ ? 1 : 0) == na && cc - (cc > pj_ ? 1 : 0) == nb) ? 1 : 0;
+    }
+    so.cand_next[2 * b] = na; so.cand_next[2 * b + 1] = nb;
+    so.cand_run[b] = (na >= 0 && !keep) ? 1 : 0;
   }
 }
 

@@ -31,13 +31,14 @@ struct Inc16 {            // per-lane description of the step: pair (m, r)
   int r, slot_r, slot_m;
   float sgn;              // +1 if r < m (the pair is (r, m)), -1 otherwise
 };
-__device__ __forceinline__ Inc16 inc16(const RowSet& rs, const int* ij_prev, int b, int n, int r) {
+__device__ __forceinline__ Inc16 inc16(const RowSet& rs, const int* ij_prev, int b, int n, int r, int qn = 0) {
   Inc16 L;
   const int m = min(max(ij_prev[2 * b], 0), n - 1);
-  L.r = r;
+  L.r = r;                                               // qn: q, the row's index among the rows other than m (q_to_r)
   L.slot_m = slot_of(rs, b, m);
-  L.slot_r = slot_of(rs, b, r < n ? r : 0);              // lanes beyond the rows read row 0 (never used)
-  L.sgn = r < m ? 1.0f : -1.0f;
+  const int pos = qn ? q_to_r(r, m) : r;
+  L.slot_r = slot_of(rs, b, pos < n ? pos : 0);          // lanes beyond the rows read row 0 (never used)
+  L.sgn = r < m ? 1.0f : -1.0f;                          // (q < m <=> r < m)
   return L;
 }
 // x = S_m + sigmoid(U_r - U_m + s*b) (S_r - S_m)   (see inc_gate).  The accumulators of U_r = W_h S_r start at
@@ -172,7 +173,8 @@ template <int NG, bool CTX>
 __global__ __launch_bounds__(64 * T16_WAVES) void k_inc_score16(RowSet rs, ScorerW w, const int* __restrict__ ij_prev,
                                                                 const float* __restrict__ alpha,
                                                                 const uint8_t* __restrict__ mask,
-                                                                float* __restrict__ score_part, int n, int C, int cs) {
+                                                                float* __restrict__ score_part, int n, int C, int cs,
+                                                                int qn) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int NSLOT = T16_WAVES / NG;
   constexpr int NC = NG == 3 ? 4 : NG;                     // image geometry: 16*NC columns (3 waves use the 64-column one)
@@ -197,7 +199,7 @@ __global__ __launch_bounds__(64 * T16_WAVES) void k_inc_score16(RowSet rs, Score
     for (int i = tid; i < NSLOT * IMG; i += 64 * T16_WAVES) smem[3 * IMG64 + i] = 0.f;
   }
   __syncthreads();
-  const Inc16 L = inc16(rs, ij_prev, b, n, 16 * tl + l15);
+  const Inc16 L = inc16(rs, ij_prev, b, n, 16 * tl + l15, qn);
   const size_t bo = (size_t)b * rs.bstride;
   const float* Sr = rs.S + bo + (size_t)L.slot_r * C * 64;
   const float* Sm = rs.S + bo + (size_t)L.slot_m * C * 64;
@@ -330,7 +332,7 @@ template <int NT, bool CTX, int NW = 8>
 __global__ __launch_bounds__(64 * NW) void k_inc_score_w(RowSet rs, ScorerW w, const int* __restrict__ ij_prev,
                                                      const float* __restrict__ alpha,
                                                      const uint8_t* __restrict__ mask,
-                                                     float* __restrict__ score_part, int n, int C, int cs) {
+                                                     float* __restrict__ score_part, int n, int C, int cs, int qn) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int WPF = 2;                                   // fragment reads ahead
   constexpr int RL = 16 * NT;                              // fp16 per image row
@@ -374,9 +376,8 @@ __global__ __launch_bounds__(64 * NW) void k_inc_score_w(RowSet rs, ScorerW w, c
   const float *Sm, *Um;
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
-    const Inc16 L = inc16(rs, ij_prev, b, n, 16 * t + l15);
+    const Inc16 L = inc16(rs, ij_prev, b, n, 16 * t + l15, qn);
     Sr[t] = rs.S + bo + (size_t)L.slot_r * C * 64;
-
     sgn[t] = L.sgn;
     rr[t] = L.r;
     score[t] = 0.f;

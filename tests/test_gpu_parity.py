@@ -49,6 +49,21 @@ def _oracle_f64(cfgs, packed):
     return Oracle(cfgs, packed, "f64")
 
 
+def _four_pass_ctx(cfgs, packed):
+    """A handle whose rollouts run the four-pass NJ step (k_agg_alpha / k_agg_finish / k_inc_alpha16 / k_inc_score*), the
+    kernels the step-by-step entry points (nnj_step, nnj_env_step, nnj_pair_scores_incr) run; the default rollout runs
+    the two-pass step of csrc/nnj_step2.hpp (NNJ_TWO_PASS is read by nnj_create)."""
+    import os
+    from neuralnj_amd._lib import Nnj
+    os.environ["NNJ_TWO_PASS"] = "0"
+    try:
+        g = Nnj(cfgs, "cuda:0")
+    finally:
+        del os.environ["NNJ_TWO_PASS"]
+    g.load_weights(packed)
+    return g
+
+
 RF_ROWS = []          # one row per (fixture, alignment): written to gpurun_out/rf_table.json at module teardown
 
 
@@ -293,15 +308,20 @@ def test_mask_none_equals_all_false(ctx_cache):
 @pytest.mark.parametrize("name", ["synth_b2_t8_l128_s1", "synth_b2_t70_l64_s12"])
 def test_fused_step_reproduces_the_rollout(name, ctx_cache):
     """nnj_step (merge + new scores + table + argmax in one call) iterated from the encoder output gives the
-    tables and merges of nnj_rollout_argmax bit for bit -- both run the same kernels in the same order (70 rows:
-    through the star kernels above 64 live rows, then the 64-row kernels)."""
+    tables and merges of a rollout on the same (four-pass) kernels bit for bit -- same kernels in the same order (70
+    rows: through the star kernels above 64 live rows, then the 64-row kernels) -- and those of the default rollout
+    (two-pass step: other summation orders) within a fifth of the tolerance."""
     z, cfgs, packed = load_golden(name)
     g = ctx_cache(cfgs, packed)
     codes, mask = torch.from_numpy(z["codes"]), torch.from_numpy(z["mask"])
     B, T, L = z["codes"].shape
-    ref = g.rollout_argmax(codes, mask, want_trace=True, want_state=True)
+    g4 = _four_pass_ctx(cfgs, packed)
+    ref = g4.rollout_argmax(codes, mask, want_trace=True, want_state=True)
+    two = g.rollout_argmax(codes, mask, want_trace=True, forced_merges=ref["merges"].cpu().numpy())
+    assert_logits_close(two["logits"].cpu().numpy(), ref["logits"].cpu().numpy(), 0.2 * RTOL, "two-pass vs four-pass step")
     tables = split_trace(ref["logits"].cpu().numpy(), T)
     merges = ref["merges"].cpu().numpy()
+    g4.close()
     state = g.encode(codes, mask)
     logits = g.pair_scores_full(state, mask)
     assert np.array_equal(logits.cpu().numpy(), tables[0])
@@ -319,13 +339,16 @@ def test_fused_step_reproduces_the_rollout(name, ctx_cache):
 def test_dense_state_session_reproduces_the_rollout(name, ctx_cache):
     """The reference's call sequence decode_zxr -> argmax -> env.step -> decode_zxr ... through the dense-state entry
     points (nnj_pair_scores_full / nnj_env_step / nnj_pair_scores_incr): handed the tensors it produced, the library
-    continues a session (include/nnj.h) and gives the tables of nnj_rollout_argmax bit for bit; a state tensor the
-    caller has rewritten in place is NOT taken for the session's (stateless path, same values within tolerance)."""
+    continues a session (include/nnj.h) and gives the tables of a rollout on the same (four-pass) kernels bit for bit; a
+    state tensor the caller has rewritten in place is NOT taken for the session's (stateless path, same values within
+    tolerance)."""
     z, cfgs, packed = load_golden(name)
     g = ctx_cache(cfgs, packed)
     codes, mask = torch.from_numpy(z["codes"]), torch.from_numpy(z["mask"])
     B, T, L = z["codes"].shape
-    ref = g.rollout_argmax(codes, mask, want_trace=True)
+    g4 = _four_pass_ctx(cfgs, packed)
+    ref = g4.rollout_argmax(codes, mask, want_trace=True)
+    g4.close()
     tables = split_trace(ref["logits"].cpu().numpy(), T)
     merges = ref["merges"].cpu().numpy()
     state = g.encode(codes, mask)
