@@ -254,7 +254,7 @@ int beta_stride(int B, int C) {
 // workspace regions of the NJ loop (after the state/slots buffer), in floats
 struct LoopWs {
   size_t U, Kp, beta, alpha_part, alpha, score_part, full, agg_part, logits0, logits1, merged, live, ij, zmask;
-  size_t lam, beta_tot, acand, Xc, am, need, cand, cand_run, end;      // the two-pass step (nnj_step2.hpp)
+  size_t lam, beta_tot, acand, Xc, am, need, cand, cand_run, mrep, end; // the two-pass step (nnj_step2.hpp); replicated mask
 };
 LoopWs loop_ws(int B, int T, int C) {
   LoopWs w;
@@ -303,6 +303,7 @@ LoopWs loop_ws(int B, int T, int C) {
   w.need = take((size_t)B);
   w.cand = take((size_t)B * 4);                  // two lists of (a, b): this step's candidate / the next one's
   w.cand_run = take((size_t)B);
+  w.mrep = take(((size_t)B * C + 3) / 4);          // site mask of a replicated alignment (bytes)
   w.end = o;
   return w;
 }
@@ -1216,7 +1217,7 @@ static int rollout_core(nnj_handle* h, const uint8_t* codes, const uint8_t* mask
     Scope sc(h, st, PK_MISC);
     hipLaunchKernelGGL(k_replicate, dim3(64, (unsigned)(B - 1)), dim3(256), 0, st, S, (long)T * C * 16);
     if (mask_in) {
-      uint8_t* mrep = reinterpret_cast<uint8_t*>(base + w.merged);       // [B][L] bytes fit in the merged-row scratch
+      uint8_t* mrep = reinterpret_cast<uint8_t*>(base + w.mrep);
       hipLaunchKernelGGL(k_replicate_u8, dim3((unsigned)(((size_t)B * L + 255) / 256)), dim3(256), 0, st, mask_in, mrep, B, L);
       mask = mrep;
     }

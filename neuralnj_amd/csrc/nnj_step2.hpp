@@ -104,7 +104,7 @@ __global__ __launch_bounds__(64 * NW) void k_step_alpha(RowSet rs, ScorerW w, St
   float* Wg_l = smem + 2 * IMG64;
   const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, kq = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int slot = wave % NSLOT, tl = wave / NSLOT;
+  const int slot = wave % NSLOT, tl = wave / NSLOT;        // (the waves of a site on different SIMDs -- slot = wave / NG -- measured slower: 54.9 vs 52.4 ms per rollout)
   float* img = smem + 3 * IMG64 + slot * IMG;
   float* xs = smem + 3 * IMG64 + NSLOT * IMG + slot * XS;
   int* cnt0 = reinterpret_cast<int*>(smem + 3 * IMG64 + NSLOT * IMG + NSLOT * XS);
@@ -163,23 +163,22 @@ __global__ __launch_bounds__(64 * NW) void k_step_alpha(RowSet rs, ScorerW w, St
   }
   for (; c < c1; c += NSLOT) {
     asm volatile("" ::: "memory");
-    // ---- 1. am_r S_r[c]: the wave's 16 rows as fp32 rows of the (dead) image buffer, columns rotated by 4 per row so
-    // that both the 16-byte row stores and the column reads are conflict free; then the column sums of those rows
+    // ---- 1. am_r S_r[c]: the wave's 16 rows as fp32 rows of the (dead) image buffer, 16-byte chunk ch of row k stored
+    // at chunk ch ^ k: the row stores and the column reads are conflict free and a column read is one XOR with a
+    // constant away from the lane's base address; then the column sums of those rows
     if constexpr (NG > 1) group_barrier_lds<NG>(cnt, epoch, status);     // everyone is done with the previous site's image
     {
-      const int row = 16 * tl + l15;
+      float* pw = img + (16 * tl + l15) * 64;
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt) {
         const f32x4 p = sr.t[mt] * aw;
-        *reinterpret_cast<f32x4*>(img + row * 64 + ((16 * mt + 4 * kq + 4 * row) & 63)) = p;
+        *reinterpret_cast<f32x4*>(pw + 4 * ((4 * mt + kq) ^ l15)) = p;
       }
       asm volatile("" ::: "memory");
+      const float* pr = img + 16 * tl * 64;
       float s = 0.f;
 #pragma unroll
-      for (int k = 0; k < 16; ++k) {
-        const int rr = 16 * tl + k;
-        s += img[rr * 64 + ((lane + 4 * rr) & 63)];
-      }
+      for (int k = 0; k < 16; ++k) s += pr[k * 64 + (lane ^ (4 * k))];
       xgp[tl * 64 + lane] = s;
     }
     if constexpr (NG > 1) group_barrier_lds<NG>(cnt, epoch, status);     // all column sums are in xgp
@@ -257,8 +256,8 @@ __global__ __launch_bounds__(64 * NW) void k_step_alpha(RowSet rs, ScorerW w, St
     // ---- 3. the new pairs (m, r)
     V64 x;
     {
-      V64 sm, um, ur;
-      load_v64(sm, v_sm, kq);
+      V64 sm, um, ur;                                      // (U_r = W_h S_r issued by the partners of wave 0 while they wait for
+      load_v64(sm, v_sm, kq);                              //  the merged row: measured slower, 56.0 vs 52.7 ms per rollout)
       load_v64(um, v_um, kq);
       gate_init16(ur, um, cv, sgn, kq);
       lds_wait_all();
