@@ -254,7 +254,7 @@ int beta_stride(int B, int C) {
 // workspace regions of the NJ loop (after the state/slots buffer), in floats
 struct LoopWs {
   size_t U, Kp, beta, alpha_part, alpha, score_part, full, agg_part, logits0, logits1, merged, live, ij, zmask;
-  size_t lam, beta_tot, acand, Xc, am, need, cand, cand_run, mrep, end; // the two-pass step (nnj_step2.hpp); replicated mask
+  size_t lam, beta_slot, acand, Xc, am, need, cand, cand_run, mrep, end; // the two-pass step (nnj_step2.hpp); replicated mask
 };
 LoopWs loop_ws(int B, int T, int C) {
   LoopWs w;
@@ -296,7 +296,7 @@ LoopWs loop_ws(int B, int T, int C) {
   w.ij = take((size_t)B * 2 + 2);
   w.zmask = take(((size_t)B * C + 3) / 4);       // all-false site mask for callers that pass none (bytes)
   w.lam = take((size_t)B * 4096);
-  w.beta_tot = take((size_t)B * 64);
+  w.beta_slot = take((size_t)B * T);
   w.acand = take((size_t)B * pair_geom(PAIRS_INCR, 2, B, C).blocks * 64);
   w.Xc = take((size_t)B * C * 64);
   w.am = take((size_t)B * 64);
@@ -641,6 +641,7 @@ int launch_pair_scores(nnj_handle* h, const RowSet& rs, const int* ij_prev, cons
 // position ij[0], whose slot still holds S_i); live_old = the list before it.  Produces the merged row in place and
 // the score partials of the n-1 new pairs (q numbering) in w.score_part.
 struct Step2 {
+  bool first;         // the previous step ran the other kernels: the per-row biases are summed from their partials
   bool fallback;      // the previous table kernel may have left `need` set: launch the per-alignment fallback
   bool cand;          // carry the candidate pair's logits along
   int* cand_cur;      // [B][2]
@@ -655,6 +656,11 @@ int launch_step2(nnj_handle* h, RowSet rs, const int* live_old, const int* ij, c
   int* need = reinterpret_cast<int*>(base + w.need);
   int* cand_run = reinterpret_cast<int*>(base + w.cand_run);
   const int T = rs.live_stride;
+  if (o.first) {
+    Scope sc(h, st, PK_STEP_SMALL);
+    hipLaunchKernelGGL(k_beta_sum, dim3((unsigned)((B * T + 255) / 256)), dim3(256), 0, st, rs.beta_part, rs.ntile32,
+                       rs.ntile32, (float)C * sw.t0, base + w.beta_slot, B * T);
+  }
   if (o.fallback) {
     // weights of the merge for the alignments whose pick was neither a pair of the last step nor the candidate
     Scope sc(h, st, PK_STEP_SMALL);
@@ -667,19 +673,13 @@ int launch_step2(nnj_handle* h, RowSet rs, const int* live_old, const int* ij, c
     hipLaunchKernelGGL(k_agg_dot, dim3((unsigned)nch, (unsigned)B), dim3(256), 0, st, ro, (const float*)(base + w.merged),
                        (const int*)need, base + w.agg_part, n + 1, C, rp);
     hipLaunchKernelGGL(k_agg_am, dim3((unsigned)B), dim3(64), 0, st, ro, sw, ij, (const int*)need,
-                       (const float*)(base + w.agg_part), nch, rp, rs.ntile32, base + w.am, n + 1, C);
+                       (const float*)(base + w.agg_part), nch, rp, (const float*)(base + w.beta_slot), base + w.am, n + 1, C);
   }
   const bool cand = o.cand && n > 2;
-  if (cand) {
-    Scope sc(h, st, PK_STEP_SMALL);
-    const size_t lds = (size_t)IMG64 * sizeof(float);
-    hipLaunchKernelGGL(k_pair_xp, dim3((unsigned)((C + 127) / 128), (unsigned)B), dim3(256), lds, st, rs.S, rs.U, rs.bstride,
-                       rs.live, T, sw, (const int*)o.cand_cur, (const int*)cand_run, base + w.Xc, n, C);
-  }
   StepIO io;
   io.ij = ij; io.live_old = live_old; io.am = base + w.am; io.alpha_part = base + w.alpha_part;
   io.S_w = S_w; io.U_w = U_w; io.beta_w = const_cast<float*>(rs.beta_part); io.beta_n = rs.ntile32;
-  io.cand = cand ? o.cand_cur : nullptr; io.Xc = base + w.Xc; io.acand_part = base + w.acand;
+  io.cand = cand ? o.cand_cur : nullptr; io.cand_run = cand_run; io.Xc = base + w.Xc; io.acand_part = base + w.acand;
   const int np = n - 1;                                    // pairs = rows other than the merged one
   const int ng = np > 48 ? 4 : (np > 32 ? 3 : (np > 16 ? 2 : 1));
   const dim3 grid((unsigned)g.blocks, (unsigned)B);
@@ -699,7 +699,7 @@ int launch_step2(nnj_handle* h, RowSet rs, const int* live_old, const int* ij, c
   if (has_ctx) {
     Scope sc(h, st, PK_ALPHA_SOFTMAX);
     hipLaunchKernelGGL(k_step_softmax, dim3(16, (unsigned)B), dim3(256), 0, st, rs, sw, ij, (const float*)(base + w.alpha_part),
-                       base + w.alpha, base + w.lam, base + w.beta_tot, rs.ntile32, n, C, g.blocks);
+                       base + w.alpha, base + w.lam, base + w.beta_slot, g.blocks, n, C);
   }
   {
     Scope sc(h, st, PK_PAIR_SCORE_INCR);
@@ -1246,7 +1246,7 @@ static int rollout_core(nnj_handle* h, const uint8_t* codes, const uint8_t* mask
   const bool use_cand = two_pass && h->two_pass_cand != 0;
   int* candbuf[2] = {reinterpret_cast<int*>(base + w.cand), reinterpret_cast<int*>(base + w.cand) + 2 * (size_t)B};
   bool prev_gave_am = false;                               // did the previous table kernel write am / need?
-  bool prev_lam = false;
+  bool prev_lam = false, prev_v2 = false;
   for (int step = 0, n = T; n >= 2; ++step, --n) {
     const int mode = step == 0 ? PAIRS_FULL : PAIRS_INCR;
     PairGeom g;
@@ -1256,6 +1256,7 @@ static int rollout_core(nnj_handle* h, const uint8_t* codes, const uint8_t* mask
       Step2 o;
       // without forced / sampled picks the pick of a step >= 1 of this kind is always covered (a new pair or the
       // candidate); the first such step follows a table whose kernels carry no logits
+      o.first = !prev_v2;
       o.fallback = !prev_lam || forced != nullptr || uniforms != nullptr || !use_cand;
       o.cand = use_cand;
       o.cand_cur = candbuf[step & 1];
@@ -1268,7 +1269,8 @@ static int rollout_core(nnj_handle* h, const uint8_t* codes, const uint8_t* mask
     StepOut so{};
     if (next_v2) {
       so.lam = (v2 && n > 2) ? base + w.lam : nullptr;
-      so.beta_tot = base + w.beta_tot;
+      so.beta_slot = base + w.beta_slot;
+      so.nslot = T;
       so.acand_part = (v2 && use_cand && n > 2) ? base + w.acand : nullptr;
       so.nblk = g.blocks;
       so.cand_cur = (v2 && use_cand && n > 2) ? candbuf[step & 1] : nullptr;
@@ -1290,6 +1292,7 @@ static int rollout_core(nnj_handle* h, const uint8_t* codes, const uint8_t* mask
     off += (size_t)n * (n - 1) / 2;
     prev_gave_am = next_v2;
     prev_lam = so.lam != nullptr;
+    prev_v2 = v2;
     if (n > 2 && !next_v2) {                                                                        // env.step :164
       if (int rc = launch_aggregate(h, rs, ij, base, w, S, base + w.U, base + w.Kp, base + w.beta, rs.bstride, T, 1, n,
                                     B, C, st)) return rc;

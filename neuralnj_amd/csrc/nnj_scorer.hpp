@@ -907,7 +907,8 @@ __global__ __launch_bounds__(256) void k_agg_finish(RowSet rs, ScorerW w, const 
 // named one step ago) and the candidate of the next step.  All null for the callers that do not use it.
 struct StepOut {
   const float* lam;           // [B][64 q][64 q'] summed logits of this step's new pairs (k_step_softmax), or null
-  const float* beta_tot;      // [B][64] summed beta partials of the rows of this table, by position
+  const float* beta_slot;     // [B][slots] per-row bias of the attention logits (sum of the row's beta partials + C t0)
+  int nslot;
   const float* acand_part;    // [B][nblk][64] logits of the candidate against the rows (k_step_alpha), or null
   int nblk;
   const int* cand_cur;        // [B][2] the candidate those logits belong to, positions of THIS table; (-1,-1) = none
@@ -938,6 +939,11 @@ __global__ __launch_bounds__(256) void k_assemble_argmax(const float* __restrict
                                                          int live_stride, int qn, StepOut so) {
   __shared__ float newsc[256];
   __shared__ int picked_j, picked_i;
+  // the two-pass step asks for the best entry WITHOUT the rows of the pick: the pass over the table keeps every
+  // entry's rows (and value) in LDS so that the second pass is a few LDS reads per thread
+  constexpr int PCACHE = 2304;
+  __shared__ unsigned short pcode[PCACHE];
+  __shared__ float pval[PCACHE];
   // the rollout keeps two live lists: this kernel also writes the NEXT one (the current list without position j:
   // environment.py:764-768), which used to be a launch of its own per step (k_update_live; 5 us of the 100 us of a
   // step at batch 1).  The current entries are loaded here, their latency hides behind the table pass.
@@ -968,19 +974,27 @@ __global__ __launch_bounds__(256) void k_assemble_argmax(const float* __restrict
   // barriers instead of the 16 + 8 of a shared-memory tree
   float best = -INFINITY, second = -INFINITY;
   int besti = 0x7fffffff;
+  const bool pc = so.cand_next != nullptr && np <= PCACHE;
   for (int p = tid; p < np; p += 256) {
     float v;
     if (mode == PAIRS_FULL) {
       v = 0.f;
 #pragma unroll 8
       for (int sc = 0; sc < nsc; ++sc) v += score_part[((size_t)b * nsc + sc) * ppad + p];
+      if (pc) {
+        int ii, jj;
+        pair_from_index(n, p, ii, jj);
+        pcode[p] = (unsigned short)(ii << 8 | jj);
+      }
     } else {
       int ii, jj;
       pair_from_index(n, p, ii, jj);
       if (ii == ip) v = newsc[jj];
       else if (jj == ip) v = newsc[ii];
       else v = logits_prev[(size_t)b * np_prev + pair_index(n + 1, ii + (ii >= jp), jj + (jj >= jp))];
+      if (pc) pcode[p] = (unsigned short)(ii << 8 | jj);
     }
+    if (pc) pval[p] = v;
     logits_out[(size_t)b * np + p] = v;
     if (trace_out) trace_out[(size_t)b * trace_bstride + p] = v;
     if (v > best) { second = best; best = v; besti = p; }       // p increases: a later equal value never replaces
@@ -1072,28 +1086,36 @@ __global__ __launch_bounds__(256) void k_assemble_argmax(const float* __restrict
   // ---- the two-pass step: weights of the merge just picked, candidate of the next step
   __syncthreads();
   const int pi_ = picked_i, pj_ = picked_j;
-  if (tid < 64) {
-    // source of the merged pair's logits a_r (nnj_step2.hpp): 1 = a pair scored in this step, 2 = the candidate
-    int src = 0, qs = 0;
-    if (mode == PAIRS_INCR && so.lam && (pi_ == ip || pj_ == ip)) {
-      src = 1;
-      const int rs_ = pi_ == ip ? pj_ : pi_;
-      qs = rs_ - (rs_ > ip ? 1 : 0);
-    } else if (so.acand_part && so.cand_cur && so.cand_cur[2 * b] == pi_ && so.cand_cur[2 * b + 1] == pj_) {
-      src = 2;
+  // source of the merged pair's logits a_r (nnj_step2.hpp): 1 = a pair scored in this step, 2 = the candidate
+  int src = 0, qs = 0;
+  if (mode == PAIRS_INCR && so.lam && (pi_ == ip || pj_ == ip)) {
+    src = 1;
+    const int rs_ = pi_ == ip ? pj_ : pi_;
+    qs = rs_ - (rs_ > ip ? 1 : 0);
+  } else if (so.acand_part && so.cand_cur && so.cand_cur[2 * b] == pi_ && so.cand_cur[2 * b + 1] == pj_) {
+    src = 2;
+  }
+  if (src == 2) {
+    // the candidate's logits: the partials of the k_step_alpha workgroups, four threads per row (every 4th block
+    // each), the four sums added in order by wave 0 below
+    const int r = tid & 63, part = tid >> 6;
+    float a = 0.f;
+    if (r < n) {
+      const int col = (mode == PAIRS_INCR && r == ip) ? 63 : r - ((mode == PAIRS_INCR && r > ip) ? 1 : 0);
+      for (int k = part; k < so.nblk; k += 4) a += so.acand_part[((size_t)b * so.nblk + k) * 64 + col];
     }
+    pval[PCACHE - 256 + tid] = a;                           // (entries the table never reaches: np <= 2080 when src == 2)
+    __syncthreads();
+  }
+  if (tid < 64) {
     const int r = tid;
     const bool in = src != 0 && n > 2 && r < n && r != pi_ && r != pj_;
     float v = -INFINITY;
     if (in) {
-      float a = 0.f;
-      if (src == 1) {
-        a = so.lam[((size_t)b * 64 + qs) * 64 + (r - (r > ip ? 1 : 0))];
-      } else {
-        const int col = (mode == PAIRS_INCR && r == ip) ? 63 : r - ((mode == PAIRS_INCR && r > ip) ? 1 : 0);
-        for (int k = 0; k < so.nblk; ++k) a += so.acand_part[((size_t)b * so.nblk + k) * 64 + col];
-      }
-      v = (a + so.beta_tot[(size_t)b * 64 + r]) * so.inv_scale;
+      float a;
+      if (src == 1) a = so.lam[((size_t)b * 64 + qs) * 64 + (r - (r > ip ? 1 : 0))];
+      else a = ((pval[PCACHE - 256 + r] + pval[PCACHE - 192 + r]) + pval[PCACHE - 128 + r]) + pval[PCACHE - 64 + r];
+      v = (a + so.beta_slot[(size_t)b * so.nslot + live_cur[(size_t)b * live_stride + r]]) * so.inv_scale;
     }
     float mx = v;
 #pragma unroll
@@ -1114,9 +1136,10 @@ __global__ __launch_bounds__(256) void k_assemble_argmax(const float* __restrict
   int cbi = 0x7fffffff;
   for (int p = tid; p < np; p += 256) {
     int ii, jj;
-    pair_from_index(n, p, ii, jj);
+    float v;
+    if (pc) { const int code = pcode[p]; ii = code >> 8; jj = code & 255; v = pval[p]; }
+    else { pair_from_index(n, p, ii, jj); v = logits_out[(size_t)b * np + p]; }
     if (ii == pi_ || ii == pj_ || jj == pi_ || jj == pj_) continue;
-    const float v = logits_out[(size_t)b * np + p];
     if (v > cb) { cb = v; cbi = p; }
   }
 #pragma unroll

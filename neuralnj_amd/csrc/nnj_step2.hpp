@@ -37,9 +37,23 @@ struct StepIO {
   float* beta_w;
   int beta_n;                 // beta partials per row in use (entries beyond the writer's block count are zeroed)
   const int* cand;            // [B][2] best OLD pair of the coming table by new position, (-1, -1) = none
-  const float* Xc;            // [B][C][64] x' = A^T x of that pair
+  const int* cand_run;        // [B] 1 = the x' row in Xc belongs to another pair: the workgroups rewrite their sites first
+  float* Xc;                  // [B][C][64] x' = A^T x of that pair
   float* acand_part;          // [B][blocks][64]: [q] = sum_c x'_cand . S_r(q), [63] = ... . S_m
 };
+
+// beta_slot[b][slot] = sum of the row's beta partials + C t0 (the per-row bias of the attention logits: it changes only
+// when the row does).  One thread per row; run once when the two-pass steps take over from the other kernels.
+__global__ void k_beta_sum(const float* __restrict__ beta_part, int stride, int nb, float ct0, float* __restrict__ beta_slot,
+                           int total) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const float* bp = beta_part + (size_t)i * stride;
+  float s = 0.f;
+#pragma unroll 8
+  for (int t = 0; t < nb; ++t) s += bp[t];
+  beta_slot[i] = s + ct0;
+}
 
 // x' = A^T gate(S_a, S_b) of ONE designated pair per alignment (positions `pair[b]`, list `live`), tokens = sites.
 // Used for the candidate pair (skipped while `skip[b]` says the row in Xout is still the right one) and by the
@@ -135,7 +149,42 @@ __global__ __launch_bounds__(64 * NW) void k_step_alpha(RowSet rs, ScorerW w, St
   const bool pairs = n > 2;                                // with two rows left the one new pair has no context (model.py:111)
   const int ca = io.cand ? io.cand[2 * b] : -1;
   const bool has_cand = ca >= 0 && pairs;
-  const float* Xc = io.Xc + (size_t)b * C * 64;
+  float* Xc = io.Xc + (size_t)b * C * 64;
+  if (has_cand && io.cand_run[b]) {
+    // the candidate changed: x' = A^T gate(S_a, S_b) of its rows for this workgroup's sites, 16 sites per wave and pass
+    // (tokens = sites), written to Xc and read back below (the lines are in nobody's L1 yet)
+    const int cb2 = io.cand[2 * b + 1];
+    const float* Sa = rs.S + bo + (size_t)slot_of(rs, b, ca) * C * 64;
+    const float* Sb = rs.S + bo + (size_t)slot_of(rs, b, cb2) * C * 64;
+    const float* Ua = rs.U + bo + (size_t)slot_of(rs, b, ca) * C * 64;
+    const float* Ub = rs.U + bo + (size_t)slot_of(rs, b, cb2) * C * 64;
+    for (int cc0 = c0 + 16 * wave; cc0 < c1; cc0 += 16 * NW) {
+      const int cc = cc0 + l15;
+      const bool ok = cc < c1;
+      const size_t o = (size_t)(ok ? cc : c1 - 1) * 64;
+      V64 sa, sb, ua, ub, x;
+      load_v64(sa, Sa + o, kq); load_v64(sb, Sb + o, kq);
+      load_v64(ua, Ua + o, kq); load_v64(ub, Ub + o, kq);
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) {
+        const f32x4 b4 = *reinterpret_cast<const f32x4*>(cv + 16 * mt + 4 * kq);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float z = sigmoid_l2(ua.t[mt][e] - ub.t[mt][e] + b4[e]);
+          x.t[mt][e] = sb.t[mt][e] + z * (sa.t[mt][e] - sb.t[mt][e]);
+        }
+      }
+      V64 xp;
+      lds_wait_all();
+      linear_t16p<4, false, false>(xp.t, x, At_l, nullptr, lane);
+      if (ok) {
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) *reinterpret_cast<f32x4*>(Xc + o + 16 * mt + 4 * kq) = xp.t[mt];
+      }
+    }
+    __threadfence_block();
+    __syncthreads();
+  }
   const float u_l = w.u[lane];                             // wave 0 of a site: one feature per lane
   const float bh_l = cv[lane];
   f32x4 acc[NG];
@@ -328,31 +377,32 @@ __global__ __launch_bounds__(64 * NW) void k_step_alpha(RowSet rs, ScorerW w, St
 
 // ------------------------------------------------------------------ k_step_softmax
 // alpha[b][q][q'] = softmax_q'((lam + beta_r(q')) / sqrt(64 C)) over the rows other than m and r(q); lam = the summed
-// partials of k_step_alpha, kept for the next merge; beta_tot[b][r] = the summed beta partials of every row r < n.
-// One wave per pair q, lane = q'.  grid (16, B).
+// partials of k_step_alpha, kept for the next merge.  The last wave of the grid also sums the beta partials
+// k_step_alpha wrote for the merged row into beta_slot (no pair of this step has m in its context; the table kernel
+// and later steps do).  One wave per pair q, lane = q'.  grid (16, B).
 __global__ __launch_bounds__(256) void k_step_softmax(RowSet rs, ScorerW w, const int* __restrict__ ij_prev,
                                                       const float* __restrict__ alpha_part, float* __restrict__ alpha,
-                                                      float* __restrict__ lam, float* __restrict__ beta_tot, int beta_n,
-                                                      int n, int C, int nsc) {
+                                                      float* __restrict__ lam, float* __restrict__ beta_slot, int nblk,
+                                                      int n, int C) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int q = blockIdx.x * 4 + wave, b = blockIdx.y;
   const int m = min(max(ij_prev[2 * b], 0), n - 1);
+  const int nrow = (int)(rs.bstride / ((long)C * 64));
+  if (q == 63) {                                           // (q <= 62 are pairs: n - 1 <= 63)
+    const float* bp = rs.beta_part + ((size_t)b * nrow + slot_of(rs, b, m)) * rs.ntile32;
+    float s = 0.f;
+    for (int t = lane; t < nblk; t += 64) s += bp[t];
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) beta_slot[(size_t)b * nrow + slot_of(rs, b, m)] = s + (float)C * w.t0;
+  }
   float a = 0.f;
 #pragma unroll 8          // independent loads in flight; the additions stay in order
-  for (int sc = 0; sc < nsc; ++sc) a += alpha_part[(((size_t)b * nsc + sc) * 64 + q) * 64 + lane];
+  for (int sc = 0; sc < nblk; ++sc) a += alpha_part[(((size_t)b * nblk + sc) * 64 + q) * 64 + lane];
   lam[((size_t)b * 64 + q) * 64 + lane] = a;
-  const int nrow = (int)(rs.bstride / ((long)C * 64));
-  auto beta_of = [&](int r) {
-    const float* bp = rs.beta_part + ((size_t)b * nrow + slot_of(rs, b, r)) * rs.ntile32;
-    float s = 0.f;
-#pragma unroll 8
-    for (int t = 0; t < beta_n; ++t) s += bp[t];
-    return s + (float)C * w.t0;
-  };
-  if (q == 0 && lane < n) beta_tot[(size_t)b * 64 + lane] = beta_of(lane);
   const bool in = q < n - 1 && lane < n - 1 && lane != q;
   float v = -INFINITY;
-  if (in) v = (a + beta_of(q_to_r(lane, m))) * (1.0f / sqrtf(64.0f * (float)C));
+  if (in) v = (a + beta_slot[(size_t)b * nrow + slot_of(rs, b, q_to_r(lane, m))]) * (1.0f / sqrtf(64.0f * (float)C));
   float mx = v;
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
@@ -401,8 +451,8 @@ __global__ __launch_bounds__(256) void k_agg_dot(RowSet rs, const float* __restr
 // am[b][r'] (positions AFTER the merge of (i, j): position j removed, 0 at i) = softmax over the rows other than i, j of
 // (sum of the chunk partials + beta_r) / sqrt(64 C).  One wave per alignment; n = rows before the merge (<= 65).
 __global__ __launch_bounds__(64) void k_agg_am(RowSet rs, ScorerW w, const int* __restrict__ ij, const int* __restrict__ need,
-                                               const float* __restrict__ part, int nch, int rp, int beta_n,
-                                               float* __restrict__ am, int n, int C) {
+                                               const float* __restrict__ part, int nch, int rp,
+                                               const float* __restrict__ beta_slot, float* __restrict__ am, int n, int C) {
   const int b = blockIdx.x, lane = threadIdx.x;
   if (need && !need[b]) return;
   const int pi = min(max(ij[2 * b], 0), n - 1), pj = min(max(ij[2 * b + 1], 0), n - 1);
@@ -419,11 +469,7 @@ __global__ __launch_bounds__(64) void k_agg_am(RowSet rs, ScorerW w, const int* 
       float s = 0.f;
 #pragma unroll 16
       for (int ch = 0; ch < nch; ++ch) s += part[((size_t)b * nch + ch) * rp + r];
-      const float* bp = rs.beta_part + ((size_t)b * nrow + slot_of(rs, b, r)) * rs.ntile32;
-      float beta = 0.f;
-#pragma unroll 8
-      for (int t = 0; t < beta_n; ++t) beta += bp[t];
-      v[k] = (s + beta + (float)C * w.t0) * (1.0f / sqrtf(64.0f * (float)C));
+      v[k] = (s + beta_slot[(size_t)b * nrow + slot_of(rs, b, r)]) * (1.0f / sqrtf(64.0f * (float)C));
     }
     mx = fmaxf(mx, v[k]);
   }
