@@ -6,7 +6,13 @@ full size is the oracle -- itself pinned to the reference's outputs on every fix
 and the complete score tables of eight sampled steps.  tests/test_gpu_parity.py teacher-forces the HIP rollout along
 the stored merges and asserts the tables within 1e-4 ("next round" 2b).
 
-Takes tens of minutes of CPU; run once:   python tests/golden/gen_cfg5_f64.py [threads]
+Beside every fp64 table the file keeps how far the plain-fp32 build of the same oracle (the reference's arithmetic,
+teacher-forced along the same merges) is from it: under the stress ("sharp") weights the six encoder layers amplify
+fp32 rounding of the encoder output (1-3e-5) about twenty-fold into the tables, so NO fp32 evaluation of this shape is
+within 1e-4 of the truth there; the "plain" (reference-scale) weights give the second file, where 1e-4 is asserted
+outright.
+
+Takes tens of minutes of CPU per style; run once:   python tests/golden/gen_cfg5_f64.py [threads] [sharp|plain]
 """
 import hashlib
 import os
@@ -29,23 +35,40 @@ STEPS = (0, 1, 40, 90, 135, 136, 170, 197)        # rows live: 200, 199, 160, 11
 
 def main():
     threads = int(sys.argv[1]) if len(sys.argv) > 1 else 6
+    style = sys.argv[2] if len(sys.argv) > 2 else "sharp"
+    path = os.path.join(HERE, "cfg5_f64_t200_l4096.npz" if style == "sharp" else f"cfg5_f64_{style}_t200_l4096.npz")
     cfgs = utils.shipped_config()
-    packed = weights.pack(cfgs, weights.seeded_state(cfgs, 0, "sharp"))
+    packed = weights.pack(cfgs, weights.seeded_state(cfgs, 0, style))
     codes = synth.synth_codes_tree(1, T, L, seed=SEED)
-    o = Oracle(cfgs, packed, "f64")
-    o.set_threads(threads)
-    t0 = time.time()
-    ref = o.rollout_argmax(onehot_f32(codes), None)
-    dt = time.time() - t0
-    tabs = split_trace(ref["logits"], T)
-    out = dict(codes_sha256=hashlib.sha256(codes.tobytes()).hexdigest(), shape=np.array([T, L]), seed=SEED,
-               wseed=0, style="sharp", weights_sha256=weights.digest(packed), merges=ref["merges"][0],
-               top2_gap=ref["top2_gap"][0], steps=np.array(STEPS), oracle_seconds=dt,
-               scale=float(np.abs(ref["logits"]).max()))
-    for s in STEPS:
-        out[f"table_{s}"] = tabs[s][0]
-    np.savez_compressed(os.path.join(HERE, "cfg5_f64_t200_l4096.npz"), **out)
-    print(f"done in {dt:.0f} s, scale {out['scale']:.2f}")
+    if os.path.exists(path):
+        out = dict(np.load(path))
+    else:
+        o = Oracle(cfgs, packed, "f64")
+        o.set_threads(threads)
+        t0 = time.time()
+        ref = o.rollout_argmax(onehot_f32(codes), None)
+        dt = time.time() - t0
+        tabs = split_trace(ref["logits"], T)
+        out = dict(codes_sha256=hashlib.sha256(codes.tobytes()).hexdigest(), shape=np.array([T, L]), seed=SEED,
+                   wseed=0, style=style, weights_sha256=weights.digest(packed), merges=ref["merges"][0],
+                   top2_gap=ref["top2_gap"][0], steps=np.array(STEPS), oracle_seconds=dt,
+                   scale=float(np.abs(ref["logits"]).max()))
+        for s in STEPS:
+            out[f"table_{s}"] = tabs[s][0]
+        np.savez_compressed(path, **out)
+        print(f"fp64 free run done in {dt:.0f} s, scale {out['scale']:.2f}", flush=True)
+    if "o32_err" not in out:
+        # the plain-fp32 build along the same merges: its distance from the fp64 tables, per stored step
+        o32 = Oracle(cfgs, packed)
+        o32.set_threads(threads)
+        t0 = time.time()
+        r32 = o32.rollout_argmax(onehot_f32(codes), None, forced_merges=out["merges"][None])
+        t32 = split_trace(r32["logits"], T)
+        out["o32_err"] = np.array([float(np.abs(t32[int(s)][0] - out[f"table_{int(s)}"]).max()) for s in out["steps"]])
+        out["o32_seconds"] = time.time() - t0
+        np.savez_compressed(path, **out)
+        print("fp32 oracle vs fp64, per stored step (abs):", out["o32_err"], flush=True)
+    print("done", path)
 
 
 if __name__ == "__main__":

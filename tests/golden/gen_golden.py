@@ -310,6 +310,19 @@ def main():
         run_case("synth_b1_t100_l256_s11", codes, np.zeros((1, 256), dtype=bool), 11, "sharp", ref)
     add("synth_b1_t100_l256_s11", wide_synth)
 
+    # round 3: 200 taxa (the kernels above 128 rows were pinned through the oracle only), and two more 100-taxon
+    # alignments under the stress weights (how far do fp32-level evaluations of this shape scatter?)
+    def wide_200():
+        codes = synth.synth_codes_tree(1, 200, 256, 2013)
+        run_case("synth_b1_t200_l256_s13", codes, np.zeros((1, 256), dtype=bool), 13, "sharp", ref)
+    add("synth_b1_t200_l256_s13", wide_200)
+
+    for sd in (14, 15):
+        def wide_100(sd=sd):
+            codes = synth.synth_codes_tree(1, 100, 256, 2000 + sd)
+            run_case(f"synth_b1_t100_l256_s{sd}", codes, np.zeros((1, 256), dtype=bool), sd, "sharp", ref)
+        add(f"synth_b1_t100_l256_s{sd}", wide_100)
+
     def wide_70():
         codes = synth.synth_codes_tree(2, 70, 64, 2012)
         run_case("synth_b2_t70_l64_s12", codes, np.zeros((2, 64), dtype=bool), 12, "plain", ref)

@@ -3,6 +3,8 @@ golden vectors captured from the reference, and size-independent properties at t
 BASELINE sizes.  Tolerance: pair scores within 1e-4 of the table's scale (BASELINE.json:
 "pairwise-distance floats within 1e-4 relative"); merge lists exact wherever the
 reference's own top-2 gap is decisive (> 4e-4 of the scale), i.e. RF = 0."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -473,6 +475,32 @@ def test_model_env_api_follows_reference_call_sequence():
     np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), atol=2e-5)   # LUT path == MLP path
 
 
+def _certify_sampled(ref, merges, logits_g, u, temperature, T):
+    """Sampled trajectories against the oracle twin (same uniforms): identical, except where the uniform lands within
+    fp32 rounding of a CDF boundary of the oracle's own table -- at the first divergent step of a differing trajectory
+    the two picks must be NEIGHBOURS in the flat pair order and the target u * total within the tables' rounding of
+    the boundary between them.  Returns the per-trajectory agreement flags."""
+    agree = (ref["merges"] == merges).all(axis=(1, 2))
+    tabs_o = split_trace(ref["logits"], T)
+    tabs_g = split_trace(logits_g, T)
+    for b in np.nonzero(~agree)[0]:
+        s_ = int(np.argmax(np.any(ref["merges"][b] != merges[b], axis=1)))
+        n = T - s_
+        to = tabs_o[s_][b].astype(np.float64)
+        assert_logits_close(tabs_g[s_][b], tabs_o[s_][b], RTOL, "table at the divergent step")
+        e = np.exp((to - to.max()) / temperature)
+        cdf = np.cumsum(e)
+        k_o = flat_pair(n, *ref["merges"][b, s_])
+        k_g = flat_pair(n, *merges[b, s_])
+        assert abs(k_o - k_g) == 1, "sampled picks are not neighbours in the CDF"
+        target = float(u[b, s_]) * cdf[-1]
+        boundary = cdf[min(k_o, k_g)]
+        # table entries within RTOL * scale move every CDF value by at most that (relative, / temperature)
+        slack = (RTOL * max(float(np.abs(to).max()), 1.0) / temperature) * cdf[-1] * 2
+        assert abs(target - boundary) <= slack, f"trajectory {b} step {s_}: not a CDF-boundary case"
+    return agree
+
+
 def test_sampling_mode_matches_oracle_and_replicates(ctx_cache):
     """nnj_rollout_sample (NeuralNJ-MC device part, finetune_rl_search.py:147): same sampled merge lists
     as the oracle for the same uniforms; encode-once-and-replicate equals B explicit copies bit for bit;
@@ -495,24 +523,7 @@ def test_sampling_mode_matches_oracle_and_replicates(ctx_cache):
     # identical trajectories, except where the uniform lands within fp32 rounding of a CDF boundary of the
     # oracle's own table: at the first divergent step of a differing trajectory the two picks must be
     # NEIGHBOURS in the flat pair order and the target u * total within the tables' rounding of the boundary
-    agree = (ref["merges"] == merges).all(axis=(1, 2))
-    tabs_o = split_trace(ref["logits"], T)
-    tabs_g = split_trace(r_all["logits"].cpu().numpy(), T)
-    for b in np.nonzero(~agree)[0]:
-        s_ = int(np.argmax(np.any(ref["merges"][b] != merges[b], axis=1)))
-        n = T - s_
-        to = tabs_o[s_][b].astype(np.float64)
-        assert_logits_close(tabs_g[s_][b], tabs_o[s_][b], RTOL, "table at the divergent step")
-        e = np.exp((to - to.max()) / 3.0)
-        cdf = np.cumsum(e)
-        k_o = flat_pair(n, *ref["merges"][b, s_])
-        k_g = flat_pair(n, *merges[b, s_])
-        assert abs(k_o - k_g) == 1, "sampled picks are not neighbours in the CDF"
-        target = float(u[b, s_]) * cdf[-1]
-        boundary = cdf[min(k_o, k_g)]
-        # table entries within RTOL * scale move every CDF value by at most that (relative, / temperature)
-        slack = (RTOL * max(float(np.abs(to).max()), 1.0) / 3.0) * cdf[-1] * 2
-        assert abs(target - boundary) <= slack, f"trajectory {b} step {s_}: not a CDF-boundary case"
+    agree = _certify_sampled(ref, merges, r_all["logits"].cpu().numpy(), u, 3.0, T)
     assert agree.mean() >= 0.5
     assert_logits_close(r_all["logits"].cpu().numpy()[agree], ref["logits"][agree], RTOL, "sampled tables")
     cold = g.rollout_sample(torch.from_numpy(codes1), torch.from_numpy(mask1), u[:1], temperature=1e-4)
@@ -694,3 +705,69 @@ def test_small_magnitude_weights(ctx_cache):
         scale = np.abs(ref["logits"]).max()
         decisive = ref["top2_gap"] > 4 * RTOL * max(scale, 1.0)
         assert (ref["merges"][decisive] == merges[decisive]).all()
+
+
+def test_config5_200x4096_matches_fp64_golden(ctx_cache):
+    """BASELINE configs[4] at the FULL size against the float64 oracle (tests/golden/gen_cfg5_f64.py: a free Argmax
+    run of one 200 x 4096 alignment, 22 minutes of CPU): the HIP rollout teacher-forced along the stored merges must
+    give the complete score tables of eight sampled steps (200 ... 3 rows live: star kernels, the 65 -> 64 row
+    hand-over, the two-pass steps) within 1e-4 of each table's scale, and pick the stored pair wherever the fp64
+    top-2 gap is decisive."""
+    import hashlib
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "cfg5_f64_t200_l4096.npz"))
+    T, L = (int(v) for v in z["shape"])
+    cfgs = utils.shipped_config()
+    packed = weights.pack(cfgs, weights.seeded_state(cfgs, int(z["wseed"]), str(z["style"])))
+    assert weights.digest(packed) == str(z["weights_sha256"])
+    codes = synth.synth_codes_tree(1, T, L, seed=int(z["seed"]))
+    assert hashlib.sha256(codes.tobytes()).hexdigest() == str(z["codes_sha256"])
+    g = ctx_cache(cfgs, packed)
+    r = g.rollout_argmax(torch.from_numpy(codes), None, forced_merges=z["merges"][None], want_trace=True)
+    g.check_numeric()
+    tabs = split_trace(r["logits"].cpu().numpy(), T)
+    worst = 0.0
+    for s in z["steps"]:
+        worst = max(worst, assert_logits_close(tabs[int(s)][0], z[f"table_{int(s)}"], RTOL, f"step {int(s)} ({T - int(s)} rows)"))
+    print(f"200 x 4096 vs fp64 golden: worst table error {worst:.2e} of its scale")
+    free = g.rollout_argmax(torch.from_numpy(codes), None)["merges"].cpu().numpy()[0]
+    decisive = z["top2_gap"] > 4 * RTOL * float(z["scale"])
+    first_bad = next((s for s in range(T - 1) if not np.array_equal(free[s], z["merges"][s])), T - 1)
+    assert first_bad == T - 1 or not decisive[first_bad], f"free run leaves the fp64 merge list at decisive step {first_bad}"
+
+
+def _cfg5_golden(style):
+    name = "cfg5_f64_t200_l4096.npz" if style == "sharp" else f"cfg5_f64_{style}_t200_l4096.npz"
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name)
+    return np.load(path) if os.path.exists(path) else None
+
+
+def test_search_mode_at_config5_200x4096(ctx_cache):
+    """BASELINE configs[4] in Search mode (infer_opt=Search: sampled rollouts, finetune_rl_search.py:338-427) at the
+    full size: eight replicas of ONE 200 x 4096 alignment, encoded once.  (1) merge lists are valid and not all equal;
+    (2) the tables of a sampled rollout are those of the Argmax rollout teacher-forced along the same merges, bit for
+    bit (same kernels, same batch geometry); (3) the duplicate filter's keys agree with the merge lists; (4) on a
+    160-site window of the same alignment (all 200 rows live: the oracle needs minutes for 4096 sites) the sampled
+    trajectories are the oracle twin's for the same uniforms, CDF-boundary cases certified."""
+    cfgs = utils.shipped_config()
+    packed = weights.pack(cfgs, weights.seeded_state(cfgs, 0, "sharp"))
+    g = ctx_cache(cfgs, packed)
+    T, L, R = 200, 4096, 8
+    one = synth.synth_codes_tree(1, T, L, seed=4242)
+    u = np.random.default_rng(5).random((R, T - 1)).astype(np.float32)
+    rs = g.rollout_sample(torch.from_numpy(one), None, u, temperature=1.0, replicas=R, want_trace=True)
+    g.check_numeric()
+    merges = rs["merges"].cpu().numpy()
+    assert (merges[:, :, 0] < merges[:, :, 1]).all() and (merges[:, :, 1] < np.arange(T, 1, -1)[None, :]).all()
+    assert len({tuple(m.reshape(-1)) for m in merges}) > 1
+    forced = g.rollout_argmax(torch.from_numpy(np.repeat(one, R, 0)), None, forced_merges=merges, want_trace=True)
+    assert torch.equal(forced["logits"], rs["logits"])
+    keys = g.topology_hash(rs["merges"]).cpu().numpy()
+    same_tree = {tuple(m.reshape(-1)) for m in merges}
+    assert len(set(keys.tolist())) <= len(same_tree)
+    win = one[:, :, :160]
+    o = _oracle(cfgs, packed)
+    uw = u[:4]
+    ref = o.rollout_sample(onehot_f32(np.repeat(win, 4, 0)), np.zeros((4, 160), bool), uw, temperature=1.0)
+    got = g.rollout_sample(torch.from_numpy(win), None, uw, temperature=1.0, replicas=4, want_trace=True)
+    agree = _certify_sampled(ref, got["merges"].cpu().numpy(), got["logits"].cpu().numpy(), uw, 1.0, T)
+    assert agree.mean() >= 0.5
