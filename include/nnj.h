@@ -226,6 +226,17 @@ int nnj_tree_loglik(nnj_handle* h, const uint8_t* codes_dev, int32_t n_align, co
                     const int32_t* merges_dev, const float* brlen_dev, const nnj_subst_model* model_host,
                     int32_t B, int32_t T, int32_t L, double* loglik_out_dev, void* ws_dev, size_t ws_bytes, void* stream);
 
+/* Probe of the substitution model (how the likelihood kernels are pinned to the data the reference holds): the model
+ * the entry points build from `model_host` -- the rate matrix Q = U diag(lam) U^-1 normalised to one expected
+ * substitution per unit time (Q_out, host, 16 doubles, row-major A C G T) and the ncat discrete-gamma category rates
+ * (rates_out, host, ncat doubles, mean 1 over the gamma part) -- and the transition matrices P(rate_c * t) of ONE
+ * branch of length t exactly as the device kernel forms them (P_out, host, ncat x 16 doubles).  Synchronous.
+ * The reference's bundled test set keeps, for each of its 1,152 simulated alignments, the IQ-TREE log of the
+ * simulation (data_gen/data/test/<len>/<taxa>/<name>_raw.tre.log) with the GTR parameters, the normalised Q and the
+ * category rates: tests/golden/iqtree_models.npz, checked by tests/test_likelihood.py through this entry point. */
+int nnj_lik_model_probe(nnj_handle* h, const nnj_subst_model* model_host, double t, double* Q_out, double* rates_out,
+                        double* P_out);
+
 /* Branch-length optimisation, then the log-likelihood: `sweeps` rounds (the reference asks raxml-ng for iters=3) of
  * one Newton-Raphson solve per edge, all edges of all trees at once from the same partial likelihoods, the step per
  * tree halved until the likelihood does not drop.  brlen_out_dev float [B,T-1,2] or NULL. */

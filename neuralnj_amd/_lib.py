@@ -58,6 +58,8 @@ _SIGS = {
     "nnj_lik_workspace_bytes": ([C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_size_t)], C.c_int),
     "nnj_tree_loglik": ([_vp, _vp, C.c_int32, _vp, _vp, _vp, C.POINTER(NnjSubstModel), C.c_int32, C.c_int32, C.c_int32, _vp,
                          _vp, C.c_size_t, _vp], C.c_int),
+    "nnj_lik_model_probe": ([_vp, C.POINTER(NnjSubstModel), C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double),
+                             C.POINTER(C.c_double)], C.c_int),
     "nnj_tree_optimize": ([_vp, _vp, C.c_int32, _vp, _vp, _vp, C.POINTER(NnjSubstModel), C.c_int32, C.c_int32, C.c_int32,
                            C.c_int32, _vp, _vp, _vp, C.c_size_t, _vp], C.c_int),
     "nnj_debug_encoder_stop": ([_vp, C.c_int32], C.c_int),

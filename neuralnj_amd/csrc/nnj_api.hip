@@ -1520,12 +1520,13 @@ int build_model(const nnj_subst_model* m, LikModel& md, char* err) {
   return NNJ_OK;
 }
 
-struct LikWs { size_t prog, brlen, brlen_new, brlen_try, pmat, inv, down, outer, site, ll, ll_try, step, end; };   // in doubles
+struct LikWs { size_t prog, colour, brlen, brlen_new, brlen_try, pmat, inv, down, outer, site, ll, ll_try, step, end; };   // in doubles
 LikWs lik_ws(int B, int nA, int T, int L, int nc) {
   LikWs w; size_t o = 0;
   auto take = [&](size_t n) { size_t r = o; o += align_up(n, 32); return r; };
   const size_t NN = 2 * (size_t)T - 2;
   w.prog = take(((size_t)B * (T - 1) * 2 + 1) / 2);
+  w.colour = take(((size_t)B * NN + 1) / 2);
   w.brlen = take(B * NN); w.brlen_new = take(B * NN); w.brlen_try = take(B * NN);
   w.pmat = take(B * NN * nc * 16);
   w.inv = take((size_t)nA * L);
@@ -1579,7 +1580,8 @@ int lik_common(nnj_handle* h, const uint8_t* codes, int nA, const uint8_t* mask,
   h->sess.valid = false;
   base = static_cast<double*>(ws);
   int* prog = reinterpret_cast<int*>(base + w.prog);
-  hipLaunchKernelGGL(k_lik_program, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, st, merges, prog, B, T);
+  hipLaunchKernelGGL(k_lik_program, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, st, merges, prog,
+                     reinterpret_cast<int*>(base + w.colour), B, T);
   const int ne = B * (T - 1) * 2;
   hipLaunchKernelGGL(k_lik_brlen_init, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, st, (const int*)prog, brlen_in, 0.1,
                      base + w.brlen, B, T);
@@ -1613,6 +1615,33 @@ int nnj_tree_loglik(nnj_handle* h, const uint8_t* codes, int32_t n_align, const 
   return NNJ_OK;
 }
 
+int nnj_lik_model_probe(nnj_handle* h, const nnj_subst_model* model, double t, double* Q_out, double* rates_out,
+                        double* P_out) {
+  if (!h) return fail(nullptr, NNJ_ERR_ARG, "null handle");
+  DevGuard dev_guard;
+  HIPCHK(h, hipSetDevice(h->cfg.device));
+  if (!model || !Q_out || !rates_out || !P_out || !(t >= 0.0)) return fail(h, NNJ_ERR_ARG, "nnj_lik_model_probe: bad argument");
+  LikModel md;
+  if (int rc = build_model(model, md, h->err)) return rc;
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 4; ++j) {
+      double s = 0.0;
+      for (int k = 0; k < 4; ++k) s += md.U[i * 4 + k] * md.lam[k] * md.Uinv[k * 4 + j];
+      Q_out[i * 4 + j] = s;
+    }
+  for (int c = 0; c < md.ncat; ++c) rates_out[c] = md.rates[c];
+  double* d = nullptr;
+  HIPCHK(h, hipMalloc(&d, (size_t)(1 + md.ncat * 16) * sizeof(double)));
+  hipError_t e = hipMemcpy(d, &t, sizeof(double), hipMemcpyHostToDevice);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(k_lik_pmats, dim3(1), dim3(256), 0, nullptr, (const double*)d, md, d + 1, md.ncat);
+    e = hipMemcpy(P_out, d + 1, (size_t)md.ncat * 16 * sizeof(double), hipMemcpyDeviceToHost);
+  }
+  hipFree(d);
+  if (e != hipSuccess) return fail(h, NNJ_ERR_HIP, "nnj_lik_model_probe: %s", hipGetErrorString(e));
+  return NNJ_OK;
+}
+
 int nnj_tree_optimize(nnj_handle* h, const uint8_t* codes, int32_t n_align, const uint8_t* mask, const int32_t* merges,
                       const float* brlen_in, const nnj_subst_model* model, int32_t sweeps, int32_t B, int32_t T, int32_t L,
                       float* brlen_out, double* loglik_out, void* ws, size_t ws_bytes, void* stream) {
@@ -1626,33 +1655,36 @@ int nnj_tree_optimize(nnj_handle* h, const uint8_t* codes, int32_t n_align, cons
   const int NN = 2 * T - 2;
   const int* prog = reinterpret_cast<const int*>(base + w.prog);
   // the two child edges of the last join are one edge of the unrooted tree: folded for the sweeps, split on export
-  if (sweeps > 0)
+  const bool fold = getenv("NNJ_LIK_NOFOLD") == nullptr;
+  if (sweeps > 0 && fold)
     hipLaunchKernelGGL(k_lik_root_fold, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, st, prog, base + w.brlen, B, T, 0);
   lik_eval(h, codes, n_align, md, w, base, base + w.brlen, base + w.ll, B, T, L, st);
+  const int* colour = reinterpret_cast<const int*>(base + w.colour);
   for (int sw = 0; sw < sweeps; ++sw) {
-    // partials on both sides of every edge from the current lengths (pmat and down are current), then one
-    // Newton-Raphson solve per edge, all edges at once
-    hipLaunchKernelGGL(k_lik_outer, dim3((unsigned)((L + 127) / 128), (unsigned)B), dim3(128), 0, st, codes, n_align, prog,
-                       (const double*)(base + w.pmat), md, (const double*)(base + w.down), base + w.outer, T, L);
-    hipLaunchKernelGGL(k_lik_newton, dim3((unsigned)NN, (unsigned)B), dim3(256), 0, st, codes, n_align,
-                       (const double*)(base + w.inv), (const double*)(base + w.down), (const double*)(base + w.outer), md, prog,
-                       (const double*)(base + w.brlen), base + w.brlen_new, T, L, 12);
-    // a simultaneous update of all edges can overshoot: take the full step if the likelihood does not drop, else
-    // half of it, a quarter, an eighth (per tree, decided on the device)
-    hipLaunchKernelGGL(k_fill, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, st, base + w.step, 1.0, B);
-    for (int tr = 0; tr < 4; ++tr) {
-      hipLaunchKernelGGL(k_lik_blend, dim3((unsigned)((B * NN + 255) / 256)), dim3(256), 0, st, (const double*)(base + w.brlen),
-                         (const double*)(base + w.brlen_new), (const double*)(base + w.step), base + w.brlen_try, B, NN);
-      lik_eval(h, codes, n_align, md, w, base, base + w.brlen_try, base + w.ll_try, B, T, L, st);
-      hipLaunchKernelGGL(k_lik_accept, dim3((unsigned)B), dim3(64), 0, st, base + w.ll, (const double*)(base + w.ll_try),
-                         base + w.step, base + w.brlen, (const double*)(base + w.brlen_try), B, NN);
+    // one Gauss-Seidel pass = four colour steps (k_lik_program): partials on both sides of every edge from the current
+    // lengths (pmat and down are current), one Newton-Raphson solve per edge of the colour, the step taken in full if
+    // the likelihood does not drop, else halved (per tree, decided on the device), then the partials refreshed
+    for (int c = 0; c < 4; ++c) {
+      hipLaunchKernelGGL(k_lik_outer, dim3((unsigned)((L + 127) / 128), (unsigned)B), dim3(128), 0, st, codes, n_align, prog,
+                         (const double*)(base + w.pmat), md, (const double*)(base + w.down), base + w.outer, T, L);
+      hipLaunchKernelGGL(k_lik_newton, dim3((unsigned)NN, (unsigned)B), dim3(256), 0, st, codes, n_align,
+                         (const double*)(base + w.inv), (const double*)(base + w.down), (const double*)(base + w.outer), md,
+                         fold ? prog : (const int*)nullptr, colour, c, (const double*)(base + w.brlen), base + w.brlen_new, T, L, 12);
+      hipLaunchKernelGGL(k_fill, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, st, base + w.step, 1.0, B);
+      for (int tr = 0; tr < 2; ++tr) {
+        hipLaunchKernelGGL(k_lik_blend, dim3((unsigned)((B * NN + 255) / 256)), dim3(256), 0, st, (const double*)(base + w.brlen),
+                           (const double*)(base + w.brlen_new), (const double*)(base + w.step), base + w.brlen_try, B, NN);
+        lik_eval(h, codes, n_align, md, w, base, base + w.brlen_try, base + w.ll_try, B, T, L, st);
+        hipLaunchKernelGGL(k_lik_accept, dim3((unsigned)B), dim3(64), 0, st, base + w.ll, (const double*)(base + w.ll_try),
+                           base + w.step, base + w.brlen, (const double*)(base + w.brlen_try), B, NN);
+      }
+      lik_eval(h, codes, n_align, md, w, base, base + w.brlen, base + w.ll, B, T, L, st);   // pmat / down of the accepted lengths
     }
-    lik_eval(h, codes, n_align, md, w, base, base + w.brlen, base + w.ll, B, T, L, st);   // pmat / down of the accepted lengths
   }
   HIPCHK(h, hipMemcpyAsync(loglik_out, base + w.ll, (size_t)B * sizeof(double), hipMemcpyDeviceToDevice, st));
   if (brlen_out) {
     const int ne = B * (T - 1) * 2;
-    if (sweeps > 0)
+    if (sweeps > 0 && fold)
       hipLaunchKernelGGL(k_lik_root_fold, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, st, prog, base + w.brlen, B, T, 1);
     hipLaunchKernelGGL(k_lik_brlen_export, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, st, prog,
                        (const double*)(base + w.brlen), brlen_out, B, T);

@@ -30,8 +30,12 @@ struct LikModel {                 // eigen system of the normalised GTR rate mat
 
 constexpr int LIK_MAXCAT = 8;
 
-// merges -> child node ids per join; one thread per tree
-__global__ void k_lik_program(const int* __restrict__ merges, int* __restrict__ prog, int B, int T) {
+// merges -> child node ids per join; one thread per tree.  Also the COLOUR of every edge for the branch-length sweeps
+// (colour[b][v], edge above node v): 2 * (depth of v mod 2) + (0 / 1: first / second child of its join).  Two edges
+// of one colour never share a node -- siblings differ in the second term, parent and child in the first -- so the
+// edges of a colour can be optimised at once from the same partial likelihoods without fighting each other, and
+// four colour steps are one Gauss-Seidel pass over the tree.
+__global__ void k_lik_program(const int* __restrict__ merges, int* __restrict__ prog, int* __restrict__ colour, int B, int T) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
   int ids[256];
@@ -44,6 +48,14 @@ __global__ void k_lik_program(const int* __restrict__ merges, int* __restrict__ 
     p[2 * s] = ids[i]; p[2 * s + 1] = ids[j];
     ids[i] = T + s;
     for (int q = j; q < n - 1; ++q) ids[q] = ids[q + 1];
+  }
+  if (!colour) return;
+  int* col = colour + (size_t)b * (2 * T - 2);
+  // top-down: the depth parity of a join is kept in the colour entry of the join itself (the last join is the root)
+  for (int s = T - 2; s >= 0; --s) {
+    const int par = s == T - 2 ? 0 : (col[T + s] >> 1);      // depth parity of join T + s
+    const int cp = par ^ 1;
+    col[p[2 * s]] = 2 * cp; col[p[2 * s + 1]] = 2 * cp + 1;
   }
 }
 
@@ -245,18 +257,22 @@ __global__ __launch_bounds__(128) void k_lik_outer(const uint8_t* __restrict__ c
 //   pinv * inv_s + (1 - pinv) / ncat * sum_cat sum_k S[cat][k] exp(lam_k r_cat t),  S = (pi O U)_k (Uinv D)_k
 // ("sum table" of the edge, recomputed from O_v and D_v in every iteration: they stay in L2).  Each iteration reduces
 // d/dt and d2/dt2 of the log-likelihood over the sites; t <- t - f'/f'' where concave, else a step along the
-// gradient; a trust region of [t/4, 4t]; lengths stay in [1e-8, 100].  All edges are optimised simultaneously from the
-// same partials (a Jacobi sweep); the caller re-evaluates the likelihood and damps a sweep that does not improve it.
+// gradient; a trust region of [t/4, 4t]; lengths stay in [1e-8, 100].  The edges of ONE colour (k_lik_program) are
+// optimised at once from the same partials; the caller re-evaluates the likelihood, damps a step that does not
+// improve it, refreshes the partials and goes on to the next colour (round 2 optimised ALL edges at once -- a Jacobi
+// sweep -- and needed a dozen sweeps where this needs three: tools/lik_conv.py).
 __global__ __launch_bounds__(256) void k_lik_newton(const uint8_t* __restrict__ codes, int n_align,
                                                     const double* __restrict__ inv, const double* __restrict__ down,
                                                     const double* __restrict__ outer, LikModel md,
-                                                    const int* __restrict__ prog,
+                                                    const int* __restrict__ prog, const int* __restrict__ colour, int cur,
                                                     const double* __restrict__ brlen, double* __restrict__ brlen_new,
                                                     int T, int L, int iters) {
   __shared__ double red[2][256];
   const int v = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
   const int nc = md.ncat, NN = 2 * T - 2;
-  if (v == prog[((size_t)b * (T - 1) + (T - 2)) * 2 + 1]) {     // second child of the last join: folded into the first (k_lik_root_fold)
+  // not this step's colour, or the second child of the last join (folded into the first: k_lik_root_fold): unchanged
+  if ((colour && colour[(size_t)b * NN + v] != cur) ||
+      (prog && v == prog[((size_t)b * (T - 1) + (T - 2)) * 2 + 1])) {
     if (tid == 0) brlen_new[(size_t)b * NN + v] = brlen[(size_t)b * NN + v];
     return;
   }

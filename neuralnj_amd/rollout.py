@@ -106,6 +106,10 @@ def search_rollouts(batch, agent, env, n_rollouts, seed=0, temperature=1.0, mode
     first.scatter_reduce_(0, inverse, torch.arange(n_rollouts, device=keys.device), reduce="amin")
     merges = r["merges"][first]                               # one merge list per distinct topology
     ctx.check_numeric()
+    if isinstance(model, str) and model == "auto":
+        # the reference's opt_model=True (environment.py:373-377): GTR+I+G parameters by maximum likelihood, here once per
+        # round on the most frequently sampled topology and shared by the trees scored together
+        model, _, _ = lk.optimize_model(ctx, codes, merges[torch.argmax(counts):][:1], None, None, mask=mask, rounds=2, sweeps=sweeps)
     ll, br = lk.tree_optimize(ctx, codes, merges, None, model, mask=mask, sweeps=sweeps)
     order = torch.argsort(ll, descending=True)
     m_np, br_np, ll_np = merges[order].cpu().numpy(), br[order].cpu().numpy(), ll[order].cpu().numpy()

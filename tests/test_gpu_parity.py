@@ -707,14 +707,22 @@ def test_small_magnitude_weights(ctx_cache):
         assert (ref["merges"][decisive] == merges[decisive]).all()
 
 
-def test_config5_200x4096_matches_fp64_golden(ctx_cache):
+@pytest.mark.parametrize("style", ["plain", "sharp"])
+def test_config5_200x4096_matches_fp64_golden(style, ctx_cache):
     """BASELINE configs[4] at the FULL size against the float64 oracle (tests/golden/gen_cfg5_f64.py: a free Argmax
-    run of one 200 x 4096 alignment, 22 minutes of CPU): the HIP rollout teacher-forced along the stored merges must
-    give the complete score tables of eight sampled steps (200 ... 3 rows live: star kernels, the 65 -> 64 row
-    hand-over, the two-pass steps) within 1e-4 of each table's scale, and pick the stored pair wherever the fp64
-    top-2 gap is decisive."""
+    run of one 200 x 4096 alignment, 22 minutes of CPU per weight style): the HIP rollout teacher-forced along the
+    stored merges against the complete score tables of eight sampled steps (200 ... 3 rows live: star kernels, the
+    65 -> 64 row hand-over, the two-pass steps), and the free run against the stored merge list.
+      plain (reference-scale weights): every table within 1e-4 of its scale.
+      sharp (the stress weights of the other fixtures): six encoder layers amplify fp32 rounding of the encoder output
+      (HIP 1.4e-5, fp32 oracle 2.6e-5 of its scale: tests/cfg5_margin.py) about twenty-fold into the tables, so NO
+      fp32 evaluation of this shape is within 1e-4 of the truth; the fixture keeps the distance of the plain-fp32
+      oracle (the reference's arithmetic) from the fp64 tables per step, and HIP must be within 1e-4 or within 1.25 x
+      that distance, and never beyond 4e-4."""
     import hashlib
-    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "cfg5_f64_t200_l4096.npz"))
+    z = _cfg5_golden(style)
+    if z is None:
+        pytest.skip(f"tests/golden/cfg5_f64 fixture for {style} weights not generated")
     T, L = (int(v) for v in z["shape"])
     cfgs = utils.shipped_config()
     packed = weights.pack(cfgs, weights.seeded_state(cfgs, int(z["wseed"]), str(z["style"])))
@@ -725,10 +733,16 @@ def test_config5_200x4096_matches_fp64_golden(ctx_cache):
     r = g.rollout_argmax(torch.from_numpy(codes), None, forced_merges=z["merges"][None], want_trace=True)
     g.check_numeric()
     tabs = split_trace(r["logits"].cpu().numpy(), T)
-    worst = 0.0
-    for s in z["steps"]:
-        worst = max(worst, assert_logits_close(tabs[int(s)][0], z[f"table_{int(s)}"], RTOL, f"step {int(s)} ({T - int(s)} rows)"))
-    print(f"200 x 4096 vs fp64 golden: worst table error {worst:.2e} of its scale")
+    rows = []
+    for k, s in enumerate(int(v) for v in z["steps"]):
+        ref = z[f"table_{s}"]
+        scale = max(float(np.abs(ref).max()), 1.0)
+        err = float(np.abs(tabs[s][0] - ref).max()) / scale
+        o32 = float(z["o32_err"][k]) / scale
+        rows.append((s, T - s, err, o32))
+        bound = RTOL if style == "plain" else min(4 * RTOL, max(RTOL, 1.25 * o32))
+        assert err <= bound, f"{style} weights, step {s} ({T - s} rows): HIP {err:.2e} of the table's scale (fp32 oracle {o32:.2e}), bound {bound:.2e}"
+    print(f"200 x 4096, {style} weights, vs fp64 (step, rows, HIP, fp32 oracle): " + ", ".join(f"({s}, {n}, {e:.1e}, {o:.1e})" for s, n, e, o in rows))
     free = g.rollout_argmax(torch.from_numpy(codes), None)["merges"].cpu().numpy()[0]
     decisive = z["top2_gap"] > 4 * RTOL * float(z["scale"])
     first_bad = next((s for s in range(T - 1) if not np.array_equal(free[s], z["merges"][s])), T - 1)
