@@ -15,8 +15,8 @@ def golden_names(max_taxa=None, min_taxa=None):
     out = []
     for p in sorted(glob.glob(os.path.join(GOLDEN_DIR, "*.npz"))):
         nm = os.path.basename(p)[:-4]
-        if nm.startswith(("grad_", "cfg5_", "iqtree_")):   # other fixture families: Finetune gradients, the fp64 tables
-            continue                                        # of configs[4], the substitution-model pins of the likelihood
+        if nm.startswith(("grad_", "cfg5_", "iqtree_", "lik_")):   # other fixture families: Finetune gradients, the fp64
+            continue                                        # tables of configs[4], the pins of the likelihood
         z = np.load(p)
         T = z["codes"].shape[1]
         if max_taxa is not None and T > max_taxa:
