@@ -15,13 +15,31 @@ from neuralnj_amd import synth, utils, weights
 pytestmark = pytest.mark.gpu
 
 RTOL = 1e-4
-# Per-fixture exceptions, each with its measured reason (tests/wide_margin.py, profiles/r02/wide_margin.txt).
-# synth_b1_t100_l256_s11: 100 rows under the sharpened stress weights amplify encoder rounding about 7x into the
-# scores.  Measured over the whole rollout (profiles/r02/parity_margin.json): HIP 1.96e-4 of the score scale from the
-# reference's tables and 1.6e-4 from the fp64 oracle; the fp32 oracle 1.2e-4 from fp64; the reference itself 4.4e-5.
-# HIP's encoder output is as close to fp64 as the fp32 oracle's (1.6e-5 vs 1.4e-5): three fp32-level evaluations.
-# The reference's real 100-taxon alignments (data_G_*, 2-3e-5) and every other fixture hold 1e-4.
-RTOL_FIXTURE = {"synth_b1_t100_l256_s11": 2.5e-4}
+# No per-fixture tolerances.  Where a table misses 1e-4 of the REFERENCE's fp32 table (wide alignments under the
+# sharpened stress weights: six encoder layers amplify fp32 rounding of the encoder output -- HIP's 1.6e-5, the fp32
+# oracle's 1.4e-5 of its scale at 100 x 256 -- seven- to twenty-fold into the scores; every single HIP operation fed
+# with exact inputs is within 3e-6, tools/step_ops_margin.py) the fp64 oracle arbitrates: two independent fp32
+# evaluations of the fixture exist -- the reference's own tables and the plain-fp32 oracle -- and HIP must be no
+# farther from the fp64 tables than twice the larger of THEIR distances (measured: 100 x 256 s11: HIP 1.7e-4, reference
+# 4.4e-5, fp32 oracle 1.2e-4; 200 x 256 s13: HIP 1.6e-4, reference 4.6e-4, fp32 oracle 5.3e-4; 100 x 256 s14 / s15 and
+# the reference's real 100-taxon alignments: all three within 3e-5).  The figures of a run go to
+# gpurun_out/golden_noise.json.
+NOISE_ROWS = []
+
+
+def _fp64_arbitration(name, z, cfgs, packed, logits):
+    """(hip vs fp64, reference vs fp64, fp32 oracle vs fp64), scale-relative, over all tables of the fixture."""
+    from oracle_lib import Oracle
+    oh = onehot_f32(z["codes"])
+    t64 = Oracle(cfgs, packed, "f64").rollout_argmax(oh, z["mask"], forced_merges=z["merges"])["logits"]
+    t32 = Oracle(cfgs, packed).rollout_argmax(oh, z["mask"], forced_merges=z["merges"])["logits"]
+    scale = max(float(np.abs(t64).max()), 1.0)
+    row = dict(fixture=name, hip_vs_fp64=float(np.abs(logits - t64).max()) / scale,
+               reference_vs_fp64=float(np.abs(z["logits"] - t64).max()) / scale,
+               fp32_oracle_vs_fp64=float(np.abs(t32 - t64).max()) / scale,
+               hip_vs_reference=float(np.abs(logits - z["logits"]).max()) / scale)
+    NOISE_ROWS.append(row)
+    return row
 
 
 @pytest.fixture(scope="module")
@@ -83,6 +101,11 @@ def _rf_table_dump():
             json.dump(dict(what="free-running HIP rollout against the reference's own tree, per golden alignment "
                                 "(tests/test_gpu_parity.py::test_rollout_matches_reference_golden)",
                            summary=summary, rows=RF_ROWS), f, indent=1)
+    if NOISE_ROWS and os.path.isdir(out):
+        with open(os.path.join(out, "golden_noise.json"), "w") as f:
+            json.dump(dict(what="fixtures whose HIP tables miss 1e-4 of the reference's fp32 tables: distances from the fp64 "
+                                "oracle's tables (scale-relative, whole rollout, teacher-forced along the reference's merges)",
+                           rows=NOISE_ROWS), f, indent=1)
 
 
 @pytest.mark.parametrize("name", golden_names())
@@ -98,7 +121,13 @@ def test_rollout_matches_reference_golden(name, ctx_cache):
     B, T, L = z["codes"].shape
     r = g.rollout_argmax(codes, mask, forced_merges=z["merges"], want_trace=True, want_state=True)
     logits = r["logits"].cpu().numpy()
-    assert_logits_close(logits, z["logits"], RTOL_FIXTURE.get(name, RTOL))
+    scale_ = max(float(np.abs(z["logits"]).max()), 1.0)
+    if float(np.abs(logits - z["logits"]).max()) > RTOL * scale_:
+        row = _fp64_arbitration(name, z, cfgs, packed, logits)
+        noise = max(row["reference_vs_fp64"], row["fp32_oracle_vs_fp64"])
+        assert row["reference_vs_fp64"] <= 1e-3, f"the fp64 oracle does not reproduce the reference: {row}"
+        assert row["hip_vs_fp64"] <= max(RTOL, 2.0 * noise), \
+            f"HIP is farther from the fp64 tables than twice the fp32 evaluations of this fixture are: {row}"
     st = r["state"].cpu().numpy()
     if "enc" in z.files:
         np.testing.assert_allclose(st, z["enc"], atol=RTOL * np.abs(z["enc"]).max())
@@ -475,7 +504,7 @@ def test_model_env_api_follows_reference_call_sequence():
     np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), atol=2e-5)   # LUT path == MLP path
 
 
-def _certify_sampled(ref, merges, logits_g, u, temperature, T):
+def _certify_sampled(ref, merges, logits_g, u, temperature, T, rtol=RTOL):
     """Sampled trajectories against the oracle twin (same uniforms): identical, except where the uniform lands within
     fp32 rounding of a CDF boundary of the oracle's own table -- at the first divergent step of a differing trajectory
     the two picks must be NEIGHBOURS in the flat pair order and the target u * total within the tables' rounding of
@@ -487,7 +516,7 @@ def _certify_sampled(ref, merges, logits_g, u, temperature, T):
         s_ = int(np.argmax(np.any(ref["merges"][b] != merges[b], axis=1)))
         n = T - s_
         to = tabs_o[s_][b].astype(np.float64)
-        assert_logits_close(tabs_g[s_][b], tabs_o[s_][b], RTOL, "table at the divergent step")
+        assert_logits_close(tabs_g[s_][b], tabs_o[s_][b], rtol, "table at the divergent step")
         e = np.exp((to - to.max()) / temperature)
         cdf = np.cumsum(e)
         k_o = flat_pair(n, *ref["merges"][b, s_])
@@ -496,7 +525,7 @@ def _certify_sampled(ref, merges, logits_g, u, temperature, T):
         target = float(u[b, s_]) * cdf[-1]
         boundary = cdf[min(k_o, k_g)]
         # table entries within RTOL * scale move every CDF value by at most that (relative, / temperature)
-        slack = (RTOL * max(float(np.abs(to).max()), 1.0) / temperature) * cdf[-1] * 2
+        slack = (rtol * max(float(np.abs(to).max()), 1.0) / temperature) * cdf[-1] * 2
         assert abs(target - boundary) <= slack, f"trajectory {b} step {s_}: not a CDF-boundary case"
     return agree
 
@@ -718,7 +747,7 @@ def test_config5_200x4096_matches_fp64_golden(style, ctx_cache):
       (HIP 1.4e-5, fp32 oracle 2.6e-5 of its scale: tests/cfg5_margin.py) about twenty-fold into the tables, so NO
       fp32 evaluation of this shape is within 1e-4 of the truth; the fixture keeps the distance of the plain-fp32
       oracle (the reference's arithmetic) from the fp64 tables per step, and HIP must be within 1e-4 or within 1.25 x
-      that distance, and never beyond 4e-4."""
+      that distance."""
     import hashlib
     z = _cfg5_golden(style)
     if z is None:
@@ -740,7 +769,7 @@ def test_config5_200x4096_matches_fp64_golden(style, ctx_cache):
         err = float(np.abs(tabs[s][0] - ref).max()) / scale
         o32 = float(z["o32_err"][k]) / scale
         rows.append((s, T - s, err, o32))
-        bound = RTOL if style == "plain" else min(4 * RTOL, max(RTOL, 1.25 * o32))
+        bound = RTOL if style == "plain" else max(RTOL, 1.25 * o32)
         assert err <= bound, f"{style} weights, step {s} ({T - s} rows): HIP {err:.2e} of the table's scale (fp32 oracle {o32:.2e}), bound {bound:.2e}"
     print(f"200 x 4096, {style} weights, vs fp64 (step, rows, HIP, fp32 oracle): " + ", ".join(f"({s}, {n}, {e:.1e}, {o:.1e})" for s, n, e, o in rows))
     free = g.rollout_argmax(torch.from_numpy(codes), None)["merges"].cpu().numpy()[0]
@@ -783,5 +812,6 @@ def test_search_mode_at_config5_200x4096(ctx_cache):
     uw = u[:4]
     ref = o.rollout_sample(onehot_f32(np.repeat(win, 4, 0)), np.zeros((4, 160), bool), uw, temperature=1.0)
     got = g.rollout_sample(torch.from_numpy(win), None, uw, temperature=1.0, replicas=4, want_trace=True)
-    agree = _certify_sampled(ref, got["merges"].cpu().numpy(), got["logits"].cpu().numpy(), uw, 1.0, T)
+    # (200 rows under the stress weights: two fp32 evaluations differ by up to 2e-4 -- test_config5_200x4096_properties)
+    agree = _certify_sampled(ref, got["merges"].cpu().numpy(), got["logits"].cpu().numpy(), uw, 1.0, T, rtol=2 * RTOL)
     assert agree.mean() >= 0.5
