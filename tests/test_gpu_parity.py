@@ -507,8 +507,9 @@ def test_model_env_api_follows_reference_call_sequence():
 def _certify_sampled(ref, merges, logits_g, u, temperature, T, rtol=RTOL):
     """Sampled trajectories against the oracle twin (same uniforms): identical, except where the uniform lands within
     fp32 rounding of a CDF boundary of the oracle's own table -- at the first divergent step of a differing trajectory
-    the two picks must be NEIGHBOURS in the flat pair order and the target u * total within the tables' rounding of
-    the boundary between them.  Returns the per-trajectory agreement flags."""
+    the oracle's cumulative mass between the two picks must be within the tables' rounding of the target u * total
+    (neighbours in the flat pair order, or separated by entries of negligible probability only).  Returns the
+    per-trajectory agreement flags."""
     agree = (ref["merges"] == merges).all(axis=(1, 2))
     tabs_o = split_trace(ref["logits"], T)
     tabs_g = split_trace(logits_g, T)
@@ -521,12 +522,13 @@ def _certify_sampled(ref, merges, logits_g, u, temperature, T, rtol=RTOL):
         cdf = np.cumsum(e)
         k_o = flat_pair(n, *ref["merges"][b, s_])
         k_g = flat_pair(n, *merges[b, s_])
-        assert abs(k_o - k_g) == 1, "sampled picks are not neighbours in the CDF"
         target = float(u[b, s_]) * cdf[-1]
-        boundary = cdf[min(k_o, k_g)]
-        # table entries within RTOL * scale move every CDF value by at most that (relative, / temperature)
+        # table entries within rtol * scale move every CDF value by at most that (relative, / temperature)
         slack = (rtol * max(float(np.abs(to).max()), 1.0) / temperature) * cdf[-1] * 2
-        assert abs(target - boundary) <= slack, f"trajectory {b} step {s_}: not a CDF-boundary case"
+        # the oracle's pick is the first index whose cumulative mass exceeds the target; a later pick means the mass up
+        # to the entry before it must drop below the target, an earlier one that its own cumulative mass must rise above
+        miss = cdf[k_g - 1] - target if k_g > k_o else target - cdf[k_g]
+        assert 0 <= miss <= slack, f"trajectory {b} step {s_}: not a CDF-boundary case ({k_o} vs {k_g}, {miss:.3e} > {slack:.3e})"
     return agree
 
 
@@ -746,8 +748,9 @@ def test_config5_200x4096_matches_fp64_golden(style, ctx_cache):
       sharp (the stress weights of the other fixtures): six encoder layers amplify fp32 rounding of the encoder output
       (HIP 1.4e-5, fp32 oracle 2.6e-5 of its scale: tests/cfg5_margin.py) about twenty-fold into the tables, so NO
       fp32 evaluation of this shape is within 1e-4 of the truth; the fixture keeps the distance of the plain-fp32
-      oracle (the reference's arithmetic) from the fp64 tables per step, and HIP must be within 1e-4 or within 1.25 x
-      that distance."""
+      oracle (the reference's arithmetic) from the fp64 tables per step, and every HIP table must be within 1e-4 or
+      within 1.25 x that distance at the oracle's worst stored step (two noise realisations do not peak at the same
+      step)."""
     import hashlib
     z = _cfg5_golden(style)
     if z is None:
@@ -769,8 +772,10 @@ def test_config5_200x4096_matches_fp64_golden(style, ctx_cache):
         err = float(np.abs(tabs[s][0] - ref).max()) / scale
         o32 = float(z["o32_err"][k]) / scale
         rows.append((s, T - s, err, o32))
-        bound = RTOL if style == "plain" else max(RTOL, 1.25 * o32)
-        assert err <= bound, f"{style} weights, step {s} ({T - s} rows): HIP {err:.2e} of the table's scale (fp32 oracle {o32:.2e}), bound {bound:.2e}"
+    noise = max(o for _, _, _, o in rows)                     # the fp32 oracle's worst stored table
+    for s, n, err, o32 in rows:
+        bound = RTOL if style == "plain" else max(RTOL, 1.25 * noise)
+        assert err <= bound, f"{style} weights, step {s} ({n} rows): HIP {err:.2e} of the table's scale (fp32 oracle {o32:.2e} here, {noise:.2e} at its worst step), bound {bound:.2e}"
     print(f"200 x 4096, {style} weights, vs fp64 (step, rows, HIP, fp32 oracle): " + ", ".join(f"({s}, {n}, {e:.1e}, {o:.1e})" for s, n, e, o in rows))
     free = g.rollout_argmax(torch.from_numpy(codes), None)["merges"].cpu().numpy()[0]
     decisive = z["top2_gap"] > 4 * RTOL * float(z["scale"])
