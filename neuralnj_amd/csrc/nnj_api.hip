@@ -698,8 +698,12 @@ int launch_step2(nnj_handle* h, RowSet rs, const int* live_old, const int* ij, c
   const bool has_ctx = n > 2;
   if (has_ctx) {
     Scope sc(h, st, PK_ALPHA_SOFTMAX);
-    hipLaunchKernelGGL(k_step_softmax, dim3(16, (unsigned)B), dim3(256), 0, st, rs, sw, ij, (const float*)(base + w.alpha_part),
-                       base + w.alpha, base + w.lam, base + w.beta_slot, g.blocks, n, C);
+    if (g.blocks > 8)
+      hipLaunchKernelGGL(k_step_softmax<true>, dim3(64, (unsigned)B), dim3(256), 0, st, rs, sw, ij, (const float*)(base + w.alpha_part),
+                         base + w.alpha, base + w.lam, base + w.beta_slot, g.blocks, n, C);
+    else
+      hipLaunchKernelGGL(k_step_softmax<false>, dim3(16, (unsigned)B), dim3(256), 0, st, rs, sw, ij, (const float*)(base + w.alpha_part),
+                         base + w.alpha, base + w.lam, base + w.beta_slot, g.blocks, n, C);
   }
   {
     Scope sc(h, st, PK_PAIR_SCORE_INCR);

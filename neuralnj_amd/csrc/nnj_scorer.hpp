@@ -959,7 +959,20 @@ __global__ __launch_bounds__(256) void k_assemble_argmax(const float* __restrict
   int ip = 0, jp = 0;
   if (mode == PAIRS_INCR) {
     ip = ij_prev[2 * b]; jp = ij_prev[2 * b + 1];
-    if (tid < n) {
+    if (qn && nsc > 8) {
+      // many partials (small batch: many workgroups per alignment) and at most 64 new scores: four threads per score,
+      // every 4th partial each, the four sums added in order
+      const int r = tid & 63, part = tid >> 6;
+      float s = 0.f;
+      if (r < n) {
+        const int src = r - (r > ip ? 1 : 0);
+#pragma unroll 8
+        for (int sc = part; sc < nsc; sc += 4) s += score_part[((size_t)b * nsc + sc) * ppad + src];
+      }
+      pval[PCACHE - 256 + tid] = s;
+      __syncthreads();
+      if (tid < n) newsc[tid] = ((pval[PCACHE - 256 + tid] + pval[PCACHE - 192 + tid]) + pval[PCACHE - 128 + tid]) + pval[PCACHE - 64 + tid];
+    } else if (tid < n) {
       // qn: the partials are indexed by q, the partner's index among the rows other than the merged one (nnj_step2.hpp)
       const int src = qn ? tid - (tid > ip ? 1 : 0) : tid;
       float s = 0.f;

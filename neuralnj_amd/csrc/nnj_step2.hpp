@@ -380,15 +380,19 @@ __global__ __launch_bounds__(64 * NW) void k_step_alpha(RowSet rs, ScorerW w, St
 // partials of k_step_alpha, kept for the next merge.  The last wave of the grid also sums the beta partials
 // k_step_alpha wrote for the merged row into beta_slot (no pair of this step has m in its context; the table kernel
 // and later steps do).  One wave per pair q, lane = q'.  grid (16, B).
+template <bool SPLIT>
 __global__ __launch_bounds__(256) void k_step_softmax(RowSet rs, ScorerW w, const int* __restrict__ ij_prev,
                                                       const float* __restrict__ alpha_part, float* __restrict__ alpha,
                                                       float* __restrict__ lam, float* __restrict__ beta_slot, int nblk,
                                                       int n, int C) {
+  // SPLIT (small batches: k_step_alpha ran many workgroups per alignment, i.e. many partials): one pair per
+  // workgroup, its four waves sum every 4th partial each and the four sums are added in wave order; grid (64, B)
+  __shared__ float part4[4][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int q = blockIdx.x * 4 + wave, b = blockIdx.y;
+  const int q = SPLIT ? blockIdx.x : blockIdx.x * 4 + wave, b = blockIdx.y;
   const int m = min(max(ij_prev[2 * b], 0), n - 1);
   const int nrow = (int)(rs.bstride / ((long)C * 64));
-  if (q == 63) {                                           // (q <= 62 are pairs: n - 1 <= 63)
+  if (q == 63 && (!SPLIT || wave == 0)) {                  // (q <= 62 are pairs: n - 1 <= 63)
     const float* bp = rs.beta_part + ((size_t)b * nrow + slot_of(rs, b, m)) * rs.ntile32;
     float s = 0.f;
     for (int t = lane; t < nblk; t += 64) s += bp[t];
@@ -397,8 +401,17 @@ __global__ __launch_bounds__(256) void k_step_softmax(RowSet rs, ScorerW w, cons
     if (lane == 0) beta_slot[(size_t)b * nrow + slot_of(rs, b, m)] = s + (float)C * w.t0;
   }
   float a = 0.f;
+  if (SPLIT) {
+#pragma unroll 8
+    for (int sc = wave; sc < nblk; sc += 4) a += alpha_part[(((size_t)b * nblk + sc) * 64 + q) * 64 + lane];
+    part4[wave][lane] = a;
+    __syncthreads();
+    if (wave != 0) return;
+    a = ((part4[0][lane] + part4[1][lane]) + part4[2][lane]) + part4[3][lane];
+  } else {
 #pragma unroll 8          // independent loads in flight; the additions stay in order
-  for (int sc = 0; sc < nblk; ++sc) a += alpha_part[(((size_t)b * nblk + sc) * 64 + q) * 64 + lane];
+    for (int sc = 0; sc < nblk; ++sc) a += alpha_part[(((size_t)b * nblk + sc) * 64 + q) * 64 + lane];
+  }
   lam[((size_t)b * 64 + q) * 64 + lane] = a;
   const bool in = q < n - 1 && lane < n - 1 && lane != q;
   float v = -INFINITY;

@@ -818,5 +818,6 @@ def test_search_mode_at_config5_200x4096(ctx_cache):
     ref = o.rollout_sample(onehot_f32(np.repeat(win, 4, 0)), np.zeros((4, 160), bool), uw, temperature=1.0)
     got = g.rollout_sample(torch.from_numpy(win), None, uw, temperature=1.0, replicas=4, want_trace=True)
     # (200 rows under the stress weights: two fp32 evaluations differ by up to 2e-4 -- test_config5_200x4096_properties)
-    agree = _certify_sampled(ref, got["merges"].cpu().numpy(), got["logits"].cpu().numpy(), uw, 1.0, T, rtol=2 * RTOL)
-    assert agree.mean() >= 0.5
+    # Every trajectory that leaves the twin's is certified at its first divergent step; over 199 sampled steps per
+    # trajectory a CDF-boundary case somewhere is the rule, so no share of fully identical trajectories is asked for.
+    _certify_sampled(ref, got["merges"].cpu().numpy(), got["logits"].cpu().numpy(), uw, 1.0, T, rtol=2 * RTOL)
