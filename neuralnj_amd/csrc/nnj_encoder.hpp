@@ -463,9 +463,10 @@ __global__ __launch_bounds__(1024) void k_ffn16(float* __restrict__ x, FfnW wf, 
       for (int mt = 0; mt < 4; ++mt) hdn.t[mt] = *reinterpret_cast<const f32x4*>(cf + 192 + q * 64 + 16 * mt + 4 * kq);
       linear_t16p_core<4, FFN_PF>(hdn.t, yf, W1l + q * IMG64, lane, [] {});
 #pragma unroll
-      for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) hdn.t[mt][e] = gelu_erf(hdn.t[mt][e]);
+      for (int mt = 0; mt < 4; ++mt) {
+        const f32x2v g0 = gelu_erf2((f32x2v){hdn.t[mt][0], hdn.t[mt][1]}), g1 = gelu_erf2((f32x2v){hdn.t[mt][2], hdn.t[mt][3]});
+        hdn.t[mt] = (f32x4){g0[0], g0[1], g1[0], g1[1]};
+      }
       linear_t16p<4, true, false, FFN_PF>(out.t, hdn, W2l + q * IMG64, nullptr, lane);
     }
     if (!valid) continue;

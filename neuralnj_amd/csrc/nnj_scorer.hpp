@@ -365,15 +365,16 @@ __global__ __launch_bounds__(64 * NW) void k_pair_score(RowSet rs, ScorerW w, co
         }
         f32x16 s1[1][2];
         linear6_T<2, 2, 1, true>(s1, x, S0_l, cv + 128, lane);
-        float s = 0.f;
+        f32x2v s2 = {0.f, 0.f};
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
           for (int g4 = 0; g4 < 4; ++g4) {
             const f32x4 w4 = *reinterpret_cast<const f32x4*>(cv + 192 + 32 * mt + 8 * g4 + 4 * hh);
-#pragma unroll
-            for (int t = 0; t < 4; ++t) s += gelu_erf(s1[0][mt][4 * g4 + t]) * w4[t];
+            const f32x4 x4 = {s1[0][mt][4 * g4], s1[0][mt][4 * g4 + 1], s1[0][mt][4 * g4 + 2], s1[0][mt][4 * g4 + 3]};
+            gelu_dot4(s2, x4, w4);
           }
+        float s = s2[0] + s2[1];
         s += __shfl_xor(s, 32);
         score[tt] += (s + w.s2b) * mc;
       }
@@ -603,15 +604,16 @@ __global__ __launch_bounds__(512) void k_inc_score(RowSet rs, ScorerW w, const i
     }
     f32x16 s1[1][2];
     linear6_T<2, 2, 1, true, false>(s1, x, S0_l, cv + 128, lane);
-    float s = 0.f;
+    f32x2v s2 = {0.f, 0.f};
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const f32x4 w4 = *reinterpret_cast<const f32x4*>(cv + 192 + 32 * mt + 8 * g + 4 * hh);
-#pragma unroll
-        for (int t = 0; t < 4; ++t) s += gelu_erf(s1[0][mt][4 * g + t]) * w4[t];
+        const f32x4 x4 = {s1[0][mt][4 * g], s1[0][mt][4 * g + 1], s1[0][mt][4 * g + 2], s1[0][mt][4 * g + 3]};
+        gelu_dot4(s2, x4, w4);
       }
+    float s = s2[0] + s2[1];
     s += __shfl_xor(s, 32);
     score += (s + w.s2b) * mc;
   }

@@ -294,14 +294,14 @@ __global__ __launch_bounds__(64 * T16_WAVES) void k_inc_score16(RowSet rs, Score
     }
     V64 s1;
     linear_t16p<4, false, true, 2, false>(s1.t, x, S0_l, cv + 128, lane);
-    float s = 0.f;
+    f32x2v s2 = {0.f, 0.f};
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
       const f32x4 w4 = *reinterpret_cast<const f32x4*>(cv + 192 + 16 * mt + 4 * kq);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) s += gelu_erf(s1.t[mt][e]) * w4[e];
+      gelu_dot4(s2, s1.t[mt], w4);
       __builtin_amdgcn_sched_barrier(0);
     }
+    float s = s2[0] + s2[1];
     s += __shfl_xor(s, 16);
     s += __shfl_xor(s, 32);
     score += (s + w.s2b) * mc;
@@ -470,13 +470,13 @@ __global__ __launch_bounds__(64 * NW) void k_inc_score_w(RowSet rs, ScorerW w, c
       }
       V64 s1;
       linear_t16p<4, false, true, WPF, false>(s1.t, x[t], S0_l, cv + 128, lane);
-      float s = 0.f;
+      f32x2v s2 = {0.f, 0.f};
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt) {
         const f32x4 w4 = *reinterpret_cast<const f32x4*>(cv + 192 + 16 * mt + 4 * kq);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) s += gelu_erf(s1.t[mt][e]) * w4[e];
+        gelu_dot4(s2, s1.t[mt], w4);
       }
+      float s = s2[0] + s2[1];
       s += __shfl_xor(s, 16);
       s += __shfl_xor(s, 32);
       score[t] += (s + w.s2b) * mc;
