@@ -59,6 +59,7 @@ struct nnj_handle {
   int concurrency = 2;           // sub-batches of a rollout that run on streams of their own (nnj_set_concurrency)
   int two_pass = 1;              // rollouts run the two-pass NJ step (nnj_step2.hpp); NNJ_TWO_PASS=0 selects the four-pass kernels
   int two_pass_cand = 1;         // ... and carry the candidate pair's logits along (NNJ_TWO_PASS_CAND=0: fallback pass instead)
+  int step_w = 1;                // one wave per site in the alpha pass of 17..48 rows (NNJ_STEP_W=0: groups of waves)
   // small batches: the ~370 launches of a rollout are captured once into a hipGraph and replayed while the call's
   // arguments stay the same (launch-bound regime: BASELINE configs[1], one alignment per rollout)
   struct GraphKey {
@@ -692,7 +693,18 @@ int launch_step2(nnj_handle* h, RowSet rs, const int* live_old, const int* ij, c
     if (int rc = set_lds(h, (k_step_alpha<NG, NW>), lds)) return rc;                                            \
     hipLaunchKernelGGL((k_step_alpha<NG, NW>), grid, dim3(64 * NW), lds, st, rs, sw, io, n, C, g.cs, h->d_flag); \
   } break;
-    switch (ng) { NNJ_SA(1, 12) NNJ_SA(2, 12) NNJ_SA(3, 12) NNJ_SA(4, 12) }
+#define NNJ_SW(NT, NW)                                                                                          \
+  case NT: {                                                                                                    \
+    const size_t lds = (size_t)(3 * IMG64 + NW * (1024 * NT + 64 * 5) + SCORER_CONSTS + NW * 66 + 16) * sizeof(float); \
+    if (int rc = set_lds(h, (k_step_alpha_w<NT, NW>), lds)) return rc;                                          \
+    hipLaunchKernelGGL((k_step_alpha_w<NT, NW>), grid, dim3(64 * NW), lds, st, rs, sw, io, n, C, g.cs);         \
+  } break;
+    if (h->step_w && (ng == 2 || ng == 3)) {
+      switch (ng) { NNJ_SW(2, 8) NNJ_SW(3, 8) }
+    } else {
+      switch (ng) { NNJ_SA(1, 12) NNJ_SA(2, 12) NNJ_SA(3, 12) NNJ_SA(4, 12) }
+    }
+#undef NNJ_SW
 #undef NNJ_SA
   }
   const bool has_ctx = n > 2;
@@ -871,6 +883,7 @@ int nnj_create(const nnj_config* cfg, nnj_handle** out) {
   h->cfg = *cfg;
   if (const char* e = getenv("NNJ_TWO_PASS")) h->two_pass = atoi(e);
   if (const char* e = getenv("NNJ_TWO_PASS_CAND")) h->two_pass_cand = atoi(e);
+  if (const char* e = getenv("NNJ_STEP_W")) h->step_w = atoi(e);
   h->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   if (hipSetDevice(cfg->device) != hipSuccess || hipMalloc(&h->d_flag, sizeof(int)) != hipSuccess ||
       hipMemset(h->d_flag, 0, sizeof(int)) != hipSuccess) {

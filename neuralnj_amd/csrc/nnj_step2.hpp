@@ -232,10 +232,6 @@ __global__ __launch_bounds__(64 * NW) void k_step_alpha(RowSet rs, ScorerW w, St
     }
     if constexpr (NG > 1) group_barrier_lds<NG>(cnt, epoch, status);     // all column sums are in xgp
     else asm volatile("" ::: "memory");
-    // fp16 pieces of S_r: image row, and B operand of U_r = W_h S_r (independent of the merged row: issued first)
-    Frag3 sf[2];
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) split_8(sf[ks], sr.t[2 * ks], sr.t[2 * ks + 1]);
     // ---- 2. the merged row of this site
     if (tl == 0) {
       float xg = 0.f;
@@ -303,6 +299,11 @@ __global__ __launch_bounds__(64 * NW) void k_step_alpha(RowSet rs, ScorerW w, St
       continue;
     }
     // ---- 3. the new pairs (m, r)
+    // fp16 pieces of S_r: image row, and B operand of U_r = W_h S_r (split here, not in front of the merged row: the
+    // pieces would be live across it)
+    Frag3 sf[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) split_8(sf[ks], sr.t[2 * ks], sr.t[2 * ks + 1]);
     V64 x;
     {
       V64 sm, um, ur;                                      // (U_r = W_h S_r issued by the partners of wave 0 while they wait for
@@ -368,6 +369,276 @@ __global__ __launch_bounds__(64 * NW) void k_step_alpha(RowSet rs, ScorerW w, St
   } else if (tid == 64) {
     float v = 0.f;
     for (int s_ = 0; s_ < NSLOT; ++s_) v += epi[s_ * 66 + 64];
+    float* bp = io.beta_w + ((size_t)b * (rs.bstride / ((long)C * 64)) + slot_m) * rs.ntile32;
+    bp[sc] = v;
+    if (sc == 0)
+      for (int k = gridDim.x; k < io.beta_n; ++k) bp[k] = 0.f;          // entries of a row that had more partials
+  }
+}
+
+// ------------------------------------------------------------------ k_step_alpha_w
+// The same step with ONE WAVE PER SITE walking the NT 16-row tiles itself (as k_inc_score_w does for the scores):
+// products, column sums, the merged row and the site's image are private to the wave, so nothing in the loop
+// synchronises with another wave -- k_step_alpha pays four group barriers per site and its partners of wave 0 idle
+// while it finishes the merged row (measured: waiting, not issue, bounds that kernel: VALU 0.15, matrix pipe 0.29 of
+// the cycles).  NW waves per workgroup at <= 512 / ceil(NW / 4) registers; the other waves of the SIMD cover a wave's
+// dependent chains.
+template <int NT, int NW>
+__global__ __launch_bounds__(64 * NW) void k_step_alpha_w(RowSet rs, ScorerW w, StepIO io, int n, int C, int cs) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int IMG = 16 * NT * 64 * NPL / 2;              // floats of a site image = of the products of its rows
+  constexpr int XS = 64 * 5;                               // per-wave scratch: xg | g | S_m | U_m | spare
+  float* At_l = smem;                                      // A^T
+  float* Wh_l = smem + IMG64;
+  float* Wg_l = smem + 2 * IMG64;
+  const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, kq = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  float* img = smem + 3 * IMG64 + wave * IMG;
+  float* xs = smem + 3 * IMG64 + NW * IMG + wave * XS;
+  float* cv = smem + 3 * IMG64 + NW * IMG + NW * XS;
+  float* epi = cv + SCORER_CONSTS;                         // [NW][64 + 2] sums of the epilogue
+  const int sc = blockIdx.x, b = blockIdx.y;
+  const int c0 = sc * cs, c1 = min(C, c0 + cs);
+  stage_weight_t16(At_l, w.A, 64, tid, 64 * NW, true);
+  stage_weight_t16(Wh_l, w.Wh, 64, tid, 64 * NW);
+  stage_weight_t16(Wg_l, w.Wg, 64, tid, 64 * NW);
+  stage_scorer_consts(cv, w, tid);
+  __syncthreads();
+  const int m = min(max(io.ij[2 * b], 0), n - 1);
+  const int j_old = min(max(io.ij[2 * b + 1], 0), n);
+  const size_t bo = (size_t)b * rs.bstride;
+  const int slot_m = slot_of(rs, b, m);
+  const int slot_j = io.live_old[(size_t)b * rs.live_stride + j_old];
+  const size_t om = bo + (size_t)slot_m * C * 64, oj = bo + (size_t)slot_j * C * 64;
+  const float* Sr[NT];
+  float sgn[NT], aw[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int q = 16 * t + l15;
+    const bool qv = q < n - 1;
+    const int r = qv ? q_to_r(q, m) : (m == 0 ? 1 : 0);      // lanes beyond the rows read a row that is not written here
+    sgn[t] = r < m ? 1.0f : -1.0f;
+    aw[t] = qv ? io.am[(size_t)b * 64 + r] : 0.f;
+    Sr[t] = rs.S + bo + (size_t)slot_of(rs, b, r) * C * 64;
+  }
+  const int ca = io.cand ? io.cand[2 * b] : -1;
+  const bool has_cand = ca >= 0;
+  float* Xc = io.Xc + (size_t)b * C * 64;
+  if (has_cand && io.cand_run[b]) {
+    // the candidate changed: x' = A^T gate(S_a, S_b) of its rows for this workgroup's sites (see k_step_alpha)
+    const int cb2 = io.cand[2 * b + 1];
+    const float* Sa = rs.S + bo + (size_t)slot_of(rs, b, ca) * C * 64;
+    const float* Sb = rs.S + bo + (size_t)slot_of(rs, b, cb2) * C * 64;
+    const float* Ua = rs.U + bo + (size_t)slot_of(rs, b, ca) * C * 64;
+    const float* Ub = rs.U + bo + (size_t)slot_of(rs, b, cb2) * C * 64;
+    for (int cc0 = c0 + 16 * wave; cc0 < c1; cc0 += 16 * NW) {
+      const int cc = cc0 + l15;
+      const bool ok = cc < c1;
+      const size_t o = (size_t)(ok ? cc : c1 - 1) * 64;
+      V64 sa, sb, ua, ub, x;
+      load_v64(sa, Sa + o, kq); load_v64(sb, Sb + o, kq);
+      load_v64(ua, Ua + o, kq); load_v64(ub, Ub + o, kq);
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) {
+        const f32x4 b4 = *reinterpret_cast<const f32x4*>(cv + 16 * mt + 4 * kq);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float z = sigmoid_l2(ua.t[mt][e] - ub.t[mt][e] + b4[e]);
+          x.t[mt][e] = sb.t[mt][e] + z * (sa.t[mt][e] - sb.t[mt][e]);
+        }
+      }
+      V64 xp;
+      lds_wait_all();
+      linear_t16p<4, false, false>(xp.t, x, At_l, nullptr, lane);
+      if (ok) {
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) *reinterpret_cast<f32x4*>(Xc + o + 16 * mt + 4 * kq) = xp.t[mt];
+      }
+    }
+    __threadfence_block();
+    __syncthreads();
+  }
+  const float u_l = w.u[lane];
+  const float bh_l = cv[lane];
+  f32x4 acc[NT][NT];                                       // [pair tile][row tile]
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int mt = 0; mt < NT; ++mt) acc[t][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float cacc[NT], beta_acc = 0.f, cm_acc = 0.f;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) cacc[t] = 0.f;
+  u32x4* im4 = reinterpret_cast<u32x4*>(img);
+  constexpr int PL = 16 * NT * 8;
+  float* v_xg = xs;
+  float* v_g = xs + 64;
+  float* v_sm = xs + 128;
+  float* v_um = xs + 192;
+  float* v_xc = xs + 256;
+  for (int c = c0 + wave; c < c1; c += NW) {
+    asm volatile("" ::: "memory");
+    V64 sr[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) load_v64(sr[t], Sr[t] + (size_t)c * 64, kq);
+    const float si = rs.S[om + (size_t)c * 64 + lane], sj = rs.S[oj + (size_t)c * 64 + lane];
+    const float ui = rs.U[om + (size_t)c * 64 + lane], uj = rs.U[oj + (size_t)c * 64 + lane];
+    const float xc_l = has_cand ? Xc[(size_t)c * 64 + lane] : 0.f;
+    // ---- 1. am_r S_r[c] as fp32 rows of the (dead) image buffer (16-byte chunk ch of row k at chunk ch ^ (k & 15)),
+    // then the column sums over all rows: x_g, one feature per lane
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      float* pw = img + (16 * t + l15) * 64;
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) {
+        const f32x4 p = sr[t].t[mt] * aw[t];
+        *reinterpret_cast<f32x4*>(pw + 4 * ((4 * mt + kq) ^ l15)) = p;
+      }
+    }
+    asm volatile("" ::: "memory");
+    float xg = 0.f;
+#pragma unroll
+    for (int k8 = 0; k8 < 2 * NT; ++k8) {                  // eight reads in flight at a time (all 16 NT would take as many registers)
+#pragma unroll
+      for (int k = 8 * k8; k < 8 * k8 + 8; ++k) xg += img[k * 64 + (lane ^ (4 * (k & 15)))];
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // ---- 2. the merged row of this site (see k_step_alpha)
+    const float z = sigmoid_l2(ui - uj + bh_l);
+    const float xij = sj + z * (si - sj);
+    v_xg[lane] = xg;
+    asm volatile("" ::: "memory");
+    {
+      V64 g, sm, um;
+      {
+        V64 xv;
+        load_v64(xv, v_xg, kq);
+        Frag3 bf[2];
+        split_8(bf[0], xv.t[0], xv.t[1]);
+        split_8(bf[1], xv.t[2], xv.t[3]);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) g.t[mt] = *reinterpret_cast<const f32x4*>(cv + 64 + 16 * mt + 4 * kq);
+        lds_wait_all();
+        linear_t16p_core<4>(g.t, bf, Wg_l, lane, [] {});
+      }
+      if (l15 == 0) {
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) *reinterpret_cast<f32x4*>(v_g + 16 * mt + 4 * kq) = g.t[mt];
+      }
+      asm volatile("" ::: "memory");
+      const float wg = sigmoid_l2(v_g[lane]);
+      const float smd = xij + wg * (xg - xij);
+      io.S_w[om + (size_t)c * 64 + lane] = smd;
+      beta_acc += u_l * smd;
+      cm_acc += xc_l * smd;
+      v_sm[lane] = smd;
+      asm volatile("" ::: "memory");
+      load_v64(sm, v_sm, kq);
+      Frag3 bf[2];
+      split_8(bf[0], sm.t[0], sm.t[1]);
+      split_8(bf[1], sm.t[2], sm.t[3]);
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) um.t[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      lds_wait_all();
+      linear_t16p_core<4>(um.t, bf, Wh_l, lane, [] {});    // every column is U_m: the lane holds its 16 features as it stands
+      if (l15 == 0) {
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+          *reinterpret_cast<f32x4*>(v_um + 16 * mt + 4 * kq) = um.t[mt];
+          *reinterpret_cast<f32x4*>(io.U_w + om + (size_t)c * 64 + 16 * mt + 4 * kq) = um.t[mt];
+        }
+      }
+    }
+    if (n <= 2) continue;                                  // with two rows left the one new pair has no context (model.py:111)
+    // ---- 3. the new pairs (m, r).  First the image rows of all tiles (fp16 pieces of S_r), then tile by tile: the
+    // pieces again (split twice: kept, they and the x of every tile would not fit the registers), U_r = W_h S_r, gate,
+    // x' = A^T x, the products with the image; and x'_cand[c] . S_r[c]
+    if (has_cand) v_xc[lane] = xc_l;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      Frag3 sf[2];
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) split_8(sf[ks], sr[t].t[2 * ks], sr[t].t[2 * ks + 1]);
+      const int q = 16 * t + l15;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const int o = q * 8 + wswz6<8>(q, 4 * ks + kq);
+        im4[o] = sf[ks].h; im4[PL + o] = sf[ks].m;
+      }
+    }
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      V64 x;
+      {
+        Frag3 sf[2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) split_8(sf[ks], sr[t].t[2 * ks], sr[t].t[2 * ks + 1]);
+        V64 ur;
+        {
+          V64 um;                                          // S_m, U_m of the site are re-read from LDS per tile: kept in
+          load_v64(um, v_um, kq);                          // registers across the tiles they cost 32 of the 256
+          gate_init16(ur, um, cv, sgn[t], kq);
+        }
+        lds_wait_all();
+        linear_t16p_core<4>(ur.t, sf, Wh_l, lane, [] {});
+        V64 sm;
+        load_v64(sm, v_sm, kq);
+        gate16(x, sr[t], ur, sm);
+      }
+      if (has_cand) {
+        V64 xcv;
+        load_v64(xcv, v_xc, kq);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) cacc[t] += xcv.t[mt][e] * sr[t].t[mt][e];
+      }
+      V64 xp;
+      lds_wait_all();
+      linear_t16p<4, false, false>(xp.t, x, At_l, nullptr, lane);         // x' = A^T x
+      linear_t16<NT, true, false>(acc[t], xp, img, nullptr, lane);        // acc[q'][pair] += S_q' . x'
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  // ---- epilogue: one partial set per WORKGROUP, the waves added in wave order (bitwise reproducible)
+  __syncthreads();
+  float* red = smem + 3 * IMG64;                           // 4096 floats (NW * IMG >= 4096)
+  for (int i = tid; i < 4096; i += 64 * NW) red[i] = 0.f;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) { cacc[t] += __shfl_xor(cacc[t], 16); cacc[t] += __shfl_xor(cacc[t], 32); }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) { beta_acc += __shfl_xor(beta_acc, o); cm_acc += __shfl_xor(cm_acc, o); }
+  __syncthreads();
+  if (kq == 0) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) epi[wave * 66 + 16 * t + l15] = cacc[t];
+  }
+  if (lane == 0) { epi[wave * 66 + 64] = beta_acc; epi[wave * 66 + 65] = cm_acc; }
+  for (int s_ = 0; s_ < NW; ++s_) {
+    if (wave == s_) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int mt = 0; mt < NT; ++mt) {
+          f32x4* d4 = reinterpret_cast<f32x4*>(red + (16 * t + l15) * 64 + 16 * mt + 4 * kq);
+          *d4 = *d4 + acc[t][mt];
+        }
+    }
+    __syncthreads();
+  }
+  float* dst = io.alpha_part + ((size_t)b * gridDim.x + sc) * 4096;
+  for (int i = tid; i < 1024; i += 64 * NW)
+    reinterpret_cast<f32x4*>(dst)[i] = reinterpret_cast<const f32x4*>(red)[i];
+  if (tid < 64) {
+    float v = 0.f;
+    const int idx = tid == 63 ? 65 : (tid < 16 * NT ? tid : -1);         // (q <= 62: entry 63 carries the merged row's)
+    if (idx >= 0)
+      for (int s_ = 0; s_ < NW; ++s_) v += epi[s_ * 66 + idx];
+    if (io.acand_part) io.acand_part[((size_t)b * gridDim.x + sc) * 64 + tid] = v;
+  } else if (tid == 64) {
+    float v = 0.f;
+    for (int s_ = 0; s_ < NW; ++s_) v += epi[s_ * 66 + 64];
     float* bp = io.beta_w + ((size_t)b * (rs.bstride / ((long)C * 64)) + slot_m) * rs.ntile32;
     bp[sc] = v;
     if (sc == 0)

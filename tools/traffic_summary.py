@@ -13,7 +13,9 @@ KIND = [("k_embed", "k_embed"), ("k_key_classes", "k_embed"), ("k_qkv6", "k_qkv6
         ("k_row_pv", "k_row_pv"), ("k_tok1", "k_tok1"), ("k_ffn", "k_ffn"), ("k_row_xf", "k_row_xf"),
         ("k_pair_alpha", "k_pair_alpha"), ("k_alpha_softmax", "k_alpha_softmax"), ("k_pair_score", "k_pair_score"),
         ("k_assemble_argmax", "k_assemble_argmax"), ("k_agg_alpha", "k_agg_alpha"), ("k_agg_finish", "k_agg_finish"),
-        ("k_inc_alpha", "k_pair_alpha_incr"), ("k_inc_score", "k_pair_score_incr")]
+        ("k_inc_alpha", "k_pair_alpha_incr"), ("k_inc_score", "k_pair_score_incr"),
+        ("k_step_alpha", "k_pair_alpha_incr"), ("k_step_softmax", "k_alpha_softmax"), ("k_pair_xp", "k_step_small"),
+        ("k_agg_dot", "k_step_small"), ("k_agg_am", "k_step_small"), ("k_beta_sum", "k_step_small")]
 
 
 def read(path, counter):
@@ -54,5 +56,5 @@ if len(sys.argv) > 4:
                per_kind={k: dict(hbm_bytes_per_launch=e["hbm"] / e["launches"], launches=e["launches"])
                          for k, e in per.items()})
     json.dump(out, open(sys.argv[4], "w"), indent=1)
-for k, v in list(kernels.items())[:14]:
+for k, v in list(kernels.items())[:24]:
     print(f"{k[:40]:40s} x{v['launches']:3d}  fetch {v['fetch_bytes_per_launch_corrected'] / 1e9:8.3f} GB  write {v['write_bytes_per_launch'] / 1e9:8.3f} GB")
