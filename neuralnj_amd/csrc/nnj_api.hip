@@ -218,7 +218,8 @@ PairGeom pair_geom(int mode, int n, int B, int C) {
   if (mode == PAIRS_INCR) {
     // wave-private kernels: grid (nsc_blocks, B), 4 partial sets per block; nsc counts PARTIALS
     g.npairs = n; g.tpw = 1; g.pg = 1; g.ppad = 64;
-    int blocks = (1024 + B - 1) / B;           // (measured flat from 512 to 3072 workgroups per launch)
+    static const int wgs = getenv("NNJ_INCR_WGS") ? atoi(getenv("NNJ_INCR_WGS")) : 1024;
+    int blocks = (wgs + B - 1) / B;            // (measured flat from 512 to 3072 workgroups per launch)
     const int max_blocks = (C + 7) / 8;       // small batches: down to 8 sites per workgroup (1-2 per wave)
     if (blocks > max_blocks) blocks = max_blocks;
     if (blocks < 1) blocks = 1;
