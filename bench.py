@@ -294,6 +294,32 @@ def finetune_episode(cfgs, T, L, dev):
         return {"error": f"{type(e).__name__}: {e}"}
 
 
+def search_config5(cfgs, packed, dev, replicas=8):
+    """BASELINE configs[4] beside the headline: infer_opt=Search at 200 taxa x 4096 sites -- `replicas` sampled rollouts of
+    ONE alignment (encoded once, nnj_rollout_sample), duplicate topologies dropped by the device-side keys.  A side
+    figure (scoring of the distinct trees by likelihood is the next stage of Search and is not in this number)."""
+    try:
+        g5 = Nnj(cfgs, dev)
+        g5.load_weights(packed)
+        T5, L5 = 200, 4096
+        one = torch.from_numpy(synth.synth_codes_tree(1, T5, L5, seed=4242)).to(dev)
+        u = torch.from_numpy(np.random.default_rng(5).random((replicas, T5 - 1)).astype(np.float32))
+        g5.rollout_sample(one, None, u, temperature=1.0, replicas=replicas)["merges"].cpu()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        r = g5.rollout_sample(one, None, u, temperature=1.0, replicas=replicas)
+        keys = g5.topology_hash(r["merges"]).cpu()
+        torch.cuda.synchronize(dev)
+        dt = time.perf_counter() - t0
+        g5.check_numeric()
+        out = {"workload": f"Search mode, {T5} taxa x {L5} sites, {replicas} sampled rollouts of one alignment (BASELINE configs[4])",
+               "s_per_round": dt, "rollouts_per_sec": replicas / dt, "distinct_topologies": int(torch.unique(keys).numel())}
+        g5.close()
+        return out
+    except Exception as e:                                    # pragma: no cover
+        return {"error": f"{type(e).__name__}: {e}"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -432,7 +458,7 @@ def main():
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic", "streams_per_gpu": args.streams,
         "precision": "fp32 results (GEMM operands split into two fp16 pieces on the fp16 matrix pipe, three piece "
                      "products per fp32 product, fp32 accumulation; score tables as close to an fp64 evaluation as "
-                     "the reference's own fp32 tables, profiles/r02/parity_margin.json)",
+                     "the reference's own fp32 tables: profiles/r02/parity_margin.json, profiles/r03/golden_noise.json)",
         "config": {"workload": f"Batch={B} synthetic {T}x{L} MSAs per GPU, Argmax rollout (BASELINE configs[2]; "
                                f"configs[3] when sharded over 8 GPUs)",
                    "batch_per_gpu": B, "taxa": T, "sites": L, "gap_frac": 0.2,
@@ -542,6 +568,7 @@ def main():
             g.set_concurrency(args.streams)
         if world == 1 and not args.no_compat:
             out["finetune_episode"] = finetune_episode(cfgs, T, L, dev)
+            out["search_200x4096"] = search_config5(cfgs, packed, dev)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfgs, packed, T, L)
         if verified is not None:
