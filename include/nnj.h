@@ -53,7 +53,10 @@ typedef enum nnj_status {
 /* Mirrors cfgs.model.* read by PhyloATTN.__init__ (reference model.py:15-22). */
 typedef struct nnj_config {
   int32_t vocab_size;  /* cfgs.model.vocab_size   (4)                      */
-  int32_t patch_size;  /* cfgs.model.patch_size   (1 in the shipped yaml)  */
+  int32_t patch_size;  /* cfgs.model.patch_size   (1 in the shipped yaml; 1..16 supported: a TOKEN of the state is
+                          patch_size consecutive sites, model.py:72-79.  Every entry point takes L = SITES (a multiple
+                          of patch_size), codes / one-hot input [*,T,L(,4)] and masks [*,L] per site; state tensors are
+                          [B, rows, L / patch_size, 64]; the mask of a token is the mask of its first site.)        */
   int32_t embed_dim;   /* cfgs.model.embed_dim    (64)                     */
   int32_t num_heads;   /* cfgs.model.num_enc_heads (8)                     */
   int32_t num_layers;  /* cfgs.model.num_enc_layers (6)                    */

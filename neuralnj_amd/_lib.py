@@ -122,6 +122,7 @@ class Nnj:
                              int(m.num_enc_layers), int(self.device.index))
         self.cfgs = cfgs
         self.D = int(m.embed_dim)
+        self.K = int(m.patch_size)            # a token of the state is K consecutive sites (reference model.py:72-76)
         self.h = _vp()
         rc = self.lib.nnj_create(C.byref(self.cfg), C.byref(self.h))
         if rc != 0:
@@ -207,7 +208,7 @@ class Nnj:
         codes = self._u8(codes)
         B, T, L = codes.shape
         mask = self._u8(mask)
-        out = torch.empty((B, T, L, self.D), dtype=torch.float32, device=self.device)
+        out = torch.empty((B, T, L // self.K, self.D), dtype=torch.float32, device=self.device)
         ws = self.workspace(B, T, L)
         self._chk(self.lib.nnj_encode(self.h, _p(codes), None, _p(mask), _p(out), B, T, L, _p(ws), ws.numel(),
                                       self._stream()))
@@ -219,7 +220,7 @@ class Nnj:
         B, T, L, V = onehot.shape
         assert V == 4
         mask = self._u8(mask)
-        out = torch.empty((B, T, L, self.D), dtype=torch.float32, device=self.device)
+        out = torch.empty((B, T, L // self.K, self.D), dtype=torch.float32, device=self.device)
         ws = self.workspace(B, T, L)
         self._chk(self.lib.nnj_encode(self.h, None, _p(onehot), _p(mask), _p(out), B, T, L, _p(ws), ws.numel(),
                                       self._stream()))
@@ -227,7 +228,8 @@ class Nnj:
 
     def pair_scores_full(self, state, mask=None):
         state = self._f32(state)
-        B, n, L, _ = state.shape
+        B, n, Ct, _ = state.shape
+        L = Ct * self.K                                          # sites
         mask = self._u8(mask)
         out = torch.empty((B, n * (n - 1) // 2), dtype=torch.float32, device=self.device)
         ws = self.workspace(B, n, L)
@@ -238,7 +240,8 @@ class Nnj:
 
     def pair_scores_incr(self, state, mask, ij_prev, logits_prev):
         state = self._f32(state)
-        B, n, L, _ = state.shape
+        B, n, Ct, _ = state.shape
+        L = Ct * self.K                                          # sites
         mask = self._u8(mask)
         ij_prev = self._i32(ij_prev)
         logits_prev = self._f32(logits_prev)
@@ -259,9 +262,10 @@ class Nnj:
 
     def aggregate(self, state, ij):
         state = self._f32(state)
-        B, n, L, _ = state.shape
+        B, n, Ct, _ = state.shape
+        L = Ct * self.K                                          # sites
         ij = self._i32(ij)
-        out = torch.empty((B, 1, L, self.D), dtype=torch.float32, device=self.device)
+        out = torch.empty((B, 1, Ct, self.D), dtype=torch.float32, device=self.device)
         self._session_in(state)
         ws = self.workspace(B, n, L)
         self._chk(self.lib.nnj_aggregate(self.h, _p(state), _p(ij), _p(out), B, n, L, _p(ws), ws.numel(),
@@ -270,9 +274,10 @@ class Nnj:
 
     def env_step(self, state, ij):
         state = self._f32(state)
-        B, n, L, _ = state.shape
+        B, n, Ct, _ = state.shape
+        L = Ct * self.K                                          # sites
         ij = self._i32(ij)
-        out = torch.empty((B, n - 1, L, self.D), dtype=torch.float32, device=self.device)
+        out = torch.empty((B, n - 1, Ct, self.D), dtype=torch.float32, device=self.device)
         self._session_in(state)
         in_session = getattr(self, "_sess_tensor", None) is state
         ws = self.workspace(B, n, L)
@@ -305,7 +310,7 @@ class Nnj:
         total = sum(n * (n - 1) // 2 for n in range(2, T + 1))
         trace = torch.empty((B, total), dtype=torch.float32, device=self.device) if want_trace else None
         gap = torch.empty((B, T - 1), dtype=torch.float32, device=self.device) if want_trace else None
-        st = torch.empty((B, T, L, self.D), dtype=torch.float32, device=self.device) if want_state else None
+        st = torch.empty((B, T, L // self.K, self.D), dtype=torch.float32, device=self.device) if want_state else None
         ws = self.workspace(B, T, L)
         self._chk(self.lib.nnj_rollout_argmax(self.h, _p(codes), _p(mask), B, T, L, _p(fm), _p(merges), _p(trace),
                                               _p(gap), _p(st), _p(ws), ws.numel(), self._stream()))
@@ -321,13 +326,14 @@ class Nnj:
         """One loop iteration on the device: merge `ij` (env.step), score the new pairs and assemble the table
         (decode_zxr), argmax.  state [B,n+1,L,D] -> dict(state [B,n,L,D], logits [B,P(n)], ij [B,2], top2_gap [B])."""
         state = self._f32(state)
-        B, n1, L, _ = state.shape
+        B, n1, Ct, _ = state.shape
+        L = Ct * self.K                                          # sites
         n = n1 - 1
         mask = self._u8(mask)
         ij = self._i32(ij)
         lp = self._f32(logits_prev)
         fn = None if forced_next is None else self._i32(forced_next)
-        st = torch.empty((B, n, L, self.D), dtype=torch.float32, device=self.device)
+        st = torch.empty((B, n, Ct, self.D), dtype=torch.float32, device=self.device)
         lo = torch.empty((B, n * (n - 1) // 2), dtype=torch.float32, device=self.device)
         cij = torch.empty((B, 2), dtype=torch.int32, device=self.device)
         gap = torch.empty((B,), dtype=torch.float32, device=self.device)

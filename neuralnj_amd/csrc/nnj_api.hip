@@ -50,7 +50,7 @@ struct nnj_handle {
   size_t n_packed = 0;
   std::vector<LayerOff> lo;
   size_t oE0, oe0, oE2, oe2, oWh, obh, oWg, obg, oWgq, obgq, oWgk, obgk, oS0, os0, os2w, os2b;
-  size_t oA, oa0, ou, olut;      // derived (after the packed block)
+  size_t oA, oa0, ou, olut, optab;      // derived (after the packed block)
   size_t oWhS, obhS, oWgS, obgS; // derived: -log2(e) x (W_h, b_h, W_g, b_g): the sigmoids take exp2 arguments directly
   float t0 = 0.f, s2b = 0.f;
   int debug_stop = 0;            // encoder debug tap (nnj_debug_encoder_stop)
@@ -350,11 +350,13 @@ size_t ws_floats_one(int B, int T, int C) {
 // a rollout may run as up to NNJ_MAX_SUB independent sub-batches on streams of their own (nnj_set_concurrency):
 // the workspace holds either the whole batch or every split of it
 constexpr int NNJ_MAX_SUB = 4;
+// the tail of the workspace holds the token mask of a patched alignment (patch_size > 1: mask[:, ::patch_size])
+size_t pm_floats(int B, int C) { return align_up(((size_t)B * C + 3) / 4, 64); }
 size_t ws_floats(int B, int T, int C) {
   size_t need = ws_floats_one(B, T, C);
   for (int ns = 2; ns <= NNJ_MAX_SUB; ++ns)
     if (B >= ns) need = std::max(need, (size_t)ns * align_up(ws_floats_one((B + ns - 1) / ns, T, C), 64));
-  return need;
+  return align_up(need, 64) + pm_floats(B, C);
 }
 
 // ------------------------------------------------------------------ encoder launches
@@ -381,7 +383,8 @@ int launch_encoder(nnj_handle* h, const uint8_t* codes, const float* onehot, con
     if (int rc = set_lds(h, k_embed, lds)) return rc;
     const float* wp = h->d_w;
     const EmbedW ew{wp + h->oE0, wp + h->oe0, wp + h->oE2, wp + h->oe2};
-    hipLaunchKernelGGL(k_embed, dim3(colblocks), dim3(256), lds, st, codes, onehot, ew, lut, x, B, T, C);
+    hipLaunchKernelGGL(k_embed, dim3(colblocks), dim3(256), lds, st, codes, onehot, ew, lut, h->d_w + h->optab, x, B, T, C,
+                       h->cfg.patch_size);
     hipLaunchKernelGGL(k_key_classes, dim3((unsigned)(((size_t)B * g6.Cp + 255) / 256)), dim3(256), 0, st, mask, cls, B,
                        C, g6.Cp);
     // V6 keys beyond the alignment meet probabilities that are exactly 0: they only have to be finite
@@ -800,6 +803,24 @@ int need_ws(nnj_handle* h, void* ws, size_t ws_bytes, int B, int T, int C) {
   return NNJ_OK;
 }
 
+// sites -> tokens: a token is patch_size consecutive sites (reference model.py:72-76); the kernels work on tokens
+int to_tokens(nnj_handle* h, int L_sites, int32_t* C) {
+  const int K = h->cfg.patch_size;
+  if (L_sites <= 0 || L_sites % K) return fail(h, NNJ_ERR_ARG, "L=%d sites is not a positive multiple of patch_size=%d", L_sites, K);
+  *C = L_sites / K;
+  return NNJ_OK;
+}
+// the mask of the tokens: the caller's [B, L] mask as it is for patch_size 1, else mask[:, ::patch_size] (reference
+// model.py:79, 167) written to the tail of the (already validated) workspace
+int token_mask(nnj_handle* h, const uint8_t** mask, void* ws, int B, int T, int C, hipStream_t st) {
+  const int K = h->cfg.patch_size;
+  if (K == 1 || !*mask) return NNJ_OK;
+  uint8_t* pm = reinterpret_cast<uint8_t*>(static_cast<float*>(ws) + ws_floats(B, T, C) - pm_floats(B, C));
+  hipLaunchKernelGGL(k_patch_mask, dim3((unsigned)(((size_t)B * C + 255) / 256)), dim3(256), 0, st, *mask, pm, B, C, K);
+  *mask = pm;
+  return NNJ_OK;
+}
+
 // ---- sessions over the dense-state entry points (nnj_pair_scores_full / _incr, nnj_aggregate, nnj_env_step, nnj_step)
 // The reference's loop hands the dense state [B,n,C,D] from call to call.  The library keeps the rows of the tensor
 // it has last SEEN (nnj_pair_scores_full) or RETURNED (nnj_env_step, nnj_step) in slot layout inside the caller's
@@ -867,10 +888,10 @@ int nnj_num_params(const nnj_config* cfg, size_t* n) {
 
 int nnj_create(const nnj_config* cfg, nnj_handle** out) {
   if (!cfg || !out) return fail(nullptr, NNJ_ERR_ARG, "nnj_create: null argument");
-  if (cfg->embed_dim != NNJ_D || cfg->num_heads != NNJ_NHEAD || cfg->patch_size != 1 || cfg->vocab_size != 4 ||
-      cfg->num_layers < 0)
+  if (cfg->embed_dim != NNJ_D || cfg->num_heads != NNJ_NHEAD || cfg->patch_size < 1 || cfg->patch_size > 16 ||
+      cfg->vocab_size != 4 || cfg->num_layers < 0)
     return fail(nullptr, NNJ_ERR_UNSUPPORTED,
-                "this build covers embed_dim=64, num_enc_heads=8, patch_size=1, vocab_size=4 (got %d,%d,%d,%d)",
+                "this build covers embed_dim=64, num_enc_heads=8, patch_size 1..16, vocab_size=4 (got %d,%d,%d,%d)",
                 cfg->embed_dim, cfg->num_heads, cfg->patch_size, cfg->vocab_size);
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
@@ -932,7 +953,8 @@ int nnj_load_weights(nnj_handle* h, const float* p, size_t n) {
     }
     L.W1 = take(F * D); L.b1 = take(F); L.W2 = take(D * F); L.b2 = take(D); L.ln_w = take(D); L.ln_b = take(D);
   }
-  h->oE0 = take(D * 4); h->oe0 = take(D); h->oE2 = take(D * D); h->oe2 = take(D);
+  const size_t K = (size_t)h->cfg.patch_size;
+  h->oE0 = take(D * 4 * K); h->oe0 = take(D); h->oE2 = take(D * D); h->oe2 = take(D);
   h->oWh = take(D * D); h->obh = take(D); h->oWg = take(D * D); h->obg = take(D);
   h->oWgq = take(D * D); h->obgq = take(D); h->oWgk = take(D * D); h->obgk = take(D);
   h->oS0 = take(D * D); h->os0 = take(D); h->os2w = take(D); h->os2b = take(1);
@@ -942,7 +964,8 @@ int nnj_load_weights(nnj_handle* h, const float* p, size_t n) {
   const size_t base = align_up(need, 64);
   h->oA = base; h->oa0 = base + D * D; h->ou = h->oa0 + D; h->olut = h->ou + D;
   h->oWhS = h->olut + 6 * D; h->obhS = h->oWhS + D * D; h->oWgS = h->obhS + D; h->obgS = h->oWgS + D * D;
-  const size_t total = h->obgS + D;
+  h->optab = h->obgS + D;                                  // [K][6][D] first-layer contributions of the sites of a patch
+  const size_t total = h->optab + K * 6 * D;
   std::vector<float> host(total, 0.f);
   memcpy(host.data(), p, need * sizeof(float));
   const float *Wq = p + h->oWgq, *bq = p + h->obgq, *Wk = p + h->oWgk, *bk = p + h->obgk;
@@ -977,7 +1000,14 @@ int nnj_load_weights(nnj_handle* h, const float* p, size_t n) {
   // embed LUT of the six site vectors (model.py:39-43 on phydata.py:38-46)
   static const int onehot[6][4] = {{1,0,0,0},{0,1,0,0},{0,0,1,0},{0,0,0,1},{1,1,1,1},{0,0,0,0}};
   const float *E0 = p + h->oE0, *e0 = p + h->oe0, *E2 = p + h->oE2, *e2 = p + h->oe2;
-  for (int code = 0; code < 6; ++code) {
+  for (size_t i = 0; i < K; ++i)                            // patch table: site i of a patch carrying `code` (+ the bias once)
+    for (int code = 0; code < 6; ++code)
+      for (size_t j = 0; j < D; ++j) {
+        double s = i == 0 ? (double)e0[j] : 0.0;
+        for (int v = 0; v < 4; ++v) s += (double)E0[j * 4 * K + 4 * i + v] * onehot[code][v];
+        host[h->optab + (i * 6 + code) * D + j] = (float)s;
+      }
+  for (int code = 0; code < 6 && K == 1; ++code) {
     double t1[NNJ_D];
     for (size_t j = 0; j < D; ++j) {
       double s = e0[j];
@@ -998,33 +1028,41 @@ int nnj_load_weights(nnj_handle* h, const float* p, size_t n) {
   return NNJ_OK;
 }
 
-int nnj_workspace_bytes(const nnj_handle* h, int32_t B, int32_t T, int32_t L, size_t* bytes) {
-  if (!h || !bytes || B <= 0 || T < 1 || L <= 0) return fail(const_cast<nnj_handle*>(h), NNJ_ERR_ARG, "nnj_workspace_bytes: bad argument");
+int nnj_workspace_bytes(const nnj_handle* h, int32_t B, int32_t T, int32_t L_sites, size_t* bytes) {
+  if (!h || !bytes || B <= 0 || T < 1 || L_sites <= 0) return fail(const_cast<nnj_handle*>(h), NNJ_ERR_ARG, "nnj_workspace_bytes: bad argument");
+  int32_t L = 0;
+  if (int rc = to_tokens(const_cast<nnj_handle*>(h), L_sites, &L)) return rc;
   *bytes = ws_floats(B, T, L) * sizeof(float);
   return NNJ_OK;
 }
 
 int nnj_encode(nnj_handle* h, const uint8_t* codes, const float* onehot, const uint8_t* mask, float* state_out,
-               int32_t B, int32_t T, int32_t L, void* ws, size_t ws_bytes, void* stream) {
+               int32_t B, int32_t T, int32_t L_sites, void* ws, size_t ws_bytes, void* stream) {
   DevGuard dev_guard;
   if (int rc = ready(h)) return rc;
+  int32_t L = 0;                                           // tokens (patches of sites)
+  if (int rc = to_tokens(h, L_sites, &L)) return rc;
   if ((!codes && !onehot) || (codes && onehot) || !state_out)
     return fail(h, NNJ_ERR_ARG, "nnj_encode: exactly one of codes / onehot, and an output buffer, are required");
   if (int rc = check_shape(h, B, T, L)) return rc;
   if (int rc = need_ws(h, ws, ws_bytes, B, T, L)) return rc;
+  if (int rc = token_mask(h, &mask, ws, B, T, L, static_cast<hipStream_t>(stream))) return rc;
   float* base = static_cast<float*>(ws);
   const size_t state = align_up((size_t)B * T * L * 64, 64);
   return run_encoder(h, codes, mask, state_out, base + state, B, T, L, static_cast<hipStream_t>(stream), onehot);
 }
 
 int nnj_pair_scores_full(nnj_handle* h, const float* state, const uint8_t* mask, float* logits_out, int32_t B,
-                         int32_t n, int32_t L, void* ws, size_t ws_bytes, void* stream) {
+                         int32_t n, int32_t L_sites, void* ws, size_t ws_bytes, void* stream) {
   DevGuard dev_guard;
   if (int rc = ready(h)) return rc;
+  int32_t L = 0;                                           // tokens (patches of sites)
+  if (int rc = to_tokens(h, L_sites, &L)) return rc;
   if (!state || !logits_out || n < 2) return fail(h, NNJ_ERR_ARG, "nnj_pair_scores_full: bad argument");
   if (int rc = check_shape(h, B, n, L)) return rc;
   if (int rc = need_ws(h, ws, ws_bytes, B, n, L)) return rc;
   hipStream_t st = static_cast<hipStream_t>(stream);
+  if (int rc = token_mask(h, &mask, ws, B, n, L, st)) return rc;
   // first decode of a loop: the rows go into a session (see sess_matches) that the following nnj_env_step /
   // nnj_pair_scores_incr / nnj_aggregate calls on the same tensors continue
   const SessView v = sess_view(ws, B, n, L);
@@ -1045,16 +1083,19 @@ int nnj_pair_scores_full(nnj_handle* h, const float* state, const uint8_t* mask,
 }
 
 int nnj_pair_scores_incr(nnj_handle* h, const float* state, const uint8_t* mask, const int32_t* ij_prev,
-                         const float* logits_prev, float* logits_out, int32_t B, int32_t n, int32_t L, void* ws,
+                         const float* logits_prev, float* logits_out, int32_t B, int32_t n, int32_t L_sites, void* ws,
                          size_t ws_bytes, void* stream) {
   DevGuard dev_guard;
   if (int rc = ready(h)) return rc;
+  int32_t L = 0;                                           // tokens (patches of sites)
+  if (int rc = to_tokens(h, L_sites, &L)) return rc;
   if (!state || !ij_prev || !logits_prev || !logits_out || n < 2) return fail(h, NNJ_ERR_ARG, "nnj_pair_scores_incr: bad argument");
   hipStream_t st = static_cast<hipStream_t>(stream);
   const bool cont = sess_matches(h, ws, state, B, n, L);
   const int T0 = cont ? h->sess.T0 : n + 1;
   if (int rc = check_shape(h, B, T0, L)) return rc;
   if (int rc = need_ws(h, ws, ws_bytes, B, T0, L)) return rc;      // (invalidates the session: re-validated below)
+  if (int rc = token_mask(h, &mask, ws, B, T0, L, st)) return rc;
   PairGeom g;
   const SessView v = sess_view(ws, B, T0, L);
   RowSet rs = v.rs;
@@ -1086,9 +1127,11 @@ int nnj_score_index_map(nnj_handle* h, const int32_t* ij_prev, int64_t* idx_out,
 }
 
 int nnj_aggregate(nnj_handle* h, const float* state, const int32_t* ij, float* out_row, int32_t B, int32_t n,
-                  int32_t L, void* ws, size_t ws_bytes, void* stream) {
+                  int32_t L_sites, void* ws, size_t ws_bytes, void* stream) {
   DevGuard dev_guard;
   if (int rc = ready(h)) return rc;
+  int32_t L = 0;                                           // tokens (patches of sites)
+  if (int rc = to_tokens(h, L_sites, &L)) return rc;
   if (!state || !ij || !out_row || n < 2) return fail(h, NNJ_ERR_ARG, "nnj_aggregate: bad argument");
   hipStream_t st = static_cast<hipStream_t>(stream);
   const bool cont = sess_matches(h, ws, state, B, n, L);
@@ -1105,9 +1148,11 @@ int nnj_aggregate(nnj_handle* h, const float* state, const int32_t* ij, float* o
 }
 
 int nnj_env_step(nnj_handle* h, const float* state, const int32_t* ij, float* state_out, int32_t B, int32_t n,
-                 int32_t L, void* ws, size_t ws_bytes, void* stream) {
+                 int32_t L_sites, void* ws, size_t ws_bytes, void* stream) {
   DevGuard dev_guard;
   if (int rc = ready(h)) return rc;
+  int32_t L = 0;                                           // tokens (patches of sites)
+  if (int rc = to_tokens(h, L_sites, &L)) return rc;
   if (!state || !ij || !state_out || n < 3) return fail(h, NNJ_ERR_ARG, "nnj_env_step: bad argument (n must be >= 3)");
   hipStream_t st = static_cast<hipStream_t>(stream);
   const bool cont = sess_matches(h, ws, state, B, n, L);
@@ -1163,9 +1208,11 @@ int nnj_select_pair(nnj_handle* h, const float* logits, int32_t* ij_out, float* 
 
 int nnj_step(nnj_handle* h, const float* state, const uint8_t* mask, const int32_t* ij, const float* logits_prev,
              const int32_t* forced_next, float* state_out, float* logits_out, int32_t* chosen_ij, float* top2_gap,
-             int32_t B, int32_t n, int32_t L, void* ws, size_t ws_bytes, void* stream) {
+             int32_t B, int32_t n, int32_t L_sites, void* ws, size_t ws_bytes, void* stream) {
   DevGuard dev_guard;
   if (int rc = ready(h)) return rc;
+  int32_t L = 0;                                           // tokens (patches of sites)
+  if (int rc = to_tokens(h, L_sites, &L)) return rc;
   if (!state || !ij || !logits_prev || !state_out || !logits_out || !chosen_ij || n < 2)
     return fail(h, NNJ_ERR_ARG, "nnj_step: bad argument (n = rows after the merge, >= 2)");
   hipStream_t st = static_cast<hipStream_t>(stream);
@@ -1180,6 +1227,7 @@ int nnj_step(nnj_handle* h, const float* state, const uint8_t* mask, const int32
   const int T0 = cont ? h->sess.T0 : n + 1;
   if (int rc = check_shape(h, B, T0, L)) return rc;
   if (int rc = need_ws(h, ws, ws_bytes, B, T0, L)) return rc;      // (invalidates the session: re-validated below)
+  if (int rc = token_mask(h, &mask, ws, B, T0, L, st)) return rc;
   const SessView v = sess_view(ws, B, T0, C);
   float* S = v.S;
   float* base = v.base;
@@ -1325,7 +1373,7 @@ static int rollout_core(nnj_handle* h, const uint8_t* codes, const uint8_t* mask
 // stays asynchronous on `stream`, nothing else changes for the caller).  The sub-batches drift apart by a kernel or
 // two, so HBM-bound launches of one (merged-row passes, q/k/v planes) overlap matrix- and vector-bound launches of
 // another, and the tail of every launch is filled by the other sub-batch.
-static int rollout_impl(nnj_handle* h, const uint8_t* codes, const uint8_t* mask_in, int32_t B, int32_t T, int32_t L,
+static int rollout_impl(nnj_handle* h, const uint8_t* codes, const uint8_t* mask_in, int32_t B, int32_t T, int32_t L_sites,
                         int32_t n_encode, const int32_t* forced, const float* uniforms, float inv_temp,
                         int32_t* merges_out, float* trace, float* gap, float* state_out, void* ws, size_t ws_bytes,
                         void* stream) {
@@ -1333,9 +1381,17 @@ static int rollout_impl(nnj_handle* h, const uint8_t* codes, const uint8_t* mask
   if (int rc = ready(h)) return rc;
   if (!codes || !merges_out || T < 2) return fail(h, NNJ_ERR_ARG, "rollout: bad argument");
   if (n_encode != B && n_encode != 1) return fail(h, NNJ_ERR_ARG, "rollout: n_encode must be 1 or B");
+  int32_t L = 0;                                           // tokens (patches of sites); codes stay [*, T, L_sites]
+  if (int rc = to_tokens(h, L_sites, &L)) return rc;
   if (int rc = check_shape(h, B, T, L)) return rc;
   if (int rc = need_ws(h, ws, ws_bytes, B, T, L)) return rc;
   hipStream_t st = static_cast<hipStream_t>(stream);
+  if (h->cfg.patch_size > 1 && mask_in) {                  // mask of the tokens, n_encode rows, in the workspace tail
+    uint8_t* pm = reinterpret_cast<uint8_t*>(static_cast<float*>(ws) + ws_floats(B, T, L) - pm_floats(B, L));
+    hipLaunchKernelGGL(k_patch_mask, dim3((unsigned)(((size_t)n_encode * L + 255) / 256)), dim3(256), 0, st, mask_in, pm,
+                       n_encode, L, h->cfg.patch_size);
+    mask_in = pm;
+  }
   int ns = std::min(h->concurrency, NNJ_MAX_SUB);
   if (n_encode != B || B < 64 || ns < 2) {
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
@@ -1402,7 +1458,7 @@ static int rollout_impl(nnj_handle* h, const uint8_t* codes, const uint8_t* mask
     const int b0 = k * per, bn = std::min(per, B - b0);
     if (bn <= 0) break;
     HIPCHK(h, hipStreamWaitEvent(h->sub[k], h->ev_fork, 0));
-    if (int rc = rollout_core(h, codes + (size_t)b0 * T * L, mask_in ? mask_in + (size_t)b0 * L : nullptr, bn, T, L, bn,
+    if (int rc = rollout_core(h, codes + (size_t)b0 * T * L_sites, mask_in ? mask_in + (size_t)b0 * L : nullptr, bn, T, L, bn,
                               forced ? forced + (size_t)b0 * (T - 1) * 2 : nullptr,
                               uniforms ? uniforms + (size_t)b0 * (T - 1) : nullptr, inv_temp,
                               merges_out + (size_t)b0 * (T - 1) * 2, trace ? trace + (size_t)b0 * total : nullptr,

@@ -21,26 +21,31 @@ struct AttnW {            // pointers into the packed device weights (row-major 
 struct FfnW {
   const float *W1, *b1, *W2, *b2, *ln_w, *ln_b;
 };
-struct EmbedW {           // embed = Linear(4 -> 64), GELU, Linear(64 -> 64)  (reference model.py:39-43)
+struct EmbedW {           // embed = Linear(4 K -> 64), GELU, Linear(64 -> 64)  (reference model.py:39-43; K = patch_size)
   const float *E0, *e0, *E2, *e2;
 };
 
 // ------------------------------------------------------------------ k_embed
-// codes uint8 [B,R,L] (patch_size 1: C == L); lut [6][64] = embed MLP of the six site
-// vectors (reference model.py:39-43,76-77 evaluated on phydata.py:38-46's vectors).
+// codes uint8 [B,R,L], L = C * K sites (K = patch_size: a token is K consecutive sites, reference model.py:76
+// 'b r (c k) e -> b r c (k e)').  K = 1: lut [6][64] = the embed MLP of the six site vectors (reference
+// model.py:39-43,76-77 evaluated on phydata.py:38-46's vectors).  K > 1: ptab [K][6][64] = the first Linear's
+// contribution of site i of a patch carrying code v (its bias in entry i = 0), summed over the K sites, GELU, then the
+// second Linear on the matrix pipe.  Float input [B,R,L,4] (any values): the embed MLP itself.
 __global__ __launch_bounds__(256) void k_embed(const uint8_t* __restrict__ codes,
                                                const float* __restrict__ onehot, EmbedW ew,
-                                               const float* __restrict__ lut,
-                                               float* __restrict__ x, int B, int R, int C) {
+                                               const float* __restrict__ lut, const float* __restrict__ ptab,
+                                               float* __restrict__ x, int B, int R, int C, int K) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* E2_l = smem;             // only staged for the general float input
+  float* E2_l = smem;             // only staged for the general float input and for patches
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if (onehot) stage_weight<64>(E2_l, ew.E2, 64, tid, 256);
+  const bool mlp = onehot != nullptr || K > 1;
+  if (mlp) stage_weight<64>(E2_l, ew.E2, 64, tid, 256);
   __syncthreads();
   const long col = (long)blockIdx.x * 4 + wave;   // (b, c) flattened
   if (col >= (long)B * C) return;
   const int b = (int)(col / C), c = (int)(col % C);
   const int tok = lane & 31, hh = lane >> 5;
+  const size_t L = (size_t)C * K;
   // a wave owns one alignment column and walks its rows 32 at a time (any number of rows)
   for (int r0 = 0; r0 < R; r0 += 32) {
     const int r = r0 + tok;
@@ -49,7 +54,7 @@ __global__ __launch_bounds__(256) void k_embed(const uint8_t* __restrict__ codes
     if (onehot) {
       // general float input [B,R,L,4]: the embed MLP itself (first Linear on the VALU, second by MFMA)
       f32x16 t1[1][2];
-      const f32x4 oh = *reinterpret_cast<const f32x4*>(onehot + (((size_t)b * R + (valid ? r : 0)) * C + c) * 4);
+      const float* ohp = onehot + (((size_t)b * R + (valid ? r : 0)) * L + (size_t)c * K) * 4;
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -57,11 +62,36 @@ __global__ __launch_bounds__(256) void k_embed(const uint8_t* __restrict__ codes
           const f32x4 b4 = *reinterpret_cast<const f32x4*>(ew.e0 + 32 * mt + 8 * g + 4 * hh);
 #pragma unroll
           for (int t = 0; t < 4; ++t) {
-            const f32x4 wv = *reinterpret_cast<const f32x4*>(ew.E0 + (32 * mt + 8 * g + 4 * hh + t) * 4);
-            const float s = b4[t] + wv[0] * oh[0] + wv[1] * oh[1] + wv[2] * oh[2] + wv[3] * oh[3];
+            const float* wrow = ew.E0 + (size_t)(32 * mt + 8 * g + 4 * hh + t) * 4 * K;
+            float s = b4[t];
+            for (int i = 0; i < K; ++i) {
+              const f32x4 oh = *reinterpret_cast<const f32x4*>(ohp + 4 * i);
+              const f32x4 wv = *reinterpret_cast<const f32x4*>(wrow + 4 * i);
+              s += wv[0] * oh[0] + wv[1] * oh[1] + wv[2] * oh[2] + wv[3] * oh[3];
+            }
             t1[0][mt][4 * g + t] = valid ? gelu_erf(s) : 0.f;
           }
         }
+      linear_T<2, 2, 1>(xr, t1, E2_l, ew.e2, lane);
+    } else if (K > 1) {
+      f32x16 t1[1][2];
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t1[0][mt][k] = 0.f;
+      const uint8_t* cp = codes + ((size_t)b * R + (valid ? r : 0)) * L + (size_t)c * K;
+      for (int i = 0; i < K; ++i) {
+        int code = cp[i];
+        if (code > 5) code = 5;
+        f32x16 add[2];
+        load_token64(add, ptab + ((size_t)i * 6 + code) * 64, true, hh);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) t1[0][mt] += add[mt];
+      }
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t1[0][mt][k] = valid ? gelu_erf(t1[0][mt][k]) : 0.f;
       linear_T<2, 2, 1>(xr, t1, E2_l, ew.e2, lane);
     } else {
       int code = codes[((size_t)b * R + (valid ? r : 0)) * C + c];
@@ -70,6 +100,11 @@ __global__ __launch_bounds__(256) void k_embed(const uint8_t* __restrict__ codes
     }
     store_token64(xr[0], x + (((size_t)b * R + r) * C + c) * 64, valid, hh);
   }
+}
+// mask of the tokens of a patched alignment: batch_seq_mask[:, ::patch_size] (reference model.py:79, 167)
+__global__ void k_patch_mask(const uint8_t* __restrict__ mask, uint8_t* __restrict__ out, int B, int C, int K) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < (long)B * C) out[i] = mask[(i / C) * ((long)C * K) + (i % C) * K];
 }
 
 // ------------------------------------------------------------------ k_tok1p

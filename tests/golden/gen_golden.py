@@ -85,7 +85,7 @@ def make_cfg(utils_mod, layers=6):
     return cfgs
 
 
-def run_case(name, codes, mask, wseed, style, ref, keys=None, layers=6, capture_layers=False):
+def run_case(name, codes, mask, wseed, style, ref, keys=None, layers=6, capture_layers=False, patch=1):
     """codes uint8 [B,T,L]; mask bool [B,L] (True = padded site)."""
     import torch
     from neuralnj_amd import synth, weights
@@ -93,6 +93,7 @@ def run_case(name, codes, mask, wseed, style, ref, keys=None, layers=6, capture_
     frs, utils_mod, PGPI, PhyInferEnv = ref
     torch.manual_seed(0)
     cfgs = make_cfg(utils_mod, layers)
+    cfgs.model.patch_size = patch
     agent = PGPI(cfgs)
     st = weights.seeded_state(cfgs, wseed, style)
     agent.load_state_dict({k: torch.from_numpy(v) for k, v in st.items()}, strict=True)
@@ -176,7 +177,7 @@ def run_case(name, codes, mask, wseed, style, ref, keys=None, layers=6, capture_
 
     out = dict(
         codes=codes, mask=mask, wseed=np.int64(wseed), style=np.array(style),
-        layers=np.int64(layers), weights_sha256=np.array(weights.digest(packed)),
+        layers=np.int64(layers), patch=np.int64(patch), weights_sha256=np.array(weights.digest(packed)),
         merges=merges, logits=logits, logits_offsets=offs, top2_gap=gaps,
         newick=np.array(newick), topo=np.array(topo), best_tree=np.array(best_tree),
         keys=np.array(keys),
@@ -188,7 +189,7 @@ def run_case(name, codes, mask, wseed, style, ref, keys=None, layers=6, capture_
     else:
         # strided slice: every 7th row, every 61st column, all features
         out["enc_rows"] = np.arange(0, T, 7, dtype=np.int64)
-        out["enc_cols"] = np.arange(0, L, 61, dtype=np.int64)
+        out["enc_cols"] = np.arange(0, enc.shape[2], 61, dtype=np.int64)
         out["enc_slice"] = enc[:, ::7, ::61, :].astype(np.float32)
     for k, v in trace["sub"].items():
         out["sub_" + k] = v.astype(np.float32)
@@ -322,6 +323,26 @@ def main():
             codes = synth.synth_codes_tree(1, 100, 256, 2000 + sd)
             run_case(f"synth_b1_t100_l256_s{sd}", codes, np.zeros((1, 256), dtype=bool), sd, "sharp", ref)
         add(f"synth_b1_t100_l256_s{sd}", wide_100)
+
+    # patch_size > 1 (a token = several consecutive sites; the reference's utils.py default is 4): a small case with
+    # padded sites, and 20 taxa x 256 sites
+    def patch4_small():
+        codes = synth.synth_codes_tree(2, 8, 128, 2016)
+        codes[:, :, 112:] = 5
+        mask = np.zeros((2, 128), dtype=bool)
+        mask[:, 112:] = True
+        run_case("patch4_b2_t8_l128_s16", codes, mask, 16, "sharp", ref, patch=4, capture_layers=False)
+    add("patch4_b2_t8_l128_s16", patch4_small)
+
+    def patch4_mid():
+        codes = synth.synth_codes_tree(1, 20, 256, 2017)
+        run_case("patch4_b1_t20_l256_s17", codes, np.zeros((1, 256), dtype=bool), 17, "sharp", ref, patch=4)
+    add("patch4_b1_t20_l256_s17", patch4_mid)
+
+    def patch2_mid():
+        codes = synth.synth_codes(1, 12, 96, 2018, gap_frac=0.2)
+        run_case("patch2_b1_t12_l96_s18", codes, np.zeros((1, 96), dtype=bool), 18, "plain", ref, patch=2)
+    add("patch2_b1_t12_l96_s18", patch2_mid)
 
     def wide_70():
         codes = synth.synth_codes_tree(2, 70, 64, 2012)

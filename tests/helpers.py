@@ -31,6 +31,8 @@ def load_golden(name):
     z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
     cfgs = utils.shipped_config()
     cfgs.model.num_enc_layers = int(z["layers"])
+    if "patch" in z.files:
+        cfgs.model.patch_size = int(z["patch"])
     st = weights.seeded_state(cfgs, int(z["wseed"]), str(z["style"]))
     packed = weights.pack(cfgs, st)
     assert weights.digest(packed) == str(z["weights_sha256"]), "seeded weights drifted from the fixture"

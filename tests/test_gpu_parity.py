@@ -173,7 +173,7 @@ def test_encoder_taps_match_oracle(name, ctx_cache):
 
 
 @pytest.mark.parametrize("name", ["synth_b2_t8_l128_s1", "padded_b2_t8_l128_s3", "plain_b1_t12_l96_s4",
-                                  "synth_b1_t20_l256_s1", "synth_b2_t70_l64_s12"])
+                                  "synth_b1_t20_l256_s1", "synth_b2_t70_l64_s12", "patch4_b2_t8_l128_s16"])
 def test_entry_points_match_oracle_step_by_step(name, ctx_cache):
     """The reference's call sequence (decode_zxr / argmax / env.step) through the separate
     C-ABI entry points, each compared with the oracle on the same inputs."""
@@ -461,6 +461,17 @@ def test_unsupported_shapes_fail_loudly(ctx_cache):
     with pytest.raises(RuntimeError, match="256 rows"):
         g.rollout_argmax(torch.zeros(1, 257, 64, dtype=torch.uint8))
     from neuralnj_amd._lib import Nnj
+    c4 = utils.shipped_config()
+    c4.model.patch_size = 4                                 # tokens of four sites: 30 sites are not a whole number of them
+    g4 = Nnj(c4, "cuda:0")
+    g4.load_weights(weights.pack(c4, weights.seeded_state(c4, 0, "sharp")))
+    with pytest.raises(RuntimeError, match="multiple of patch_size"):
+        g4.rollout_argmax(torch.zeros(1, 4, 30, dtype=torch.uint8))
+    g4.close()
+    c32 = utils.shipped_config()
+    c32.model.embed_dim = 32
+    with pytest.raises(RuntimeError, match="embed_dim=64"):
+        Nnj(c32, "cuda:0")
     g2 = Nnj(cfgs, "cuda:0")
     with pytest.raises(RuntimeError, match="weights not loaded"):
         g2.encode(torch.zeros(1, 4, 32, dtype=torch.uint8))

@@ -79,6 +79,13 @@ def test_oracle_matches_reference_round3_wide_cases():
     _check("synth_b1_t200_l256_s13", "f64", rel=6e-4)
 
 
+@pytest.mark.parametrize("name", ["patch4_b2_t8_l128_s16", "patch4_b1_t20_l256_s17", "patch2_b1_t12_l96_s18"])
+def test_oracle_matches_reference_patched_tokens(name):
+    """patch_size 4 and 2 (a token = several consecutive sites, model.py:72-79; the reference's utils.py default is 4):
+    embed over the concatenated site vectors, the mask taken every patch_size-th site, alpha scaled by the patch count."""
+    _check(name)
+
+
 def test_oracle_free_run_rf_gate():
     """The RF = 0 gate of the GPU tests, exercised on the CPU: the fp32 oracle's free run against the
     reference's free run, fp64 build as arbiter where the merge lists part (helpers.free_run_verdict)."""
