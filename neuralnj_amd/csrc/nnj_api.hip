@@ -1302,6 +1302,12 @@ static int rollout_core(nnj_handle* h, const uint8_t* codes, const uint8_t* mask
   RowSet rs;
   rs.S = S; rs.U = base + w.U; rs.Kp = base + w.Kp; rs.beta_part = base + w.beta;
   rs.bstride = (long)T * C * 64; rs.live = livebuf[0]; rs.live_stride = T; rs.ntile32 = beta_stride(B, C);
+  if (h->two_pass && T <= 64 && T > 2) {
+    // the table kernel of step 0 already computes the weights of the first merge: it needs the per-row biases
+    Scope sc(h, st, PK_STEP_SMALL);
+    hipLaunchKernelGGL(k_beta_sum, dim3((unsigned)((B * T + 255) / 256)), dim3(256), 0, st, rs.beta_part, rs.ntile32,
+                       rs.ntile32, (float)C * scorer_ptrs(h).t0, base + w.beta_slot, B * T);
+  }
   size_t total = 0;
   for (int n = T; n >= 2; --n) total += (size_t)n * (n - 1) / 2;
   float* lg[2] = {base + w.logits0, base + w.logits1};
@@ -1312,7 +1318,7 @@ static int rollout_core(nnj_handle* h, const uint8_t* codes, const uint8_t* mask
   const bool use_cand = two_pass && h->two_pass_cand != 0;
   int* candbuf[2] = {reinterpret_cast<int*>(base + w.cand), reinterpret_cast<int*>(base + w.cand) + 2 * (size_t)B};
   bool prev_gave_am = false;                               // did the previous table kernel write am / need?
-  bool prev_lam = false, prev_v2 = false;
+  bool prev_lam = false, prev_v2 = false, prev_alpha0 = false;
   for (int step = 0, n = T; n >= 2; ++step, --n) {
     const int mode = step == 0 ? PAIRS_FULL : PAIRS_INCR;
     PairGeom g;
@@ -1322,8 +1328,8 @@ static int rollout_core(nnj_handle* h, const uint8_t* codes, const uint8_t* mask
       Step2 o;
       // without forced / sampled picks the pick of a step >= 1 of this kind is always covered (a new pair or the
       // candidate); the first such step follows a table whose kernels carry no logits
-      o.first = !prev_v2;
-      o.fallback = !prev_lam || forced != nullptr || uniforms != nullptr || !use_cand;
+      o.first = !prev_v2 && T > 64;                        // (up to 64 rows the biases were summed in front of step 0)
+      o.fallback = !(prev_lam || prev_alpha0) || forced != nullptr || uniforms != nullptr || !use_cand;
       o.cand = use_cand;
       o.cand_cur = candbuf[step & 1];
       if (int rc = launch_step2(h, rs, livebuf[(step + 1) & 1], ij, mask, base, w, o, n, B, C, g, st)) return rc;
@@ -1345,6 +1351,11 @@ static int rollout_core(nnj_handle* h, const uint8_t* codes, const uint8_t* mask
       so.cand_next = use_cand ? candbuf[(step + 1) & 1] : nullptr;
       so.cand_run = reinterpret_cast<int*>(base + w.cand_run);
       so.inv_scale = 1.0f / sqrtf(64.0f * (float)C);
+      if (mode == PAIRS_FULL && n <= 64 && n > 2) {          // step 0 on the 64-row kernels: the pick's logits are in alpha_part
+        so.alpha0 = base + w.alpha_part;
+        so.nsc0 = g.nsc_a;
+        so.ppad0 = g.ppad;
+      }
     }
     {
       Scope sc(h, st, PK_ASSEMBLE);                                                                 // :140-160
@@ -1358,6 +1369,7 @@ static int rollout_core(nnj_handle* h, const uint8_t* codes, const uint8_t* mask
     off += (size_t)n * (n - 1) / 2;
     prev_gave_am = next_v2;
     prev_lam = so.lam != nullptr;
+    prev_alpha0 = so.alpha0 != nullptr;
     prev_v2 = v2;
     if (n > 2 && !next_v2) {                                                                        // env.step :164
       if (int rc = launch_aggregate(h, rs, ij, base, w, S, base + w.U, base + w.Kp, base + w.beta, rs.bstride, T, 1, n,

@@ -914,6 +914,8 @@ struct StepOut {
   const float* acand_part;    // [B][nblk][64] logits of the candidate against the rows (k_step_alpha), or null
   int nblk;
   const int* cand_cur;        // [B][2] the candidate those logits belong to, positions of THIS table; (-1,-1) = none
+  const float* alpha0;        // step 0 (all pairs, <= 64 rows): k_pair_alpha's partials [B][nsc0][ppad0][64], or null
+  int nsc0, ppad0;
   float* am;                  // out [B][64]: weights of the merge just picked, by position AFTER it (0 at i)
   int* need;                  // out [B]: 1 = no source applied, the fallback kernels must compute `am`
   int* cand_next;             // out [B][2]: best entry of this table without rows i, j, by position after the merge
@@ -1109,6 +1111,19 @@ __global__ __launch_bounds__(256) void k_assemble_argmax(const float* __restrict
     qs = rs_ - (rs_ > ip ? 1 : 0);
   } else if (so.acand_part && so.cand_cur && so.cand_cur[2 * b] == pi_ && so.cand_cur[2 * b + 1] == pj_) {
     src = 2;
+  } else if (mode == PAIRS_FULL && so.alpha0) {
+    src = 3;                                               // step 0: every pair was scored in this step
+  }
+  if (src == 3) {
+    // the picked pair's logits: the partials of k_pair_alpha (x . K'_r: they differ from (A^T x) . S_r by a term that
+    // is the same for every r), four threads per row
+    const int r = tid & 63, part = tid >> 6;
+    const size_t pp = (size_t)pair_index(n, pi_, pj_);
+    float a = 0.f;
+    if (r < n)
+      for (int k = part; k < so.nsc0; k += 4) a += so.alpha0[(((size_t)b * so.nsc0 + k) * so.ppad0 + pp) * 64 + r];
+    pval[PCACHE - 256 + tid] = a;
+    __syncthreads();
   }
   if (src == 2) {
     // the candidate's logits: the partials of the k_step_alpha workgroups, four threads per row (every 4th block
@@ -1129,7 +1144,7 @@ __global__ __launch_bounds__(256) void k_assemble_argmax(const float* __restrict
     if (in) {
       float a;
       if (src == 1) a = so.lam[((size_t)b * 64 + qs) * 64 + (r - (r > ip ? 1 : 0))];
-      else a = ((pval[PCACHE - 256 + r] + pval[PCACHE - 192 + r]) + pval[PCACHE - 128 + r]) + pval[PCACHE - 64 + r];
+      else a = ((pval[PCACHE - 256 + r] + pval[PCACHE - 192 + r]) + pval[PCACHE - 128 + r]) + pval[PCACHE - 64 + r];   // src 2, 3
       v = (a + so.beta_slot[(size_t)b * so.nslot + live_cur[(size_t)b * live_stride + r]]) * so.inv_scale;
     }
     float mx = v;
