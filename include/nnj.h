@@ -266,9 +266,13 @@ int nnj_numeric_status(nnj_handle* h, int32_t* nonfinite_out, void* stream);
 /* Bits of the word nnj_numeric_status returns (0 = nothing to report).  NNJ_STATUS_BARRIER_TIMEOUT: kernels in
  * which two or more waves of a workgroup build one LDS image meet at LDS-counter barriers with a bounded spin; a
  * wave that gave up waiting (it never happens on a healthy device) computed on an incomplete image, so the results
- * since the last call must be discarded exactly like non-finite ones. */
+ * since the last call must be discarded exactly like non-finite ones.  NNJ_STATUS_MERGE_WEIGHTS: in a rollout the
+ * attention weights of a merge come from the scorer's own logits of the picked pair (two-pass NJ step);
+ * a pick for which neither source applied while the fallback pass was not scheduled is an internal error of the
+ * library, reported here instead of returning a tree built on zero weights. */
 #define NNJ_STATUS_NONFINITE 1
 #define NNJ_STATUS_BARRIER_TIMEOUT 2
+#define NNJ_STATUS_MERGE_WEIGHTS 4
 
 /* Kernel timing for bench.py's roofline object: when enabled, every kernel launch of
  * the entry points is bracketed by a HIP event pair on the launch stream, tagged with

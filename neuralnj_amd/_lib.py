@@ -362,6 +362,10 @@ class Nnj:
         before trusting merge lists fetched to the host."""
         flag = C.c_int32(0)
         self._chk(self.lib.nnj_numeric_status(self.h, C.byref(flag), self._stream()))
+        if flag.value & 4:
+            raise RuntimeError(
+                "two-pass NJ step: a merge had no source for its attention weights and no fallback was launched "
+                "(NNJ_FLAG_MERGE_WEIGHTS, an internal error): the results of this batch are invalid")
         if flag.value & 2:
             raise RuntimeError(
                 "a partner-wave barrier of a HIP kernel timed out (NNJ_STATUS_BARRIER_TIMEOUT): the results of "

@@ -1351,6 +1351,9 @@ static int rollout_core(nnj_handle* h, const uint8_t* codes, const uint8_t* mask
       so.cand_next = use_cand ? candbuf[(step + 1) & 1] : nullptr;
       so.cand_run = reinterpret_cast<int*>(base + w.cand_run);
       so.inv_scale = 1.0f / sqrtf(64.0f * (float)C);
+      // (the fallback kernels of the NEXT step: same condition as Step2::fallback there)
+      so.fallback = (!(((v2 && n > 2)) || (mode == PAIRS_FULL && n <= 64 && n > 2)) || forced != nullptr || uniforms != nullptr ||
+                     !use_cand) ? 1 : 0;
       if (mode == PAIRS_FULL && n <= 64 && n > 2) {          // step 0 on the 64-row kernels: the pick's logits are in alpha_part
         so.alpha0 = base + w.alpha_part;
         so.nsc0 = g.nsc_a;

@@ -27,6 +27,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // bits of the sticky per-handle status word (nnj_numeric_status)
 #define NNJ_FLAG_NONFINITE 1          // a pair-score table held a non-finite score
 #define NNJ_FLAG_BARRIER_TIMEOUT 2    // an LDS-counter barrier between partner waves gave up waiting
+#define NNJ_FLAG_MERGE_WEIGHTS 4      // two-pass step: a merge's attention weights had no source and no fallback was launched
 
 // compile-time loop: f(std::integral_constant<int, I>) for I in [0, N)
 template <int I, int N, typename F>

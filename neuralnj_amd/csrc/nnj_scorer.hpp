@@ -921,6 +921,8 @@ struct StepOut {
   int* cand_next;             // out [B][2]: best entry of this table without rows i, j, by position after the merge
   int* cand_run;              // out [B]: 1 = that pair is not the one whose x' row exists (k_pair_xp must run)
   float inv_scale;            // 1 / sqrt(64 C)
+  int fallback;               // 1 = the caller launches the fallback kernels where `need` is set; 0 = a pick without a
+                              // source is an internal error (sticky status bit NNJ_FLAG_MERGE_WEIGHTS: never silent)
 };
 
 // ------------------------------------------------------------------ table assemble + argmax
@@ -1157,7 +1159,10 @@ __global__ __launch_bounds__(256) void k_assemble_argmax(const float* __restrict
     so.am[(size_t)b * 64 + tid] = 0.f;
     __builtin_amdgcn_wave_barrier();
     if (in) so.am[(size_t)b * 64 + (r - (r > pj_ ? 1 : 0))] = se > 0.f ? e / se : 0.f;
-    if (tid == 0) so.need[b] = (src == 0 && n > 2) ? 1 : 0;
+    if (tid == 0) {
+      so.need[b] = (src == 0 && n > 2) ? 1 : 0;
+      if (src == 0 && n > 2 && !so.fallback && nonfinite) atomicOr(nonfinite, NNJ_FLAG_MERGE_WEIGHTS);
+    }
   }
   if (!so.cand_next) return;
   // best entry of this table that survives the merge (first maximal index: the order of the surviving pairs is the
