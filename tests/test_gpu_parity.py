@@ -245,6 +245,41 @@ def test_seeded_random_inputs_vs_oracle(ctx_cache):
         assert (merges[:, :, 1] < np.arange(T, 1, -1)[None, :]).all()
 
 
+@pytest.mark.parametrize("shape", [(3, 12, 40, 31), (2, 40, 72, 32), (1, 64, 48, 33), (2, 70, 32, 34)])
+def test_forced_random_merges_vs_oracle(shape, ctx_cache):
+    """Teacher-forcing along RANDOM merge lists (valid pairs that are almost never the argmax): in the two-pass NJ step
+    the attention weights of such a merge come from neither of the two sources the scorer provides (a pair of the last
+    step, the carried candidate) but from the per-alignment fallback kernels (k_pair_xp / k_agg_dot / k_agg_am) --
+    except where the random pick happens to be one of them, so the three routes are mixed inside one batch.  Tables
+    against the oracle along the same lists."""
+    B, T, L, seed = shape
+    cfgs = utils.shipped_config()
+    packed = weights.pack(cfgs, weights.seeded_state(cfgs, 21, "sharp"))
+    g = ctx_cache(cfgs, packed)
+    o = _oracle(cfgs, packed)
+    rng = np.random.default_rng(seed)
+    codes = synth.synth_codes_tree(B, T, L, seed)
+    mask = np.zeros((B, L), bool)
+    forced = np.zeros((B, T - 1, 2), np.int32)
+    for b in range(B):
+        for s_, n in enumerate(range(T, 1, -1)):
+            if s_ % 3 == 1 and s_ > 0:                       # every third step: merge the fresh row again (a "new pair")
+                i = int(forced[b, s_ - 1, 0])
+                j = int(rng.integers(0, n - 1))
+                j = j + 1 if j >= i else j
+                forced[b, s_] = sorted((min(i, n - 1), j)) if min(i, n - 1) != j else (0, 1)
+            else:
+                forced[b, s_] = sorted(rng.choice(n, 2, replace=False))
+    r = g.rollout_argmax(torch.from_numpy(codes), torch.from_numpy(mask), forced_merges=forced, want_trace=True)
+    g.check_numeric()
+    ref = o.rollout_argmax(synth.codes_to_onehot(codes).astype(np.float32), mask, forced_merges=forced)
+    assert_logits_close(r["logits"].cpu().numpy(), ref["logits"], RTOL, f"forced random merges {B}x{T}x{L}")
+    # (`merges` reports the model's own argmax at every forced state, as the oracle's does)
+    scale = np.abs(ref["logits"]).max()
+    decisive = ref["top2_gap"] > 4 * RTOL * scale
+    assert (ref["merges"][decisive] == r["merges"].cpu().numpy()[decisive]).all()
+
+
 @pytest.mark.parametrize("shape", [(2, 70, 64), (1, 100, 96), (1, 130, 40), (1, 200, 64), (1, 256, 32)])
 def test_wide_encoder_matches_oracle(shape, ctx_cache):
     """More than 64 alignment rows: k_tok1p with 4 / 8 waves per column (online softmax), k_row_pv over e-chunks."""
