@@ -118,11 +118,11 @@ size_t count_params(const nnj_config& c) {
 
 AttnW attn_ptrs(const nnj_handle* h, const size_t (&o)[10]) {
   const float* w = h->d_w;
-  return AttnW{w + o[0], w + o[1], w + o[2], w + o[3], w + o[4], w + o[5], w + o[6], w + o[7], w + o[8], w + o[9]};
+  return AttnW{w + o[0], w + o[1], w + o[2], w + o[3], w + o[4], w + o[5], w + o[6], w + o[7], w + o[8], w + o[9], h->cfg.embed_dim};
 }
 FfnW ffn_ptrs(const nnj_handle* h, const LayerOff& l) {
   const float* w = h->d_w;
-  return FfnW{w + l.W1, w + l.b1, w + l.W2, w + l.b2, w + l.ln_w, w + l.ln_b};
+  return FfnW{w + l.W1, w + l.b1, w + l.W2, w + l.b2, w + l.ln_w, w + l.ln_b, h->cfg.embed_dim};
 }
 ScorerW scorer_ptrs(const nnj_handle* h) {
   const float* w = h->d_w;
@@ -794,10 +794,56 @@ RowSet dense_rowset(nnj_handle* h, const float* state, float* base, const LoopWs
   return rs;
 }
 
+// ---- dense state tensors of a model narrower than 64 features (nnj_create): [.., embed_dim] at the C ABI, [.., 64] with
+// zero padding inside.  Two staging tensors of the workspace's whole-state size sit behind the regular workspace.
+__global__ void k_widen(const float* __restrict__ in, float* __restrict__ out, long ntok, int dt) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;                  // one float4 of the wide tensor
+  if (i >= ntok * 16) return;
+  const long tok = i >> 4; const int f = (int)(i & 15) * 4;
+  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+  if (f < dt) v = *reinterpret_cast<const f32x4*>(in + tok * dt + f);           // dt is a multiple of 8
+  *reinterpret_cast<f32x4*>(out + tok * 64 + f) = v;
+}
+__global__ void k_narrow(const float* __restrict__ in, float* __restrict__ out, long ntok, int dt) {
+  const int q = dt / 4;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;                  // one float4 of the narrow tensor
+  if (i >= ntok * q) return;
+  const long tok = i / q; const int f = (int)(i % q) * 4;
+  *reinterpret_cast<f32x4*>(out + tok * dt + f) = *reinterpret_cast<const f32x4*>(in + tok * 64 + f);
+}
+inline bool narrow_model(const nnj_handle* h) { return h->cfg.embed_dim != NNJ_D; }
+size_t wide_floats(int B, int T, int C) { return align_up((size_t)B * T * C * 64, 64); }
+size_t ws_floats_model(const nnj_handle* h, int B, int T, int C) {
+  return ws_floats(B, T, C) + (narrow_model(h) ? 2 * wide_floats(B, T, C) : 0);
+}
+// staging tensor k (0: inputs, 1: outputs) of a workspace laid out for (B, T, C)
+float* wide_buf(void* ws, int B, int T, int C, int k) {
+  return static_cast<float*>(ws) + ws_floats(B, T, C) + (size_t)k * wide_floats(B, T, C);
+}
+void widen_into(const nnj_handle* h, const float* in, float* out, long ntok, hipStream_t st) {
+  hipLaunchKernelGGL(k_widen, dim3((unsigned)((ntok * 16 + 255) / 256)), dim3(256), 0, st, in, out, ntok, h->cfg.embed_dim);
+}
+// the tensor the kernels read for a caller's dense input of ntok tokens
+const float* dense_in(const nnj_handle* h, const float* user, long ntok, void* ws, int B, int T, int C, hipStream_t st) {
+  if (!narrow_model(h)) return user;
+  float* w = wide_buf(ws, B, T, C, 0);
+  widen_into(h, user, w, ntok, st);
+  return w;
+}
+// the tensor the kernels write for a caller's dense output, and the copy that hands it over afterwards
+float* dense_out(const nnj_handle* h, float* user, void* ws, int B, int T, int C) {
+  return narrow_model(h) ? wide_buf(ws, B, T, C, 1) : user;
+}
+void dense_out_done(const nnj_handle* h, const float* wide, float* user, long ntok, hipStream_t st) {
+  if (!narrow_model(h)) return;
+  const long n4 = ntok * (h->cfg.embed_dim / 4);
+  hipLaunchKernelGGL(k_narrow, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, wide, user, ntok, h->cfg.embed_dim);
+}
+
 int need_ws(nnj_handle* h, void* ws, size_t ws_bytes, int B, int T, int C) {
   h->sess.valid = false;                 // every workspace user overwrites the regions a step session lives in
   if (!ws) return fail(h, NNJ_ERR_ARG, "workspace pointer is null");
-  const size_t need = ws_floats(B, T, C) * sizeof(float);
+  const size_t need = ws_floats_model(h, B, T, C) * sizeof(float);
   if (ws_bytes < need) return fail(h, NNJ_ERR_WORKSPACE, "workspace too small: %zu < %zu bytes", ws_bytes, need);
   if ((uintptr_t)ws % 256) return fail(h, NNJ_ERR_ARG, "workspace must be 256-byte aligned");
   return NNJ_OK;
@@ -846,7 +892,8 @@ SessView sess_view(void* ws, int B, int T0, int C) {
 }
 // start a session from a dense tensor of T0 rows: copy into the slots, identity live list, row transforms
 int sess_begin(nnj_handle* h, const SessView& v, const float* state, int B, int T0, int C, hipStream_t st) {
-  HIPCHK(h, hipMemcpyAsync(v.S, state, (size_t)B * T0 * C * 64 * sizeof(float), hipMemcpyDeviceToDevice, st));
+  if (narrow_model(h)) widen_into(h, state, v.S, (long)B * T0 * C, st);
+  else HIPCHK(h, hipMemcpyAsync(v.S, state, (size_t)B * T0 * C * 64 * sizeof(float), hipMemcpyDeviceToDevice, st));
   {
     Scope sc(h, st, PK_MISC);
     hipLaunchKernelGGL(k_init_live, dim3((unsigned)((B * T0 + 255) / 256)), dim3(256), 0, st, v.live, T0, B, T0);
@@ -875,6 +922,38 @@ int ready(nnj_handle* h) {
 
 }  // namespace
 
+// A model of embed_dim Dt < 64 (heads of 8 features) as a 64-feature model: every matrix and vector of the packed weights
+// zero-padded.  Exact: padded features are zero in every tensor of the path (a Linear's padded outputs are 0 + bias 0,
+// GELU(0) = 0, the gates mix 0 with 0, LayerNorm leaves them out of its statistics -- layer_norm64 -- and scales them by
+// gamma = 0); the padded heads attend uniformly over values that are zero.  The one place the width itself enters is the
+// scale of the aggregate's logits, 1 / sqrt(embed_dim * patch_num) (model.py:110): the kernels divide by sqrt(64 * patch_num),
+// so g_attn_q (weight and bias) carries sqrt(64 / Dt).
+void pad_weights(const nnj_config& c, const float* p, std::vector<float>& out) {
+  nnj_config c64 = c;
+  c64.embed_dim = NNJ_D; c64.num_heads = NNJ_NHEAD;
+  out.assign(count_params(c64), 0.f);
+  const size_t Dt = c.embed_dim, Ft = 4 * Dt, D = NNJ_D, F = NNJ_F, K4 = 4 * (size_t)c.patch_size;
+  size_t src = 0, dst = 0;
+  auto mat = [&](size_t rt, size_t ct, size_t rp, size_t cp, double f = 1.0) {
+    for (size_t r = 0; r < rt; ++r)
+      for (size_t q = 0; q < ct; ++q) out[dst + r * cp + q] = (float)(f * (double)p[src + r * ct + q]);
+    src += rt * ct; dst += rp * cp;
+  };
+  auto lin = [&](double f = 1.0) { mat(Dt, Dt, D, D, f); mat(1, Dt, 1, D, f); };
+  for (int l = 0; l < c.num_layers; ++l) {
+    for (int a = 0; a < 2; ++a) {
+      for (int k = 0; k < 4; ++k) lin();
+      mat(1, Dt, 1, D); mat(1, Dt, 1, D);
+    }
+    mat(Ft, Dt, F, D); mat(1, Ft, 1, F); mat(Dt, Ft, D, F); mat(1, Dt, 1, D); mat(1, Dt, 1, D); mat(1, Dt, 1, D);
+  }
+  mat(Dt, K4, D, K4); mat(1, Dt, 1, D); lin();             // embed
+  lin(); lin();                                             // h_linear_last, g_linear_last
+  lin(sqrt((double)D / (double)Dt));                        // g_attn_q
+  lin();                                                    // g_attn_k
+  lin(); mat(1, Dt, 1, D); mat(1, 1, 1, 1);                 // s_out
+}
+
 // ====================================================================== C ABI
 extern "C" {
 
@@ -888,10 +967,13 @@ int nnj_num_params(const nnj_config* cfg, size_t* n) {
 
 int nnj_create(const nnj_config* cfg, nnj_handle** out) {
   if (!cfg || !out) return fail(nullptr, NNJ_ERR_ARG, "nnj_create: null argument");
-  if (cfg->embed_dim != NNJ_D || cfg->num_heads != NNJ_NHEAD || cfg->patch_size < 1 || cfg->patch_size > 16 ||
-      cfg->vocab_size != 4 || cfg->num_layers < 0)
+  // embed_dim: 64 natively; a narrower model (a multiple of 8 with heads of 8 features, e.g. the reference's own defaults
+  // utils.py:45-52: 32 features, 4 heads) runs on the same kernels zero-padded to 64 features / 8 heads (nnj_load_weights)
+  if (cfg->embed_dim < 8 || cfg->embed_dim > NNJ_D || cfg->embed_dim % 8 || cfg->num_heads * NNJ_DH != cfg->embed_dim ||
+      cfg->patch_size < 1 || cfg->patch_size > 16 || cfg->vocab_size != 4 || cfg->num_layers < 0)
     return fail(nullptr, NNJ_ERR_UNSUPPORTED,
-                "this build covers embed_dim=64, num_enc_heads=8, patch_size 1..16, vocab_size=4 (got %d,%d,%d,%d)",
+                "this build covers embed_dim 8..64 (multiples of 8) with num_enc_heads = embed_dim / 8, patch_size 1..16, "
+                "vocab_size=4 (got %d,%d,%d,%d)",
                 cfg->embed_dim, cfg->num_heads, cfg->patch_size, cfg->vocab_size);
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
@@ -936,11 +1018,17 @@ const char* nnj_last_error(const nnj_handle* h) { return h ? h->err : g_err; }
 
 int nnj_load_weights(nnj_handle* h, const float* p, size_t n) {
   if (!h || !p) return fail(h, NNJ_ERR_ARG, "nnj_load_weights: null argument");
-  const size_t need = count_params(h->cfg);
+  size_t need = count_params(h->cfg);
   if (n != need) return fail(h, NNJ_ERR_ARG, "nnj_load_weights: got %zu floats, config needs %zu", n, need);
   DevGuard dev_guard;
   HIPCHK(h, hipSetDevice(h->cfg.device));
   const size_t D = NNJ_D, F = NNJ_F;
+  std::vector<float> widened;
+  if (h->cfg.embed_dim != NNJ_D) {           // a narrower model: every tensor zero-padded into the 64-feature layout
+    pad_weights(h->cfg, p, widened);
+    p = widened.data();
+    need = widened.size();
+  }
   size_t o = 0;
   auto take = [&](size_t k) { size_t r = o; o += k; return r; };
   h->lo.assign(h->cfg.num_layers, LayerOff());
@@ -1032,7 +1120,7 @@ int nnj_workspace_bytes(const nnj_handle* h, int32_t B, int32_t T, int32_t L_sit
   if (!h || !bytes || B <= 0 || T < 1 || L_sites <= 0) return fail(const_cast<nnj_handle*>(h), NNJ_ERR_ARG, "nnj_workspace_bytes: bad argument");
   int32_t L = 0;
   if (int rc = to_tokens(const_cast<nnj_handle*>(h), L_sites, &L)) return rc;
-  *bytes = ws_floats(B, T, L) * sizeof(float);
+  *bytes = ws_floats_model(h, B, T, L) * sizeof(float);
   return NNJ_OK;
 }
 
@@ -1049,7 +1137,11 @@ int nnj_encode(nnj_handle* h, const uint8_t* codes, const float* onehot, const u
   if (int rc = token_mask(h, &mask, ws, B, T, L, static_cast<hipStream_t>(stream))) return rc;
   float* base = static_cast<float*>(ws);
   const size_t state = align_up((size_t)B * T * L * 64, 64);
-  return run_encoder(h, codes, mask, state_out, base + state, B, T, L, static_cast<hipStream_t>(stream), onehot);
+  float* x = dense_out(h, state_out, ws, B, T, L);
+  if (int rc = run_encoder(h, codes, mask, x, base + state, B, T, L, static_cast<hipStream_t>(stream), onehot)) return rc;
+  dense_out_done(h, x, state_out, (long)B * T * L, static_cast<hipStream_t>(stream));
+  HIPCHK(h, hipGetLastError());
+  return NNJ_OK;
 }
 
 int nnj_pair_scores_full(nnj_handle* h, const float* state, const uint8_t* mask, float* logits_out, int32_t B,
@@ -1099,7 +1191,7 @@ int nnj_pair_scores_incr(nnj_handle* h, const float* state, const uint8_t* mask,
   PairGeom g;
   const SessView v = sess_view(ws, B, T0, L);
   RowSet rs = v.rs;
-  if (!cont) rs = dense_rowset(h, state, v.base, v.w, B, n, L, st);
+  if (!cont) rs = dense_rowset(h, dense_in(h, state, (long)B * n * L, ws, B, T0, L, st), v.base, v.w, B, n, L, st);
   if (int rc = scorer_mask(h, mask, v.base, v.w, B, L, st, &mask)) return rc;
   if (int rc = launch_pair_scores(h, rs, ij_prev, mask, v.base, v.w, PAIRS_INCR, n, B, L, g, st)) return rc;
   {
@@ -1140,8 +1232,10 @@ int nnj_aggregate(nnj_handle* h, const float* state, const int32_t* ij, float* o
   if (int rc = need_ws(h, ws, ws_bytes, B, T0, L)) return rc;
   const SessView v = sess_view(ws, B, T0, L);
   RowSet rs = v.rs;
-  if (!cont) rs = dense_rowset(h, state, v.base, v.w, B, n, L, st);
-  if (int rc = launch_aggregate(h, rs, ij, v.base, v.w, out_row, nullptr, nullptr, nullptr, (long)L * 64, 1, 0, n, B, L, st)) return rc;
+  if (!cont) rs = dense_rowset(h, dense_in(h, state, (long)B * n * L, ws, B, T0, L, st), v.base, v.w, B, n, L, st);
+  float* orow = dense_out(h, out_row, ws, B, T0, L);
+  if (int rc = launch_aggregate(h, rs, ij, v.base, v.w, orow, nullptr, nullptr, nullptr, (long)L * 64, 1, 0, n, B, L, st)) return rc;
+  dense_out_done(h, orow, out_row, (long)B * L, st);
   HIPCHK(h, hipGetLastError());
   if (cont) sess_set(h, ws, state, B, T0, L, n);           // the rows are untouched: the session goes on
   return NNJ_OK;
@@ -1168,20 +1262,25 @@ int nnj_env_step(nnj_handle* h, const float* state, const int32_t* ij, float* st
                                   v.rs.bstride, T0, 1, n, B, L, st)) return rc;
     Scope sc(h, st, PK_MISC);
     hipLaunchKernelGGL(k_update_live, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, st, v.live, T0, (const int*)v.ijs, B, n);
+    float* so = dense_out(h, state_out, ws, B, T0, L);
     hipLaunchKernelGGL(k_gather_rows, dim3(16, (unsigned)(n - 1), (unsigned)B), dim3(256), 0, st, (const float*)v.S,
-                       (const int*)v.live, T0, state_out, n - 1, (long)L * 16, (long)T0 * L * 16);
+                       (const int*)v.live, T0, so, n - 1, (long)L * 16, (long)T0 * L * 16);
+    dense_out_done(h, so, state_out, (long)B * (n - 1) * L, st);
     HIPCHK(h, hipGetLastError());
     sess_set(h, ws, state_out, B, T0, L, n - 1);
     return NNJ_OK;
   }
-  RowSet rs = dense_rowset(h, state, v.base, v.w, B, n, L, st);
+  const float* state_w = dense_in(h, state, (long)B * n * L, ws, B, T0, L, st);
+  RowSet rs = dense_rowset(h, state_w, v.base, v.w, B, n, L, st);
   float* merged = v.base + v.w.merged;
   if (int rc = launch_aggregate(h, rs, ij, v.base, v.w, merged, nullptr, nullptr, nullptr, (long)L * 64, 1, 0, n, B, L, st)) return rc;
   {
     Scope sc(h, st, PK_MISC);
     const long row_f4 = (long)L * 16;
-    hipLaunchKernelGGL(k_compact_rows, dim3(16, (unsigned)(n - 1), (unsigned)B), dim3(256), 0, st, state, merged, ij,
-                       state_out, n, row_f4);
+    float* so = dense_out(h, state_out, ws, B, T0, L);
+    hipLaunchKernelGGL(k_compact_rows, dim3(16, (unsigned)(n - 1), (unsigned)B), dim3(256), 0, st, state_w, merged, ij,
+                       so, n, row_f4);
+    dense_out_done(h, so, state_out, (long)B * (n - 1) * L, st);
   }
   HIPCHK(h, hipGetLastError());
   return NNJ_OK;
@@ -1261,8 +1360,10 @@ int nnj_step(nnj_handle* h, const float* state, const uint8_t* mask, const int32
   }
   {
     Scope sc(h, st, PK_MISC);
+    float* so = dense_out(h, state_out, ws, B, T0, C);
     hipLaunchKernelGGL(k_gather_rows, dim3(16, (unsigned)n, (unsigned)B), dim3(256), 0, st, (const float*)S, (const int*)live,
-                       T0, state_out, n, (long)C * 16, (long)T0 * C * 16);
+                       T0, so, n, (long)C * 16, (long)T0 * C * 16);
+    dense_out_done(h, so, state_out, (long)B * n * C, st);
   }
   HIPCHK(h, hipGetLastError());
   sess_set(h, ws, state_out, B, T0, L, n);
@@ -1288,7 +1389,8 @@ static int rollout_core(nnj_handle* h, const uint8_t* codes, const uint8_t* mask
       mask = mrep;
     }
   }
-  if (state_out) HIPCHK(h, hipMemcpyAsync(state_out, S, (size_t)B * T * C * 64 * sizeof(float), hipMemcpyDeviceToDevice, st));
+  if (state_out && narrow_model(h)) dense_out_done(h, S, state_out, (long)B * T * C, st);
+  else if (state_out) HIPCHK(h, hipMemcpyAsync(state_out, S, (size_t)B * T * C * 64 * sizeof(float), hipMemcpyDeviceToDevice, st));
   if (int rc = scorer_mask(h, mask, base, w, B, C, st, &mask)) return rc;      // (after the encoder: the region is its scratch)
   // two live lists: k_assemble_argmax writes the next step's list (without position j) beside the one the merged-row
   // kernels of this step still read
@@ -1478,7 +1580,7 @@ static int rollout_impl(nnj_handle* h, const uint8_t* codes, const uint8_t* mask
                               uniforms ? uniforms + (size_t)b0 * (T - 1) : nullptr, inv_temp,
                               merges_out + (size_t)b0 * (T - 1) * 2, trace ? trace + (size_t)b0 * total : nullptr,
                               gap ? gap + (size_t)b0 * (T - 1) : nullptr,
-                              state_out ? state_out + (size_t)b0 * T * L * 64 : nullptr,
+                              state_out ? state_out + (size_t)b0 * T * L * h->cfg.embed_dim : nullptr,
                               static_cast<float*>(ws) + (size_t)k * sub_floats, h->sub[k])) return rc;
     HIPCHK(h, hipEventRecord(h->ev_join[k], h->sub[k]));
     HIPCHK(h, hipStreamWaitEvent(st, h->ev_join[k], 0));

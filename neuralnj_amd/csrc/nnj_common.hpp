@@ -724,22 +724,28 @@ __device__ __forceinline__ void linear_t16p(f32x4 (&out)[MT], const V64& in, con
   });
 }
 
-// layer norm of a V64 (the four lanes of a token hold 16 features each)
-__device__ __forceinline__ void layer_norm_v64(V64& y, const V64& x, const float* gamma, const float* beta, int kq) {
+// layer norm of a V64 (the four lanes of a token hold 16 features each).
+// dt = the model's embed_dim (a multiple of 8, <= 64): a narrower model runs on these 64-feature kernels with its
+// tensors zero-padded (nnj_load_weights); the statistics are the ones of its dt features -- the padding adds nothing to the
+// sum and is left out of the variance -- and gamma = beta = 0 there keeps the padded features at zero.  dt = 64: as before.
+__device__ __forceinline__ void layer_norm_v64(V64& y, const V64& x, const float* gamma, const float* beta, int kq, int dt) {
   float s = 0.f;
 #pragma unroll
   for (int mt = 0; mt < 4; ++mt) s += (x.t[mt][0] + x.t[mt][1]) + (x.t[mt][2] + x.t[mt][3]);
   s += __shfl_xor(s, 16);
   s += __shfl_xor(s, 32);
-  const float mean = s * (1.0f / 64.0f);
+  const float inv_d = 1.0f / (float)dt;
+  const float mean = s * inv_d;
   float v = 0.f;
 #pragma unroll
-  for (int mt = 0; mt < 4; ++mt)
+  for (int mt = 0; mt < 4; ++mt) {
+    const bool in = 16 * mt + 4 * kq < dt;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) { const float d = x.t[mt][e] - mean; v += d * d; }
+    for (int e = 0; e < 4; ++e) { const float d = x.t[mt][e] - mean; v += in ? d * d : 0.f; }
+  }
   v += __shfl_xor(v, 16);
   v += __shfl_xor(v, 32);
-  const float inv = nnj_rsqrt(v * (1.0f / 64.0f) + 1e-5f);
+  const float inv = nnj_rsqrt(v * inv_d + 1e-5f);
 #pragma unroll
   for (int mt = 0; mt < 4; ++mt) {
     const f32x4 gm = *reinterpret_cast<const f32x4*>(gamma + 16 * mt + 4 * kq);
@@ -774,24 +780,29 @@ __device__ __forceinline__ void store_token64(const f32x16 (&a)[2], float* p, bo
     }
 }
 
-// LayerNorm over the 64 features of the lane's token (eps 1e-5, biased variance);
-// gamma/beta readable with 16-byte loads.
+// LayerNorm over the features of the lane's token (eps 1e-5, biased variance); gamma/beta readable with 16-byte loads.
+// dt: see layer_norm_v64.
 __device__ __forceinline__ void layer_norm64(f32x16 (&y)[2], const f32x16 (&x)[2],
-                                             const float* gamma, const float* beta, int hh) {
+                                             const float* gamma, const float* beta, int hh, int dt) {
   float s = 0.f;
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
     for (int r = 0; r < 16; ++r) s += x[mt][r];
   s += __shfl_xor(s, 32);
-  const float mean = s * (1.0f / 64.0f);
+  const float inv_d = 1.0f / (float)dt;
+  const float mean = s * inv_d;
   float v = 0.f;
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { const float d = x[mt][r] - mean; v += d * d; }
+    for (int g = 0; g < 4; ++g) {
+      const bool in = 32 * mt + 8 * g < dt;               // features 32 mt + 8 g + 4 hh + t (dt is a multiple of 8)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) { const float d = x[mt][4 * g + t] - mean; v += in ? d * d : 0.f; }
+    }
   v += __shfl_xor(v, 32);
-  const float inv = nnj_rsqrt(v * (1.0f / 64.0f) + 1e-5f);
+  const float inv = nnj_rsqrt(v * inv_d + 1e-5f);
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt)
 #pragma unroll

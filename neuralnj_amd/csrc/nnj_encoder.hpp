@@ -17,9 +17,11 @@
 
 struct AttnW {            // pointers into the packed device weights (row-major [out][in])
   const float *Wk, *bk, *Wv, *bv, *Wq, *bq, *Wo, *bo, *ln_w, *ln_b;
+  int dt;                 // the model's embed_dim (<= 64; narrower models run zero-padded, see layer_norm64)
 };
 struct FfnW {
   const float *W1, *b1, *W2, *b2, *ln_w, *ln_b;
+  int dt;
 };
 struct EmbedW {           // embed = Linear(4 K -> 64), GELU, Linear(64 -> 64)  (reference model.py:39-43; K = patch_size)
   const float *E0, *e0, *E2, *e2;
@@ -238,7 +240,7 @@ __global__ __launch_bounds__(512) void k_tok1p(const float* __restrict__ ctx, co
       f32x16 qh, kh, vT;
       {
         f32x16 y[2];
-        layer_norm64(y, xr[0], ct + 64, ct + 128, hh);
+        layer_norm64(y, xr[0], ct + 64, ct + 128, hh, wc.dt);
         const float bvl = ct[320 + 32 * hf + tok];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -482,7 +484,7 @@ __global__ __launch_bounds__(1024) void k_ffn16(float* __restrict__ x, FfnW wf, 
     asm volatile("" ::: "memory");          // keep the parameter loads inside the loop (hoisted, they would occupy ~200 VGPRs)
     V64 xr, y, out;
     load_v64(xr, xp, kq);
-    layer_norm_v64(y, xr, cf, cf + 64, kq);
+    layer_norm_v64(y, xr, cf, cf + 64, kq, wf.dt);
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) out.t[mt] = *reinterpret_cast<const f32x4*>(cf + 128 + 16 * mt + 4 * kq);
     // y is split ONCE (inside the loop it was split again for each of the four hidden blocks); both products read

@@ -125,7 +125,7 @@ __global__ __launch_bounds__(512) void k_qkv6(const float* __restrict__ x, const
     const bool valid = tile_ok && r < R && c < C;
     asm volatile("" ::: "memory");      // keep the parameter loads inside the loop (hoisted, they would occupy ~200 VGPRs)
     f32x16 y[1][2], o[1][6];
-    layer_norm64(y[0], xr, cq, cq + 64, hh);
+    layer_norm64(y[0], xr, cq, cq + 64, hh, wn.dt);
     // the next group's tokens go into the registers LayerNorm has just consumed: their HBM latency runs
     // behind the GEMM and the stores
     if (grp + (int)gridDim.x < ngroups) load_token64(xr, tok_addr(grp + gridDim.x), true, hh);

@@ -170,47 +170,52 @@ class PhyInferEnv:
         acts = actions.tolist() if hasattr(actions, "tolist") else list(actions)
         ij = [pairs[int(a)] for a in acts]
         self._merge_log.append(ij)
-        done = False
+        done = n == 2
+        if not done:
+            # The tensor half (reference environment.py:760-835) is queued on the device FIRST: it needs the pairs only,
+            # and the tree half below (Python objects, about a millisecond per step at a batch of 256) then runs on the
+            # host while the device works -- the reference does the two in the other order and its GPU waits.
+            self._step_device(ij, n, agent)
         for b, (i, j) in enumerate(ij):
-            done = self._merge_host(b, i, j)
+            self._merge_host(b, i, j)
         if done and branch_optimize:
             # The reference scores the finished trees here with raxml-ng (optimize_branch_length_*, environment.py:
             # 625-672: branch lengths optimised, log-likelihood under GTR+I+G).  Same place, on the GPU: the merge lists
             # of the batch go through nnj_tree_optimize (likelihood.py; default model parameters, not optimised) and
             # the trees are rebuilt with their branch lengths and scores.
             self._score_finished_trees(agent)
-        if not done:
-            # tensor half (reference environment.py:760-835) on the device
-            if agent is None:
-                raise NotImplementedError("the mean-aggregate fallback (agent=None) is not part of the hot path")
-            dev = self.state_tensor.device
-            if hasattr(agent, "_wants_grad") and agent._wants_grad():
-                from . import utils
-                ij_t = utils.upload(ij, torch.long, dev)          # no wait for the queued device work (utils.upload)
-                # Finetune mode: the same step with gradients (train_model.env_step: differentiable gathers,
-                # aggregate, concatenation)
-                from . import train_model
-                self.state_tensor = train_model.env_step(agent, self.state_tensor, ij_t)
-                return done
-            ij_t = torch.tensor(ij, dtype=torch.long, device=dev)
-            if hasattr(agent, "_context") and getattr(agent, "batch_input", None) is self.state_tensor:
-                # this package's PhyloATTN: aggregate + compaction as ONE device call (nnj_env_step).  When the state
-                # is the tensor the preceding decode_zxr scored, the library continues its session: merged row in
-                # place, no row transformed again, one gather for the dense tensor returned here (include/nnj.h,
-                # "Sessions") -- instead of aggregate + cat + gather, i.e. two copies of the whole state per step
-                self.state_tensor = agent._context().env_step(self.state_tensor, ij_t)
-                return done
-            new = agent.aggregate(None, None, (ij_t[:, 0], ij_t[:, 1]), batchwise_ij_indices=True)
-            base = []
-            for (i, j) in ij:
-                idx = list(range(n))
-                idx[i] = n
-                idx.pop(j)
-                base.append(idx)
-            base = torch.tensor(base, dtype=torch.long, device=dev)
-            cat = torch.cat((self.state_tensor, new), dim=1)
-            self.state_tensor = torch.gather(cat, 1, base[:, :, None, None].expand(-1, -1, cat.size(2), cat.size(3)))
         return done
+
+    def _step_device(self, ij, n, agent):
+        """env.step's tensor half: rows i and j of every alignment aggregated into position i, position j dropped."""
+        if agent is None:
+            raise NotImplementedError("the mean-aggregate fallback (agent=None) is not part of the hot path")
+        from . import utils
+        dev = self.state_tensor.device
+        ij_t = utils.upload(ij, torch.long, dev)              # no wait for the queued device work (utils.upload)
+        if hasattr(agent, "_wants_grad") and agent._wants_grad():
+            # Finetune mode: the same step with gradients (train_model.env_step: differentiable gathers,
+            # aggregate, concatenation)
+            from . import train_model
+            self.state_tensor = train_model.env_step(agent, self.state_tensor, ij_t)
+            return
+        if hasattr(agent, "_context") and getattr(agent, "batch_input", None) is self.state_tensor:
+            # this package's PhyloATTN: aggregate + compaction as ONE device call (nnj_env_step).  When the state
+            # is the tensor the preceding decode_zxr scored, the library continues its session: merged row in
+            # place, no row transformed again, one gather for the dense tensor returned here (include/nnj.h,
+            # "Sessions") -- instead of aggregate + cat + gather, i.e. two copies of the whole state per step
+            self.state_tensor = agent._context().env_step(self.state_tensor, ij_t)
+            return
+        new = agent.aggregate(None, None, (ij_t[:, 0], ij_t[:, 1]), batchwise_ij_indices=True)
+        base = []
+        for (i, j) in ij:
+            idx = list(range(n))
+            idx[i] = n
+            idx.pop(j)
+            base.append(idx)
+        base = utils.upload(base, torch.long, dev)
+        cat = torch.cat((self.state_tensor, new), dim=1)
+        self.state_tensor = torch.gather(cat, 1, base[:, :, None, None].expand(-1, -1, cat.size(2), cat.size(3)))
 
     def _score_finished_trees(self, agent):
         if agent is None or not hasattr(agent, "_context"):

@@ -27,14 +27,19 @@ def reinforce_rollout_argmax(batch, agent, env, device=None):
         env.state_tensor = agent.encode_zxr(env.init_state_tensor, mask)
         while True:
             B, n = env.state_tensor.shape[:2]
-            idx = None
-            if ij_prev is not None:
-                idx = torch.from_numpy(np.array(utils.get_score_indices_to_prev(ij_prev, env, n, B))).to(device)
-            logits = agent.decode_zxr(env.state_tensor, mask, (ij_prev, idx, logits_prev))["logits"]
+            # The reference computes the old->new table map on the host here (utils.get_score_indices_to_prev,
+            # finetune_rl_search.py:121-123) and hands it to decode_zxr.  This package's decode_zxr derives the same map
+            # on the device from ij_prev (nnj_score_index_map) and ignores the argument, so the host copy -- 2 ms and a
+            # blocking 2.5 MB upload per step at a batch of 256 -- is not built; utils.get_score_indices_to_prev stays
+            # available for callers that want it (tests/test_host.py pins it to the reference's).
+            logits = agent.decode_zxr(env.state_tensor, mask, (ij_prev, None, logits_prev))["logits"]
             actions = torch.argmax(logits, dim=-1)
-            ij = [env.tree_pairs_dict[n][a.item()] for a in actions]
+            # ONE device->host copy per step for the whole batch (the reference reads the actions element by element,
+            # finetune_rl_search.py:159-160: 256 synchronising .item() calls per step were 64 % of this loop's host time)
+            pairs = env.tree_pairs_dict[n]
+            ij = [pairs[a] for a in actions.tolist()]
             merges.append(ij)
-            ij_prev = torch.tensor(ij, dtype=torch.int32, device=device)
+            ij_prev = utils.upload(ij, torch.int32, device)
             if env.step(actions, [(None, None)] * B, branch_optimize=False, agent=agent):
                 break
             logits_prev = logits

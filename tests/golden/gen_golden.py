@@ -85,7 +85,7 @@ def make_cfg(utils_mod, layers=6):
     return cfgs
 
 
-def run_case(name, codes, mask, wseed, style, ref, keys=None, layers=6, capture_layers=False, patch=1):
+def run_case(name, codes, mask, wseed, style, ref, keys=None, layers=6, capture_layers=False, patch=1, dim=64, heads=8):
     """codes uint8 [B,T,L]; mask bool [B,L] (True = padded site)."""
     import torch
     from neuralnj_amd import synth, weights
@@ -94,6 +94,8 @@ def run_case(name, codes, mask, wseed, style, ref, keys=None, layers=6, capture_
     torch.manual_seed(0)
     cfgs = make_cfg(utils_mod, layers)
     cfgs.model.patch_size = patch
+    cfgs.model.embed_dim = dim
+    cfgs.model.num_enc_heads = heads
     agent = PGPI(cfgs)
     st = weights.seeded_state(cfgs, wseed, style)
     agent.load_state_dict({k: torch.from_numpy(v) for k, v in st.items()}, strict=True)
@@ -177,7 +179,7 @@ def run_case(name, codes, mask, wseed, style, ref, keys=None, layers=6, capture_
 
     out = dict(
         codes=codes, mask=mask, wseed=np.int64(wseed), style=np.array(style),
-        layers=np.int64(layers), patch=np.int64(patch), weights_sha256=np.array(weights.digest(packed)),
+        layers=np.int64(layers), patch=np.int64(patch), dim=np.int64(dim), heads=np.int64(heads), weights_sha256=np.array(weights.digest(packed)),
         merges=merges, logits=logits, logits_offsets=offs, top2_gap=gaps,
         newick=np.array(newick), topo=np.array(topo), best_tree=np.array(best_tree),
         keys=np.array(keys),
@@ -343,6 +345,27 @@ def main():
         codes = synth.synth_codes(1, 12, 96, 2018, gap_frac=0.2)
         run_case("patch2_b1_t12_l96_s18", codes, np.zeros((1, 96), dtype=bool), 18, "plain", ref, patch=2)
     add("patch2_b1_t12_l96_s18", patch2_mid)
+
+    # embed_dim < 64: the reference's own default shape (utils.py:45-52: patch 4, 32 features, 4 heads, 3 layers) and the
+    # same width at patch 1 with a padded tail; the HIP kernels run such a model zero-padded to 64 features
+    def dim32_default():
+        codes = synth.synth_codes_tree(2, 10, 256, 1019)
+        mask = np.zeros((2, 256), dtype=bool)
+        run_case("dim32_b2_t10_l256_s19", codes, mask, 19, "sharp", ref, layers=3, patch=4, dim=32, heads=4)
+    add("dim32_b2_t10_l256_s19", dim32_default)
+
+    def dim32_patch1():
+        codes = synth.synth_codes_tree(1, 20, 160, 1020)
+        codes[:, :, 148:] = 5
+        mask = np.zeros((1, 160), dtype=bool)
+        mask[:, 148:] = True
+        run_case("dim32_b1_t20_l160_s20", codes, mask, 20, "plain", ref, layers=3, patch=1, dim=32, heads=4)
+    add("dim32_b1_t20_l160_s20", dim32_patch1)
+
+    def dim16_small():
+        codes = synth.synth_codes_tree(1, 9, 96, 1021)
+        run_case("dim16_b1_t9_l96_s21", codes, np.zeros((1, 96), dtype=bool), 21, "sharp", ref, layers=2, patch=2, dim=16, heads=2)
+    add("dim16_b1_t9_l96_s21", dim16_small)
 
     def wide_70():
         codes = synth.synth_codes_tree(2, 70, 64, 2012)

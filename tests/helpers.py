@@ -33,6 +33,9 @@ def load_golden(name):
     cfgs.model.num_enc_layers = int(z["layers"])
     if "patch" in z.files:
         cfgs.model.patch_size = int(z["patch"])
+    if "dim" in z.files:                                    # narrower models (zero-padded to 64 features by the library)
+        cfgs.model.embed_dim = int(z["dim"])
+        cfgs.model.num_enc_heads = int(z["heads"])
     st = weights.seeded_state(cfgs, int(z["wseed"]), str(z["style"]))
     packed = weights.pack(cfgs, st)
     assert weights.digest(packed) == str(z["weights_sha256"]), "seeded weights drifted from the fixture"

@@ -173,7 +173,10 @@ def test_encoder_taps_match_oracle(name, ctx_cache):
 
 
 @pytest.mark.parametrize("name", ["synth_b2_t8_l128_s1", "padded_b2_t8_l128_s3", "plain_b1_t12_l96_s4",
-                                  "synth_b1_t20_l256_s1", "synth_b2_t70_l64_s12", "patch4_b2_t8_l128_s16"])
+                                  "synth_b1_t20_l256_s1", "synth_b2_t70_l64_s12", "patch4_b2_t8_l128_s16",
+                                  # embed_dim 32 / 16 (zero-padded to the kernels' 64 features): dense tensors of the
+                                  # model's own width at every entry point
+                                  "dim32_b2_t10_l256_s19", "dim32_b1_t20_l160_s20", "dim16_b1_t9_l96_s21"])
 def test_entry_points_match_oracle_step_by_step(name, ctx_cache):
     """The reference's call sequence (decode_zxr / argmax / env.step) through the separate
     C-ABI entry points, each compared with the oracle on the same inputs."""
@@ -548,6 +551,50 @@ def test_model_env_api_follows_reference_call_sequence():
     a = agent._context().encode_onehot(onehot, None)
     b = agent._context().encode(torch.from_numpy(z["codes"]), None)
     np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), atol=2e-5)   # LUT path == MLP path
+
+
+def test_reference_default_shape_through_the_model_api():
+    """The reference's own default model shape (utils.py:45-52: patch 4, 32 features, 4 heads, 3 layers) through
+    model.PhyloATTN / environment.PhyInferEnv and through the fused step API: merge list, Newick string and tables of
+    the reference's golden run."""
+    from neuralnj_amd.environment import PhyInferEnv
+    from neuralnj_amd.model import PhyloATTN
+    from neuralnj_amd.rollout import argmax_rollout, reinforce_rollout_argmax
+    z, cfgs, packed = load_golden("dim32_b2_t10_l256_s19")
+    assert (cfgs.model.embed_dim, cfgs.model.num_enc_heads, cfgs.model.patch_size, cfgs.model.num_enc_layers) == (32, 4, 4, 3)
+    agent = PhyloATTN(cfgs)
+    sd = weights.seeded_state(cfgs, int(z["wseed"]), str(z["style"]))
+    agent.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    agent = agent.to("cuda:0")
+    B, T, L = z["codes"].shape
+    batch = {"data": torch.from_numpy(synth.codes_to_onehot(z["codes"])),
+             "seqs": [synth.codes_to_seqs(z["codes"][b]) for b in range(B)],
+             "seq_keys": [list(k) for k in z["keys"]],
+             "seq_weights": torch.from_numpy((~z["mask"]).astype(np.float32))}
+    env = PhyInferEnv(cfgs, "cuda:0")
+    _, best, merges = reinforce_rollout_argmax(batch, agent, env)
+    assert np.array_equal(merges, z["merges"])
+    assert [s.subtrees[0].utree_op_str for s in env.states] == [str(x) for x in z["newick"]]
+    assert env.state_tensor is None or env.state_tensor.shape[-1] == 32
+    env2 = PhyInferEnv(cfgs, "cuda:0")
+    _, best2, merges2 = argmax_rollout(batch, agent, env2)
+    assert np.array_equal(merges2, z["merges"]) and best2 == best == str(z["best_tree"])
+    # the fused step API (nnj_step) on dense tensors of 32 features
+    g = agent._context()
+    tm = torch.from_numpy(z["mask"])
+    state = g.encode(torch.from_numpy(z["codes"]), tm)
+    assert state.shape == (B, T, L // 4, 32)
+    np.testing.assert_allclose(state.cpu().numpy(), z["enc"], atol=RTOL * np.abs(z["enc"]).max())
+    tabs = split_trace(z["logits"], T)
+    logits = g.pair_scores_full(state, tm)
+    assert_logits_close(logits.cpu().numpy(), tabs[0], RTOL, "pair_scores_full")
+    ij, _ = g.select_pair(logits, T)
+    for step, n in enumerate(range(T - 1, 1, -1)):
+        assert np.array_equal(ij.cpu().numpy(), z["merges"][:, step])
+        r = g.step(state, tm, ij, logits)
+        state, logits, ij = r["state"], r["logits"], r["ij"]
+        assert state.shape == (B, n, L // 4, 32)
+        assert_logits_close(logits.cpu().numpy(), tabs[step + 1], RTOL, f"nnj_step n={n}")
 
 
 def _certify_sampled(ref, merges, logits_g, u, temperature, T, rtol=RTOL):
