@@ -161,25 +161,50 @@ class PhyloATTN(nn.Module):
         return {"logits": scores, "distance": scores}
 
     def aggregate(self, x_i, x_j, ij_indices, batchwise_ij_indices=False):
-        if not batchwise_ij_indices:
-            raise NotImplementedError("only the env.step form (batchwise_ij_indices=True) is exposed; "
-                                      "pair scoring goes through decode_zxr")
+        """reference model.py:102-155.  batchwise_ij_indices=True: one pair per alignment (env.step's form; x_i / x_j
+        may be None = rows ij of the stashed state).  False: N pairs per alignment, x_i / x_j [B,N,C,D] and
+        ij_indices 1-D [N] (the same pairs for every alignment, the first step's form) or 2-D [B,N] -- the form
+        decode_gg uses; the hot path scores pairs through decode_zxr instead, this form is here for callers of the
+        reference's method and runs one nnj_aggregate per pair."""
         if self.batch_input is None:
             raise RuntimeError("aggregate() needs the state stashed by a preceding decode_zxr()")
+        st = self.batch_input
+        dev = st.device
+        ii, jj = ij_indices
+        ii = torch.as_tensor(ii).to(dev).to(torch.int64)
+        jj = torch.as_tensor(jj).to(dev).to(torch.int64)
+        B = st.shape[0]
+        if not batchwise_ij_indices:
+            if x_i is None or x_j is None:
+                raise ValueError("aggregate(batchwise_ij_indices=False) takes the pairs' rows x_i, x_j [B,N,C,D]")
+            if ii.dim() == 1:                                  # 'fst step': the same N pairs for every alignment
+                ii, jj = ii[None, :].expand(B, -1), jj[None, :].expand(B, -1)
+            if ii.dim() != 2 or ii.shape != jj.shape or ii.shape[0] != B or x_i.shape[1] != ii.shape[1]:
+                raise ValueError("ij_indices must be 1-D [N] or 2-D [B,N], matching x_i / x_j [B,N,C,D]")
+            if self._wants_grad():
+                from . import train_model
+                return train_model.aggregate(self, st.contiguous(), x_i, x_j, ii.contiguous(), jj.contiguous())
+            # A pair's rows are excluded from its own context (model.py:118-141), so a state whose rows i and j ARE
+            # x_i and x_j gives nnj_aggregate exactly this pair: no assumption that x_i / x_j were gathered from the state
+            ctx = self._context()
+            bi = torch.arange(B, device=dev)
+            out = []
+            for k in range(ii.shape[1]):
+                s_k = st.clone()
+                s_k[bi, ii[:, k]] = x_i[:, k].to(s_k.dtype)
+                s_k[bi, jj[:, k]] = x_j[:, k].to(s_k.dtype)
+                out.append(ctx.aggregate(s_k, torch.stack([ii[:, k], jj[:, k]], dim=1)))
+            return torch.cat(out, dim=1)
         if self._wants_grad():
             from . import train_model
-            ii, jj = ij_indices
-            ii = torch.as_tensor(ii).to(self.batch_input.device).to(torch.int64).view(-1, 1)
-            jj = torch.as_tensor(jj).to(self.batch_input.device).to(torch.int64).view(-1, 1)
-            st = self.batch_input.contiguous()
+            ii, jj = ii.view(-1, 1), jj.view(-1, 1)
+            st = st.contiguous()
             from .train_ops import GatherRows
             xi = GatherRows.apply(st, ii) if x_i is None else x_i
             xj = GatherRows.apply(st, jj) if x_j is None else x_j
             return train_model.aggregate(self, st, xi, xj, ii, jj)
         ctx = self._context()
-        ii, jj = ij_indices
-        ij = torch.stack([torch.as_tensor(ii), torch.as_tensor(jj)], dim=1)
-        return ctx.aggregate(self.batch_input, ij)
+        return ctx.aggregate(st, torch.stack([ii.view(-1), jj.view(-1)], dim=1))
 
     # fast path used by neuralnj_amd.rollout
     def rollout_argmax(self, codes, mask=None, **kw):

@@ -48,9 +48,17 @@ def test_param_count_and_argument_errors():
     assert lib.nnj_num_params(C.byref(cfg), C.byref(n)) == 0 and n.value == 425857
     assert lib.nnj_num_params(None, C.byref(n)) == -1
     h = C.c_void_p()
-    bad = _lib.NnjConfig(4, 4, 32, 4, 3, 0)                 # the reference's default (non-shipped) model
-    assert lib.nnj_create(C.byref(bad), C.byref(h)) == -2   # NNJ_ERR_UNSUPPORTED, stated loudly
-    assert b"embed_dim=64" in lib.nnj_last_error(None)
+    ref_default = _lib.NnjConfig(4, 4, 32, 4, 3, 0)         # the reference's default model (utils.py:45-52): covered
+    assert lib.nnj_num_params(C.byref(ref_default), C.byref(n)) == 0 and n.value == 57889
+    assert lib.nnj_create(C.byref(ref_default), C.byref(h)) in (0, -6)   # created, or NNJ_ERR_NO_DEVICE on a CPU box
+    if h.value:
+        lib.nnj_destroy(h)
+    for bad in (_lib.NnjConfig(4, 1, 64, 4, 6, 0),          # heads of 16 features
+                _lib.NnjConfig(4, 1, 128, 16, 6, 0),        # wider than the kernels' 64 features
+                _lib.NnjConfig(4, 1, 36, 4, 6, 0),          # not a multiple of 8
+                _lib.NnjConfig(5, 1, 64, 8, 6, 0)):         # another alphabet
+        assert lib.nnj_create(C.byref(bad), C.byref(h)) == -2   # NNJ_ERR_UNSUPPORTED, stated loudly
+        assert b"embed_dim 8..64" in lib.nnj_last_error(None)
     assert lib.nnj_profile_kinds() >= 12
     assert lib.nnj_profile_kind_name(1) == b"k_tok1"
 

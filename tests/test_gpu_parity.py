@@ -507,8 +507,8 @@ def test_unsupported_shapes_fail_loudly(ctx_cache):
         g4.rollout_argmax(torch.zeros(1, 4, 30, dtype=torch.uint8))
     g4.close()
     c32 = utils.shipped_config()
-    c32.model.embed_dim = 32
-    with pytest.raises(RuntimeError, match="embed_dim=64"):
+    c32.model.embed_dim = 32                                # 32 features in 8 heads: heads of 4 features are not covered
+    with pytest.raises(RuntimeError, match="embed_dim 8..64"):
         Nnj(c32, "cuda:0")
     g2 = Nnj(cfgs, "cuda:0")
     with pytest.raises(RuntimeError, match="weights not loaded"):
@@ -595,6 +595,50 @@ def test_reference_default_shape_through_the_model_api():
         state, logits, ij = r["state"], r["logits"], r["ij"]
         assert state.shape == (B, n, L // 4, 32)
         assert_logits_close(logits.cpu().numpy(), tabs[step + 1], RTOL, f"nnj_step n={n}")
+
+
+def test_aggregate_pairwise_form_matches_oracle():
+    """PhyloATTN.aggregate(batchwise_ij_indices=False) (reference model.py:102-155 as decode_gg calls it): N pairs per
+    alignment, 1-D indices (the same pairs for every alignment) and 2-D indices with rows that are NOT rows of the state."""
+    from neuralnj_amd.model import PhyloATTN
+    from oracle_lib import Oracle
+    z, cfgs, packed = load_golden("synth_b2_t8_l128_s1")
+    agent = PhyloATTN(cfgs)
+    sd = weights.seeded_state(cfgs, int(z["wseed"]), str(z["style"]))
+    agent.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    agent = agent.to("cuda:0").eval()
+    o = Oracle(cfgs, packed)
+    B, T, L = z["codes"].shape
+    state = o.encode(onehot_f32(z["codes"]), z["mask"])
+    st = torch.from_numpy(state).to("cuda:0")
+    tm = torch.from_numpy(z["mask"]).to("cuda:0")
+    with torch.no_grad():
+        agent.decode_zxr(st, tm, (None, None, None))                     # stashes the state, like the reference
+        row, col = torch.triu_indices(T, T, offset=1)
+        row, col = row[:9], col[:9]
+        got = agent.aggregate(st[:, row], st[:, col], (row, col)).cpu().numpy()
+        assert got.shape == (B, 9, L, 64)
+        for k in range(9):
+            ij = np.tile(np.array([[int(row[k]), int(col[k])]], np.int32), (B, 1))
+            ref = o.aggregate(state, ij)
+            np.testing.assert_allclose(got[:, k:k + 1], ref, atol=RTOL * np.abs(ref).max())
+        # 2-D indices, rows of the pairs given explicitly (not rows of the state)
+        rng = np.random.default_rng(5)
+        ii = np.array([[0, 2, 5], [1, 3, 0]], np.int64)
+        jj = np.array([[4, 7, 6], [2, 6, 7]], np.int64)
+        xi = (state[:, :3] * 0.5 + rng.standard_normal(state[:, :3].shape).astype(np.float32) * 0.1).astype(np.float32)
+        xj = (state[:, 3:6] * 0.5 + rng.standard_normal(state[:, :3].shape).astype(np.float32) * 0.1).astype(np.float32)
+        got = agent.aggregate(torch.from_numpy(xi).to("cuda:0"), torch.from_numpy(xj).to("cuda:0"),
+                              (torch.from_numpy(ii), torch.from_numpy(jj))).cpu().numpy()
+        for k in range(3):
+            s_k = state.copy()
+            for b in range(B):
+                s_k[b, ii[b, k]] = xi[b, k]
+                s_k[b, jj[b, k]] = xj[b, k]
+            ref = o.aggregate(s_k, np.stack([ii[:, k], jj[:, k]], 1).astype(np.int32))
+            np.testing.assert_allclose(got[:, k:k + 1], ref, atol=RTOL * np.abs(ref).max())
+        with pytest.raises(ValueError):
+            agent.aggregate(None, None, (row, col))
 
 
 def _certify_sampled(ref, merges, logits_g, u, temperature, T, rtol=RTOL):
