@@ -1426,6 +1426,7 @@ static int rollout_core(nnj_handle* h, const uint8_t* codes, const uint8_t* mask
     PairGeom g;
     rs.live = livebuf[step & 1];
     const bool v2 = two_pass && step >= 1 && n <= 64 && prev_gave_am;
+    const bool rep0 = step == 0 && n_encode == 1 && B > 1;
     if (v2) {
       Step2 o;
       // without forced / sampled picks the pick of a step >= 1 of this kind is always covered (a new pair or the
@@ -1436,11 +1437,14 @@ static int rollout_core(nnj_handle* h, const uint8_t* codes, const uint8_t* mask
       o.cand_cur = candbuf[step & 1];
       if (int rc = launch_step2(h, rs, livebuf[(step + 1) & 1], ij, mask, base, w, o, n, B, C, g, st)) return rc;
     } else {
-      if (int rc = launch_pair_scores(h, rs, ij, mask, base, w, mode, n, B, C, g, st)) return rc;   // :121-126
+      // sampled rollouts of ONE alignment: every replica's first table is the same numbers -- the all-pairs kernels
+      // run once (alignment 0), k_assemble_argmax gives every replica its own pick from them
+      if (int rc = launch_pair_scores(h, rs, ij, mask, base, w, mode, n, rep0 ? 1 : B, C, g, st)) return rc;   // :121-126
     }
     // does the NEXT step run as a two-pass step?  then this table kernel supplies the weights of its merge
     const bool next_v2 = two_pass && n - 1 >= 2 && n - 1 <= 64;
     StepOut so{};
+    so.rep0 = rep0 ? 1 : 0;
     if (next_v2) {
       so.lam = (v2 && n > 2) ? base + w.lam : nullptr;
       so.beta_slot = base + w.beta_slot;

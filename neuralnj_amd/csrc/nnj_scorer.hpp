@@ -923,6 +923,8 @@ struct StepOut {
   float inv_scale;            // 1 / sqrt(64 C)
   int fallback;               // 1 = the caller launches the fallback kernels where `need` is set; 0 = a pick without a
                               // source is an internal error (sticky status bit NNJ_FLAG_MERGE_WEIGHTS: never silent)
+  int rep0;                   // 1 = step 0 of B replicas of ONE alignment (sampled rollouts, finetune_rl_search.py:338-427):
+                              // the all-pairs kernels ran for alignment 0 only, its partials serve every replica's table
 };
 
 // ------------------------------------------------------------------ table assemble + argmax
@@ -961,6 +963,7 @@ __global__ __launch_bounds__(256) void k_assemble_argmax(const float* __restrict
   __shared__ float red_v[8];
   __shared__ int red_i[4];
   const int tid = threadIdx.x, b = blockIdx.x;
+  const size_t bsrc = so.rep0 ? 0 : b;                      // whose all-pairs partials this table is assembled from
   const int np = num_pairs(n), np_prev = num_pairs(n + 1);
   int ip = 0, jp = 0;
   if (mode == PAIRS_INCR) {
@@ -999,7 +1002,7 @@ __global__ __launch_bounds__(256) void k_assemble_argmax(const float* __restrict
     if (mode == PAIRS_FULL) {
       v = 0.f;
 #pragma unroll 8
-      for (int sc = 0; sc < nsc; ++sc) v += score_part[((size_t)b * nsc + sc) * ppad + p];
+      for (int sc = 0; sc < nsc; ++sc) v += score_part[(bsrc * nsc + sc) * ppad + p];
       if (pc) {
         int ii, jj;
         pair_from_index(n, p, ii, jj);
@@ -1123,7 +1126,7 @@ __global__ __launch_bounds__(256) void k_assemble_argmax(const float* __restrict
     const size_t pp = (size_t)pair_index(n, pi_, pj_);
     float a = 0.f;
     if (r < n)
-      for (int k = part; k < so.nsc0; k += 4) a += so.alpha0[(((size_t)b * so.nsc0 + k) * so.ppad0 + pp) * 64 + r];
+      for (int k = part; k < so.nsc0; k += 4) a += so.alpha0[((bsrc * so.nsc0 + k) * so.ppad0 + pp) * 64 + r];
     pval[PCACHE - 256 + tid] = a;
     __syncthreads();
   }
