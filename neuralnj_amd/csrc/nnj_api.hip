@@ -73,7 +73,13 @@ struct nnj_handle {
   };
   // nnj_step keeps the rows of an ongoing loop in slot layout inside the caller's workspace, with their cached
   // transforms (U, K', beta), exactly like the rollout: consecutive steps re-transform nothing
-  struct StepSession { bool valid = false; const void* ws = nullptr; const float* last_out = nullptr; int B = 0, T0 = 0, L = 0, n = 0; };
+  struct StepSession {
+    bool valid = false; const void* ws = nullptr; const float* last_out = nullptr; int B = 0, T0 = 0, L = 0, n = 0;
+    // nnj_step on the two-pass kernels (nnj_step2.hpp): which of the two live lists / candidate slots is current,
+    // whether the last table kernel left am / need / cand for the next merge, and whether every row still has its K'
+    // (the two-pass step does not produce K' of merged rows: the four-pass entry points then start from the dense tensor)
+    int live_idx = 0, cand_idx = 0; bool tp = false, kp_valid = true;
+  };
   StepSession sess;
   GraphKey gkey{}, gcand{};      // key of the instantiated graph; key of the previous small-batch call
   hipGraphExec_t gexec = nullptr;
@@ -256,7 +262,7 @@ int beta_stride(int B, int C) {
 // workspace regions of the NJ loop (after the state/slots buffer), in floats
 struct LoopWs {
   size_t U, Kp, beta, alpha_part, alpha, score_part, full, agg_part, logits0, logits1, merged, live, ij, zmask;
-  size_t lam, beta_slot, acand, Xc, am, need, cand, cand_run, mrep, end; // the two-pass step (nnj_step2.hpp); replicated mask
+  size_t lam, beta_slot, acand, Xc, am, need, cand, cand_run, mrep, pick, end; // the two-pass step (nnj_step2.hpp); replicated mask
 };
 LoopWs loop_ws(int B, int T, int C) {
   LoopWs w;
@@ -306,6 +312,7 @@ LoopWs loop_ws(int B, int T, int C) {
   w.cand = take((size_t)B * 4);                  // two lists of (a, b): this step's candidate / the next one's
   w.cand_run = take((size_t)B);
   w.mrep = take(((size_t)B * C + 3) / 4);          // site mask of a replicated alignment (bytes)
+  w.pick = take((size_t)B * 2);                    // nnj_step: the pick the stored merge weights belong to
   w.end = o;
   return w;
 }
@@ -875,16 +882,16 @@ int token_mask(nnj_handle* h, const uint8_t** mask, void* ws, int B, int T, int 
 // continues the session: no row is transformed again and the merge runs in place, like inside nnj_rollout_argmax.
 // Anything else runs stateless from the dense tensor, as before.
 struct SessView { float* S; float* base; LoopWs w; int* live; int* ijs; RowSet rs; };
-bool sess_matches(const nnj_handle* h, const void* ws, const float* state, int B, int n, int L) {
+bool sess_matches(const nnj_handle* h, const void* ws, const float* state, int B, int n, int L, bool need_kp = true) {
   const nnj_handle::StepSession& ss = h->sess;
-  return ss.valid && ss.ws == ws && ss.last_out == state && ss.B == B && ss.L == L && ss.n == n;
+  return ss.valid && ss.ws == ws && ss.last_out == state && ss.B == B && ss.L == L && ss.n == n && (ss.kp_valid || !need_kp);
 }
-SessView sess_view(void* ws, int B, int T0, int C) {
+SessView sess_view(void* ws, int B, int T0, int C, int live_idx = 0) {
   SessView v;
   v.S = static_cast<float*>(ws);
   v.base = v.S + align_up((size_t)B * T0 * C * 64, 64);
   v.w = loop_ws(B, T0, C);
-  v.live = reinterpret_cast<int*>(v.base + v.w.live);
+  v.live = reinterpret_cast<int*>(v.base + v.w.live) + (size_t)live_idx * B * T0;
   v.ijs = reinterpret_cast<int*>(v.base + v.w.ij);
   v.rs.S = v.S; v.rs.U = v.base + v.w.U; v.rs.Kp = v.base + v.w.Kp; v.rs.beta_part = v.base + v.w.beta;
   v.rs.bstride = (long)T0 * C * 64; v.rs.live = v.live; v.rs.live_stride = T0; v.rs.ntile32 = beta_stride(B, C);
@@ -892,6 +899,7 @@ SessView sess_view(void* ws, int B, int T0, int C) {
 }
 // start a session from a dense tensor of T0 rows: copy into the slots, identity live list, row transforms
 int sess_begin(nnj_handle* h, const SessView& v, const float* state, int B, int T0, int C, hipStream_t st) {
+  h->sess.live_idx = 0; h->sess.cand_idx = 0; h->sess.tp = false; h->sess.kp_valid = true;
   if (narrow_model(h)) widen_into(h, state, v.S, (long)B * T0 * C, st);
   else HIPCHK(h, hipMemcpyAsync(v.S, state, (size_t)B * T0 * C * 64 * sizeof(float), hipMemcpyDeviceToDevice, st));
   {
@@ -901,7 +909,7 @@ int sess_begin(nnj_handle* h, const SessView& v, const float* state, int B, int 
   return launch_row_xf(h, v.S, v.base + v.w.U, v.base + v.w.Kp, v.base + v.w.beta, (long)T0 * C * 64, T0, T0, B, C, st);
 }
 void sess_set(nnj_handle* h, const void* ws, const float* dense, int B, int T0, int L, int n) {
-  nnj_handle::StepSession& ss = h->sess;
+  nnj_handle::StepSession& ss = h->sess;                  // (live_idx, cand_idx, tp, kp_valid: kept)
   ss.valid = true; ss.ws = ws; ss.last_out = dense; ss.B = B; ss.T0 = T0; ss.L = L; ss.n = n;
 }
 
@@ -1322,11 +1330,86 @@ int nnj_step(nnj_handle* h, const float* state, const uint8_t* mask, const int32
   // when `state` is the tensor the previous call returned (same workspace, batch, sites and row count); any other
   // input starts a new one from the dense tensor (copy into slots + row transforms).  state_out is the dense
   // gather of the live rows the reference's env.step hands back (environment.py:833-835).
-  const bool cont = sess_matches(h, ws, state, B, n + 1, L);
+  // Up to 64 rows the step runs on the two-pass kernels of the rollout (nnj_step2.hpp): the merged row is produced
+  // inside the alpha pass of the new pairs and its attention weights come from the previous call's table kernel when the
+  // caller merges the pair that call picked (`chosen_ij`, the usual loop) -- any other pair takes the per-alignment
+  // fallback.  These kernels do not maintain K' of the merged rows: the session then continues through nnj_step only
+  // (the other dense-state entry points start again from the tensor they are given).
+  const bool two_pass = h->two_pass != 0 && n + 1 <= 64 && n + 1 > 2;
+  const bool cont = sess_matches(h, ws, state, B, n + 1, L, /*need_kp=*/!two_pass);
   const int T0 = cont ? h->sess.T0 : n + 1;
+  const nnj_handle::StepSession prev = h->sess;            // (need_ws invalidates the session: re-validated below)
   if (int rc = check_shape(h, B, T0, L)) return rc;
-  if (int rc = need_ws(h, ws, ws_bytes, B, T0, L)) return rc;      // (invalidates the session: re-validated below)
+  if (int rc = need_ws(h, ws, ws_bytes, B, T0, L)) return rc;
   if (int rc = token_mask(h, &mask, ws, B, T0, L, st)) return rc;
+  if (two_pass && T0 <= 64) {
+    int live_idx = cont ? prev.live_idx : 0, cand_idx = cont ? prev.cand_idx : 0;
+    const bool have_am = cont && prev.tp;
+    const SessView v = sess_view(ws, B, T0, C, live_idx);
+    float* base = v.base;
+    const LoopWs w = v.w;
+    if (!cont) {
+      if (int rc = sess_begin(h, v, state, B, T0, C, st)) return rc;
+    }
+    int* live_old = v.live;
+    int* live_new = reinterpret_cast<int*>(base + w.live) + (size_t)(live_idx ^ 1) * B * T0;
+    int* candbuf[2] = {reinterpret_cast<int*>(base + w.cand), reinterpret_cast<int*>(base + w.cand) + 2 * (size_t)B};
+    int* need = reinterpret_cast<int*>(base + w.need);
+    int* pick = reinterpret_cast<int*>(base + w.pick);
+    const bool use_cand = h->two_pass_cand != 0;
+    HIPCHK(h, hipMemcpyAsync(v.ijs, ij, (size_t)B * 2 * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+    {
+      Scope sc(h, st, PK_STEP_SMALL);
+      hipLaunchKernelGGL(k_step_prepare, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, st, v.ijs, (const int*)pick,
+                         have_am ? 0 : 1, need, candbuf[cand_idx], reinterpret_cast<int*>(base + w.cand_run),
+                         (const int*)live_old, live_new, T0, B, n + 1);
+    }
+    RowSet rs = v.rs;
+    rs.live = live_new;
+    if (int rc = scorer_mask(h, mask, base, w, B, C, st, &mask)) return rc;
+    PairGeom g;
+    Step2 o;
+    o.first = !have_am;                                    // the per-row biases of a new session: summed from the partials
+    o.fallback = true;                                     // (per alignment, only where `need` is set)
+    o.cand = use_cand;
+    o.cand_cur = candbuf[cand_idx];
+    if (int rc = launch_step2(h, rs, live_old, v.ijs, mask, base, w, o, n, B, C, g, st)) return rc;
+    StepOut so{};
+    if (n - 1 >= 2) {                                      // the table kernel prepares the next call's merge
+      so.lam = n > 2 ? base + w.lam : nullptr;
+      so.beta_slot = base + w.beta_slot;
+      so.nslot = T0;
+      so.acand_part = (use_cand && n > 2) ? base + w.acand : nullptr;
+      so.nblk = g.blocks;
+      so.cand_cur = (use_cand && n > 2) ? candbuf[cand_idx] : nullptr;
+      so.am = base + w.am;
+      so.need = need;
+      so.cand_next = use_cand ? candbuf[cand_idx ^ 1] : nullptr;
+      so.cand_run = reinterpret_cast<int*>(base + w.cand_run);
+      so.inv_scale = 1.0f / sqrtf(64.0f * (float)C);
+      so.fallback = 1;
+    }
+    {
+      Scope sc(h, st, PK_ASSEMBLE);
+      hipLaunchKernelGGL(k_assemble_argmax, dim3((unsigned)B), dim3(256), 0, st, g.score_src, g.nsc, g.ppad, logits_prev,
+                         (const int*)v.ijs, logits_out, (float*)nullptr, 0L, forced_next, 2L, (int*)nullptr, 0L, top2_gap, 1L,
+                         chosen_ij, (int)PAIRS_INCR, n, (const float*)nullptr, 0L, 1.0f, h->d_flag, (const int*)live_new,
+                         (int*)nullptr, T0, 1, so);
+    }
+    HIPCHK(h, hipMemcpyAsync(pick, chosen_ij, (size_t)B * 2 * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+    {
+      Scope sc(h, st, PK_MISC);
+      float* so_ = dense_out(h, state_out, ws, B, T0, C);
+      hipLaunchKernelGGL(k_gather_rows, dim3(16, (unsigned)n, (unsigned)B), dim3(256), 0, st, (const float*)v.S,
+                         (const int*)live_new, T0, so_, n, (long)C * 16, (long)T0 * C * 16);
+      dense_out_done(h, so_, state_out, (long)B * n * C, st);
+    }
+    HIPCHK(h, hipGetLastError());
+    sess_set(h, ws, state_out, B, T0, L, n);
+    h->sess.live_idx = live_idx ^ 1; h->sess.cand_idx = cand_idx ^ 1;
+    h->sess.tp = n - 1 >= 2; h->sess.kp_valid = false;
+    return NNJ_OK;
+  }
   const SessView v = sess_view(ws, B, T0, C);
   float* S = v.S;
   float* base = v.base;

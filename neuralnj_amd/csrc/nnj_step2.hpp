@@ -772,3 +772,24 @@ __global__ __launch_bounds__(64) void k_agg_am(RowSet rs, ScorerW w, const int* 
     if (in[k]) am[(size_t)b * 64 + (r - (r > pj ? 1 : 0))] = se > 0.f ? v[k] / se : 0.f;
   }
 }
+
+// nnj_step (include/nnj.h) on the two-pass kernels.  In a rollout the table kernel of a step prepares the NEXT merge (its
+// attention weights `am`, the candidate, the next live list) for the pair it has just picked; through the step API the
+// CALLER names the merge of the next call.  One thread per alignment: the pair is brought into range like the table kernel
+// does, compared with the pick the stored weights belong to -- another pair (or the first step of a session: `first`)
+// sets `need`, so the fallback kernels compute the weights, and drops the candidate, whose positions assumed the pick --
+// and the list after the merge is written beside the one before it (environment.py:764-768: position j leaves).
+__global__ void k_step_prepare(int* __restrict__ ij, const int* __restrict__ pick, int first, int* __restrict__ need,
+                               int* __restrict__ cand_cur, int* __restrict__ cand_run, const int* __restrict__ live_old,
+                               int* __restrict__ live_new, int live_stride, int B, int n1) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const int j = min(max(ij[2 * b + 1], 1), n1 - 1);
+  const int i = min(max(ij[2 * b], 0), j - 1);
+  ij[2 * b] = i; ij[2 * b + 1] = j;
+  const bool same = !first && pick[2 * b] == i && pick[2 * b + 1] == j;
+  if (!same) { need[b] = 1; cand_cur[2 * b] = -1; cand_cur[2 * b + 1] = -1; cand_run[b] = 0; }
+  const int* lo = live_old + (size_t)b * live_stride;
+  int* ln = live_new + (size_t)b * live_stride;
+  for (int p = 0; p < n1 - 1; ++p) ln[p] = lo[p + (p >= j ? 1 : 0)];
+}

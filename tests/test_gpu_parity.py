@@ -374,34 +374,107 @@ def test_mask_none_equals_all_false(ctx_cache):
     assert torch.equal(a["logits"], b["logits"]) and torch.equal(a["merges"], b["merges"])
 
 
-@pytest.mark.parametrize("name", ["synth_b2_t8_l128_s1", "synth_b2_t70_l64_s12"])
+def _step_loop(g, codes, mask, T):
+    """encode + all-pairs table + (T - 2) x nnj_step, every call merging the pair the previous one picked."""
+    state = g.encode(codes, mask)
+    logits = g.pair_scores_full(state, mask)
+    ij, _ = g.select_pair(logits, T)
+    tabs, picks = [logits.cpu().numpy()], [ij.cpu().numpy()]
+    for n in range(T - 1, 1, -1):
+        r = g.step(state, mask, ij, logits)
+        state, logits, ij = r["state"], r["logits"], r["ij"]
+        assert state.shape[1] == n
+        tabs.append(logits.cpu().numpy())
+        picks.append(ij.cpu().numpy())
+    g.check_numeric()
+    return tabs, picks
+
+
+@pytest.mark.parametrize("name", ["synth_b2_t8_l128_s1", "synth_b1_t20_l256_s0", "synth_b2_t70_l64_s12"])
 def test_fused_step_reproduces_the_rollout(name, ctx_cache):
-    """nnj_step (merge + new scores + table + argmax in one call) iterated from the encoder output gives the
-    tables and merges of a rollout on the same (four-pass) kernels bit for bit -- same kernels in the same order (70
-    rows: through the star kernels above 64 live rows, then the 64-row kernels) -- and those of the default rollout
-    (two-pass step: other summation orders) within a fifth of the tolerance."""
+    """nnj_step (merge + new scores + table + argmax in one call) iterated from the encoder output.  On a handle whose
+    steps run the four-pass kernels it gives the tables and merges of that handle's rollout bit for bit (same kernels,
+    same order; 70 rows: through the star kernels above 64 live rows, then the 64-row kernels).  On the default handle
+    the step runs the rollout's two-pass kernels up to 64 rows (the first merge takes its attention weights from the
+    fallback kernels instead of the all-pairs kernel's partials: another summation order): the rollout's tables within a
+    fifth of the tolerance, the same merges; above 64 rows the four-pass kernels, bit for bit."""
     z, cfgs, packed = load_golden(name)
     g = ctx_cache(cfgs, packed)
     codes, mask = torch.from_numpy(z["codes"]), torch.from_numpy(z["mask"])
     B, T, L = z["codes"].shape
     g4 = _four_pass_ctx(cfgs, packed)
     ref = g4.rollout_argmax(codes, mask, want_trace=True, want_state=True)
-    two = g.rollout_argmax(codes, mask, want_trace=True, forced_merges=ref["merges"].cpu().numpy())
-    assert_logits_close(two["logits"].cpu().numpy(), ref["logits"].cpu().numpy(), 0.2 * RTOL, "two-pass vs four-pass step")
     tables = split_trace(ref["logits"].cpu().numpy(), T)
     merges = ref["merges"].cpu().numpy()
+    tabs4, picks4 = _step_loop(g4, codes, mask, T)
     g4.close()
-    state = g.encode(codes, mask)
-    logits = g.pair_scores_full(state, mask)
-    assert np.array_equal(logits.cpu().numpy(), tables[0])
-    ij, _ = g.select_pair(logits, T)
-    assert np.array_equal(ij.cpu().numpy(), merges[:, 0])
-    for step, n in enumerate(range(T - 1, 1, -1), start=1):
-        r = g.step(state, mask, ij, logits)
-        state, logits, ij = r["state"], r["logits"], r["ij"]
-        assert np.array_equal(logits.cpu().numpy(), tables[step]), f"table after merge {step}"
-        assert np.array_equal(ij.cpu().numpy(), merges[:, step])
+    for step in range(T - 1):
+        assert np.array_equal(tabs4[step], tables[step]), f"four-pass step API: table after merge {step}"
+        assert np.array_equal(picks4[step], merges[:, step])
+    two = g.rollout_argmax(codes, mask, want_trace=True, forced_merges=merges)
+    assert_logits_close(two["logits"].cpu().numpy(), ref["logits"].cpu().numpy(), 0.2 * RTOL, "two-pass vs four-pass step")
+    tabs, picks = _step_loop(g, codes, mask, T)
+    if T > 64:
+        for step in range(T - 1):
+            assert np.array_equal(tabs[step], tables[step]), f"table after merge {step}"
+            assert np.array_equal(picks[step], merges[:, step])
+        return
+    free = g.rollout_argmax(codes, mask, want_trace=True)
+    ftabs, fm = split_trace(free["logits"].cpu().numpy(), T), free["merges"].cpu().numpy()
+    assert np.array_equal(tabs[0], ftabs[0])
+    for step in range(T - 1):
+        assert np.array_equal(picks[step], fm[:, step]), f"pick {step}"
+        assert_logits_close(tabs[step], ftabs[step], 0.2 * RTOL, f"step API vs rollout, table after merge {step}")
+
+
+@pytest.mark.parametrize("shape", [(3, 12, 40, 41), (2, 40, 72, 42), (1, 64, 48, 43)])
+def test_fused_step_with_caller_chosen_merges_vs_oracle(shape, ctx_cache):
+    """nnj_step merging pairs the CALLER names: random valid pairs (the weights of such a merge come from the fallback
+    kernels), the pair the previous call picked (from that call's table kernel: a new pair or the carried candidate), and
+    a forced_next pair (the table kernel prepares THAT merge) -- mixed over the steps and inside the batch.  Tables
+    against the oracle teacher-forced along the merges actually applied."""
+    B, T, L, seed = shape
+    cfgs = utils.shipped_config()
+    packed = weights.pack(cfgs, weights.seeded_state(cfgs, 21, "sharp"))
+    g = ctx_cache(cfgs, packed)
+    o = _oracle(cfgs, packed)
+    rng = np.random.default_rng(seed)
+    codes = synth.synth_codes_tree(B, T, L, seed)
+    mask = np.zeros((B, L), bool)
+    tc, tm = torch.from_numpy(codes), torch.from_numpy(mask)
+    state = g.encode(tc, tm)
+    logits = g.pair_scores_full(state, tm)
+    ij = g.select_pair(logits, T)[0].cpu().numpy()
+    applied, tabs = [], [logits.cpu().numpy()]
+    forced_next = None
+    for s_, n in enumerate(range(T, 2, -1)):                 # n rows before the merge
+        use = ij.copy()                                      # default: the pair the last call picked
+        if forced_next is not None:
+            use = forced_next                                # ... which was forced
+        for b in range(B):
+            if (s_ + b) % 3 == 1:                            # a pair of the caller's own
+                use[b] = sorted(rng.choice(n, 2, replace=False))
+        applied.append(use.copy())
+        forced_next = None
+        fn = None
+        if s_ % 4 == 2 and n - 1 >= 2:                       # ask the table kernel to prepare a given merge
+            fn = np.stack([np.array(sorted(rng.choice(n - 1, 2, replace=False)), np.int32) for _ in range(B)])
+            forced_next = fn.copy()
+        r = g.step(state, tm, torch.from_numpy(use.astype(np.int32)), logits,
+                   forced_next=None if fn is None else torch.from_numpy(fn))
+        state, logits = r["state"], r["logits"]
+        ij = r["ij"].cpu().numpy()
+        if fn is not None:
+            assert np.array_equal(ij, fn)
+        tabs.append(logits.cpu().numpy())
     g.check_numeric()
+    forced = np.zeros((B, T - 1, 2), np.int32)
+    forced[:, :T - 2] = np.stack(applied, 1)
+    forced[:, T - 2] = (0, 1)
+    ref = o.rollout_argmax(synth.codes_to_onehot(codes).astype(np.float32), mask, forced_merges=forced)
+    rt = split_trace(ref["logits"], T)
+    for s_ in range(T - 1):
+        assert_logits_close(tabs[s_], rt[s_], RTOL, f"step API, caller's merges {B}x{T}x{L}, table {s_}")
 
 
 @pytest.mark.parametrize("name", ["synth_b2_t8_l128_s1", "synth_b1_t20_l256_s0"])
