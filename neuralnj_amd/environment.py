@@ -104,8 +104,12 @@ class PhylogeneticTreeState:
         self.num_trees = len(subtrees)
         self.is_done = self.num_trees == 1
         self.last_state = isinstance(subtrees[0], UnrootedPhyloTree)
-        self.is_initial = all(t.left_tree_data is None for t in subtrees) and not self.last_state
         self.log_score = subtrees[0].log_score if self.last_state else None
+
+    @property
+    def is_initial(self):
+        # (evaluated when read: a walk over the subtrees per state was half of env.step's host time at a batch of 256)
+        return all(t.left_tree_data is None for t in self.subtrees) and not self.last_state
 
 
 class PhyInferEnv:
@@ -204,7 +208,8 @@ class PhyInferEnv:
             # is the tensor the preceding decode_zxr scored, the library continues its session: merged row in
             # place, no row transformed again, one gather for the dense tensor returned here (include/nnj.h,
             # "Sessions") -- instead of aggregate + cat + gather, i.e. two copies of the whole state per step
-            self.state_tensor = agent._context().env_step(self.state_tensor, ij_t)
+            fused = agent.fused_env_step(self.state_tensor, ij_t) if hasattr(agent, "fused_env_step") else None
+            self.state_tensor = fused if fused is not None else agent._context().env_step(self.state_tensor, ij_t)
             return
         new = agent.aggregate(None, None, (ij_t[:, 0], ij_t[:, 1]), batchwise_ij_indices=True)
         base = []

@@ -20,11 +20,15 @@ def reinforce_rollout_argmax(batch, agent, env, device=None):
     device = device or next(agent.parameters()).device
     arr = batch["data"].to(device)
     mask = batch["seq_weights"].to(device) == 0
-    env.init_states(batch["seqs"], batch["seq_keys"], arr)
     agent.eval()
     ij_prev, logits_prev, merges = None, None, []
     with torch.no_grad():
-        env.state_tensor = agent.encode_zxr(env.init_state_tensor, mask)
+        # the encoder is queued BEFORE the host builds the leaf trees (the reference calls env.init_states first,
+        # finetune_rl_search.py:108-112; the two are independent): 12,800 Python objects at a batch of 256 are built
+        # while the device encodes
+        state0 = agent.encode_zxr(arr, mask)
+        env.init_states(batch["seqs"], batch["seq_keys"], arr)
+        env.state_tensor = state0
         while True:
             B, n = env.state_tensor.shape[:2]
             # The reference computes the old->new table map on the host here (utils.get_score_indices_to_prev,
