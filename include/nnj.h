@@ -57,8 +57,12 @@ typedef struct nnj_config {
                           patch_size consecutive sites, model.py:72-79.  Every entry point takes L = SITES (a multiple
                           of patch_size), codes / one-hot input [*,T,L(,4)] and masks [*,L] per site; state tensors are
                           [B, rows, L / patch_size, 64]; the mask of a token is the mask of its first site.)        */
-  int32_t embed_dim;   /* cfgs.model.embed_dim    (64)                     */
-  int32_t num_heads;   /* cfgs.model.num_enc_heads (8)                     */
+  int32_t embed_dim;   /* cfgs.model.embed_dim    (64 in the shipped yaml; 8..64 in multiples of 8 supported with
+                          num_heads = embed_dim / 8, e.g. the reference's own default 32 / 4 heads, utils.py:45-52.
+                          The kernels work on 64 features: a narrower model runs zero-padded -- exact, every padded
+                          feature stays zero through the whole path -- and its dense state tensors keep their own
+                          width [.., embed_dim] at this interface; ffn width = 4 * embed_dim, model.py:28)         */
+  int32_t num_heads;   /* cfgs.model.num_enc_heads (8; must be embed_dim / 8: heads of 8 features)                */
   int32_t num_layers;  /* cfgs.model.num_enc_layers (6)                    */
   int32_t device;      /* HIP device ordinal                               */
 } nnj_config;
@@ -159,8 +163,15 @@ int nnj_select_pair(nnj_handle* h, const float* logits_dev, int32_t* ij_out_dev,
  * when state_dev is the tensor the library last saw or returned (same workspace pointer, B, L, and n+1 = the session's
  * row count); anything else -- another tensor, another workspace, an entry point other than the dense-state ones
  * (nnj_encode, nnj_rollout_*) on the same workspace in between -- starts a new session from the dense state_dev (copy
- * + row transforms).  Iterated from the encoder output it reproduces nnj_rollout_argmax bit for bit.  state_out_dev
- * is the dense tensor the reference's env.step returns. */
+ * + row transforms).  state_out_dev is the dense tensor the reference's env.step returns.
+ * Up to 64 rows the step runs the two-pass kernels of nnj_rollout_argmax's loop: the merged row is produced inside the
+ * alpha pass of the new pairs and its attention weights are the ones the PREVIOUS call's table kernel prepared for the
+ * pair it returned in chosen_ij_dev -- merging that pair (the usual loop) costs no extra pass; any other ij_dev is
+ * served by per-alignment fallback kernels.  Such a session is continued by nnj_step only (the other dense-state entry
+ * points start again from the tensor they are given).  Iterated from the encoder output it gives nnj_rollout_argmax's
+ * merges and its tables to fp32 rounding (the first merge takes its weights from the fallback kernels, the rollout from
+ * the all-pairs kernel's partial sums); above 64 rows, and on a handle created under NNJ_TWO_PASS=0, the four-pass
+ * kernels, whose loop it reproduces bit for bit. */
 int nnj_step(nnj_handle* h, const float* state_dev, const uint8_t* mask_dev, const int32_t* ij_dev,
              const float* logits_prev_dev, const int32_t* forced_next_dev, float* state_out_dev,
              float* logits_out_dev, int32_t* chosen_ij_dev, float* top2_gap_dev, int32_t B, int32_t n, int32_t L,
@@ -187,7 +198,8 @@ int nnj_rollout_argmax(nnj_handle* h, const uint8_t* codes_dev, const uint8_t* m
  * order) on the caller's uniforms_dev float [B,T-1] in [0,1) -- the reference's own RNG stream is not
  * reproducible across devices, so the stream is an input.  n_encode = B: codes/mask hold B alignments;
  * n_encode = 1: ONE alignment (codes [1,T,L], mask [1,L]) is encoded once and replicated to the B
- * rollouts (the reference re-encodes it per rollout).  merges_out [B,T-1,2] = the sampled pairs.
+ * rollouts (the reference re-encodes it per rollout), and the all-pairs scores of the first step --
+ * the same numbers for every rollout -- are computed once.  merges_out [B,T-1,2] = the sampled pairs.
  * Tree likelihood scoring of the sampled trees (raxml-ng) is outside this library. */
 int nnj_rollout_sample(nnj_handle* h, const uint8_t* codes_dev, const uint8_t* mask_dev,
                        int32_t B, int32_t T, int32_t L, int32_t n_encode,
