@@ -476,6 +476,7 @@ __global__ __launch_bounds__(1024) void k_ffn16(float* __restrict__ x, FfnW wf, 
   if (tid < 64) { cf[tid] = wf.ln_w[tid]; cf[64 + tid] = wf.ln_b[tid]; cf[128 + tid] = wf.b2[tid]; }
   if (tid < 256) cf[192 + tid] = wf.b1[tid];
   __syncthreads();
+  const int nq = (4 * wf.dt + 63) / 64;      // hidden blocks of 64 in use: the ffn width is 4 embed_dim (model.py:28)
   for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
     const int b = grp / groups_per_b;
     int c, r; bool valid;
@@ -494,7 +495,7 @@ __global__ __launch_bounds__(1024) void k_ffn16(float* __restrict__ x, FfnW wf, 
     split_8(yf[0], y.t[0], y.t[1]);
     split_8(yf[1], y.t[2], y.t[3]);
 #pragma unroll 1
-    for (int q = 0; q < 4; ++q) {              // 64 hidden units at a time
+    for (int q = 0; q < nq; ++q) {             // 64 hidden units at a time (a narrower model's padded blocks are skipped)
       V64 hdn;
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt) hdn.t[mt] = *reinterpret_cast<const f32x4*>(cf + 192 + q * 64 + 16 * mt + 4 * kq);
