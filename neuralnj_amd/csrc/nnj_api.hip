@@ -505,6 +505,16 @@ int launch_row_xf(nnj_handle* h, const float* S, float* U, float* Kp, float* bet
 
 // more than 64 live rows: the star kernels of nnj_scorer_wide.hpp (incremental: one star per batch element;
 // all pairs: n-1 stars in launches of at most MB)
+// per-row bias of the attention logits for the softmax kernels of the four-pass / all-pairs path: beta_slot[b][slot] = sum of
+// the row's beta partials + C t0, the sum every pair's wave used to repeat (same order: the same bits).  The two-pass steps
+// keep beta_slot up to date themselves and never run between these launches and their softmax.
+int row_slots(const RowSet& rs, int C) { return (int)(rs.bstride / ((long)C * 64)); }
+void launch_beta_sum(nnj_handle* h, const RowSet& rs, float* base, const LoopWs& w, int B, int C, hipStream_t st) {
+  Scope sc(h, st, PK_STEP_SMALL);
+  const int total = B * row_slots(rs, C);
+  hipLaunchKernelGGL(k_beta_sum, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, rs.beta_part, rs.ntile32, rs.ntile32,
+                     (float)C * scorer_ptrs(h).t0, base + w.beta_slot, total);
+}
 int launch_pair_scores_wide(nnj_handle* h, const RowSet& rs, const int* ij_prev, const uint8_t* mask, float* base,
                             const LoopWs& w, int mode, int n, int B, int C, PairGeom& g, hipStream_t st) {
   const bool full = mode == PAIRS_FULL;
@@ -513,6 +523,7 @@ int launch_pair_scores_wide(nnj_handle* h, const RowSet& rs, const int* ij_prev,
   const int* ijp = full ? nullptr : ij_prev;
   const size_t lds_a = (size_t)(2 * IMG64 + 64 * wg.RP + SCORER_CONSTS) * sizeof(float);
   const size_t lds_s = (size_t)(3 * IMG64 + 64 * wg.RP + SCORER_CONSTS) * sizeof(float);
+  launch_beta_sum(h, rs, base, w, B, C, st);
   for (int m0 = 0; m0 < wg.M; m0 += wg.MB) {
     const int mc = std::min(wg.MB, wg.M - m0);
     const dim3 grid((unsigned)wg.nsc, (unsigned)mc, (unsigned)B);
@@ -531,7 +542,8 @@ int launch_pair_scores_wide(nnj_handle* h, const RowSet& rs, const int* ij_prev,
     {
       Scope sc(h, st, PK_ALPHA_SOFTMAX);
       hipLaunchKernelGGL(k_wide_softmax, dim3((unsigned)(wg.RP / 4), (unsigned)mc, (unsigned)B), dim3(256), 0, st, rs, sw,
-                         ijp, m0, base + w.alpha_part, base + w.alpha, n, C, wg.RP, wg.nsc);
+                         ijp, m0, base + w.alpha_part, base + w.alpha, n, C, wg.RP, wg.nsc,
+                         (const float*)(base + w.beta_slot), row_slots(rs, C));
     }
     {
       Scope sc(h, st, full ? PK_PAIR_SCORE : PK_PAIR_SCORE_INCR);
@@ -586,8 +598,10 @@ int launch_pair_scores(nnj_handle* h, const RowSet& rs, const int* ij_prev, cons
       }
       {
         Scope sc(h, st, PK_ALPHA_SOFTMAX);
+        launch_beta_sum(h, rs, base, w, B, C, st);
         hipLaunchKernelGGL(k_alpha_softmax, dim3((unsigned)(g.ppad / 4), (unsigned)B), dim3(256), 0, st, rs, sw, ij_prev,
-                           base + w.alpha_part, base + w.alpha, mode, n, C, g.npairs, g.ppad, g.nsc_a);
+                           base + w.alpha_part, base + w.alpha, mode, n, C, g.npairs, g.ppad, g.nsc_a,
+                           (const float*)(base + w.beta_slot), row_slots(rs, C));
       }
     }
     {
@@ -635,8 +649,10 @@ int launch_pair_scores(nnj_handle* h, const RowSet& rs, const int* ij_prev, cons
     }
     {
       Scope sc(h, st, PK_ALPHA_SOFTMAX);
+      launch_beta_sum(h, rs, base, w, B, C, st);
       hipLaunchKernelGGL(k_alpha_softmax, dim3((unsigned)(g.ppad / 4), (unsigned)B), dim3(256), 0, st, rs, sw, ij_prev,
-                         base + w.alpha_part, base + w.alpha, mode, n, C, g.npairs, g.ppad, g.nsc);
+                         base + w.alpha_part, base + w.alpha, mode, n, C, g.npairs, g.ppad, g.nsc,
+                         (const float*)(base + w.beta_slot), row_slots(rs, C));
     }
   }
   {

@@ -258,7 +258,8 @@ __global__ __launch_bounds__(64 * NW) void k_pair_alpha(RowSet rs, ScorerW w, co
 __global__ __launch_bounds__(256) void k_alpha_softmax(RowSet rs, ScorerW w, const int* __restrict__ ij_prev,
                                                        const float* __restrict__ alpha_part,
                                                        float* __restrict__ alpha, int mode, int n, int C,
-                                                       int npairs, int ppad, int nsc) {
+                                                       int npairs, int ppad, int nsc,
+                                                       const float* __restrict__ beta_slot, int nslot) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int p = blockIdx.x * 4 + wave, b = blockIdx.y;
   if (p >= ppad) return;
@@ -267,13 +268,9 @@ __global__ __launch_bounds__(256) void k_alpha_softmax(RowSet rs, ScorerW w, con
   float a = 0.f;
 #pragma unroll 8          // independent loads in flight; the additions stay in order
   for (int sc = 0; sc < nsc; ++sc) a += alpha_part[(((size_t)b * nsc + sc) * ppad + p) * 64 + lane];
-  float beta = 0.f;
-  if (lane < n) {
-    const float* bp = rs.beta_part + ((size_t)b * (rs.bstride / ((long)C * 64)) + slot_of(rs, b, lane)) * rs.ntile32;
-#pragma unroll 8
-    for (int t = 0; t < rs.ntile32; ++t) beta += bp[t];
-    beta += (float)C * w.t0;
-  }
+  // per-row bias of the logits: summed once per row by k_beta_sum (every pair's wave used to add the row's C / 32 partials
+  // itself: four times the loads of the logits' own partials at 4096 sites)
+  const float beta = lane < n ? beta_slot[(size_t)b * nslot + slot_of(rs, b, lane)] : 0.f;
   a = (a + beta) * (1.0f / sqrtf(64.0f * (float)C));
   const bool in = valid && lane < n && lane != pi && lane != pj;
   float v = in ? a : -INFINITY;

@@ -143,7 +143,8 @@ __global__ __launch_bounds__(512) void k_wide_alpha(RowSet rs, ScorerW w, const 
 // (model.py:118-146); pairs the star does not want are written as zeros.  One wave per pair row, lane = r' mod 64.
 __global__ __launch_bounds__(256) void k_wide_softmax(RowSet rs, ScorerW w, const int* __restrict__ ij_prev, int m0,
                                                       const float* __restrict__ alpha_part,
-                                                      float* __restrict__ alpha, int n, int C, int RP, int nsc) {
+                                                      float* __restrict__ alpha, int n, int C, int RP, int nsc,
+                                                      const float* __restrict__ beta_slot, int nslot) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = blockIdx.x * 4 + wave, b = blockIdx.z;
   if (r >= RP) return;
@@ -164,16 +165,10 @@ __global__ __launch_bounds__(256) void k_wide_softmax(RowSet rs, ScorerW w, cons
   for (int k = 0; k < nk; ++k) {
     const int rp = 64 * k + lane;
     float s = 0.f;
-#pragma unroll 4          // independent loads in flight; the additions stay in order
+#pragma unroll 8          // independent loads in flight; the additions stay in order
     for (int sc = 0; sc < nsc; ++sc) s += alpha_part[((star * nsc + sc) * RP + r) * RP + rp];
-    float beta = 0.f;
     const bool in = rp < n && rp != st.m && rp != r;
-    if (rp < n) {
-      const float* bp = rs.beta_part + ((size_t)b * (rs.bstride / ((long)C * 64)) + slot_of(rs, b, rp)) * rs.ntile32;
-#pragma unroll 8
-      for (int t = 0; t < rs.ntile32; ++t) beta += bp[t];
-      beta += (float)C * w.t0;
-    }
+    const float beta = rp < n ? beta_slot[(size_t)b * nslot + slot_of(rs, b, rp)] : 0.f;   // (k_beta_sum, once per row)
     a[k] = in ? (s + beta) * inv : -INFINITY;
     mx = fmaxf(mx, a[k]);
   }

@@ -50,7 +50,7 @@ __global__ void k_beta_sum(const float* __restrict__ beta_part, int stride, int 
   if (i >= total) return;
   const float* bp = beta_part + (size_t)i * stride;
   float s = 0.f;
-#pragma unroll 8
+#pragma unroll 32          // (32 loads in flight, added in order: one thread walks up to C / 32 partials)
   for (int t = 0; t < nb; ++t) s += bp[t];
   beta_slot[i] = s + ct0;
 }
