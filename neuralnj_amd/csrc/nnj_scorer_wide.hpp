@@ -13,7 +13,9 @@
 // score: S^T [64 d][RP r']) between two workgroup barriers and then multiply their own pairs with all of it.
 // Work per star is n pairs x n context rows; a star re-reads the n rows of its sites (L2 / MALL resident:
 // consecutive workgroups are the stars of one site chunk).
-//   alpha_part [b][mi][sc][RP pair r][RP r']   alpha [b][mi][RP][RP]   score_part [b][mi][sc][RP]
+//   alpha_part [b][mi][RP pair r][sc][RP r']   alpha [b][mi][RP][RP]   score_part [b][mi][sc][RP]
+//   (the partials of a pair row are contiguous: the softmax kernel streams nsc x RP floats per row; with the site chunk
+//    outermost its reads were a power-of-two stride of RP x RP floats apart and met in the same channels)
 #pragma once
 #include "nnj_scorer16.hpp"
 
@@ -128,13 +130,13 @@ __global__ __launch_bounds__(512) void k_wide_alpha(RowSet rs, ScorerW w, const 
     }
   }
   // partial sums of this site chunk: [pair r][r'], the lane's four r' of tile mt at 16mt + 4kq
-  float* dst = alpha_part + (((size_t)b * gridDim.y + st.mi) * nsc + sc) * ((size_t)RP * RP);
+  float* dst = alpha_part + ((size_t)b * gridDim.y + st.mi) * ((size_t)nsc * RP * RP) + (size_t)sc * RP;
 #pragma unroll
   for (int pt = 0; pt < PT; ++pt) {
     if (pt != pth || !act[pt]) continue;
 #pragma unroll
     for (int mt = 0; mt < NGT; ++mt)
-      *reinterpret_cast<f32x4*>(dst + (size_t)rr[pt] * RP + 16 * mt + 4 * kq) = acc[mt];
+      *reinterpret_cast<f32x4*>(dst + (size_t)rr[pt] * nsc * RP + 16 * mt + 4 * kq) = acc[mt];
   }
 }
 
@@ -166,7 +168,7 @@ __global__ __launch_bounds__(256) void k_wide_softmax(RowSet rs, ScorerW w, cons
     const int rp = 64 * k + lane;
     float s = 0.f;
 #pragma unroll 8          // independent loads in flight; the additions stay in order
-    for (int sc = 0; sc < nsc; ++sc) s += alpha_part[((star * nsc + sc) * RP + r) * RP + rp];
+    for (int sc = 0; sc < nsc; ++sc) s += alpha_part[((star * RP + r) * nsc + sc) * RP + rp];
     const bool in = rp < n && rp != st.m && rp != r;
     const float beta = rp < n ? beta_slot[(size_t)b * nslot + slot_of(rs, b, rp)] : 0.f;   // (k_beta_sum, once per row)
     a[k] = in ? (s + beta) * inv : -INFINITY;
