@@ -105,6 +105,9 @@ __global__ __launch_bounds__(512) void k_wide_alpha(RowSet rs, ScorerW w, const 
         const int o = rr[pt] * 8 + wswz6<8>(rr[pt], 4 * ks + kq);
         im4[o] = sf[ks].h; im4[PL + o] = sf[ks].m;
       }
+      // the pair vectors exist for the tiles that hold a wanted pair only (wave-uniform): a tile of rows r <= m of an
+      // all-pairs star, or beyond the rows, contributes its rows to the image and nothing else
+      if (!act[pt]) continue;
       gate_init16(ur, um, cv, sgn[pt], kq);
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
@@ -263,6 +266,7 @@ __global__ __launch_bounds__(512) void k_wide_score(RowSet rs, ScorerW w, const 
           t16[o0] = (unsigned short)h; t16[o1] = (unsigned short)(h >> 16);
           t16[PLH + o0] = (unsigned short)m; t16[PLH + o1] = (unsigned short)(m >> 16);
         }
+      if (!act[pt]) continue;                              // (see k_wide_alpha: no pair vector for a tile without a wanted pair)
       gate_init16(ur, um, cv, sgn[pt], kq);
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
