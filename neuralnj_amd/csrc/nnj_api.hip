@@ -596,9 +596,9 @@ int launch_pair_scores(nnj_handle* h, const RowSet& rs, const int* ij_prev, cons
         switch (ng) { NNJ_IA(1, 16) NNJ_IA(2, 16) NNJ_IA(3, 12) NNJ_IA(4, 12) }
 #undef NNJ_IA
       }
+      launch_beta_sum(h, rs, base, w, B, C, st);             // (a scope of its own: profiling scopes do not nest)
       {
         Scope sc(h, st, PK_ALPHA_SOFTMAX);
-        launch_beta_sum(h, rs, base, w, B, C, st);
         hipLaunchKernelGGL(k_alpha_softmax, dim3((unsigned)(g.ppad / 4), (unsigned)B), dim3(256), 0, st, rs, sw, ij_prev,
                            base + w.alpha_part, base + w.alpha, mode, n, C, g.npairs, g.ppad, g.nsc_a,
                            (const float*)(base + w.beta_slot), row_slots(rs, C));
@@ -647,9 +647,9 @@ int launch_pair_scores(nnj_handle* h, const RowSet& rs, const int* ij_prev, cons
       hipLaunchKernelGGL((k_pair_alpha<1, 8>), grid, dim3(512), lds, st, rs, sw, ij_prev, base + w.alpha_part, mode, n, C,
                          g.npairs, g.ppad, g.cs, g.nsc, g.pg, B);
     }
+    launch_beta_sum(h, rs, base, w, B, C, st);
     {
       Scope sc(h, st, PK_ALPHA_SOFTMAX);
-      launch_beta_sum(h, rs, base, w, B, C, st);
       hipLaunchKernelGGL(k_alpha_softmax, dim3((unsigned)(g.ppad / 4), (unsigned)B), dim3(256), 0, st, rs, sw, ij_prev,
                          base + w.alpha_part, base + w.alpha, mode, n, C, g.npairs, g.ppad, g.nsc,
                          (const float*)(base + w.beta_slot), row_slots(rs, C));

@@ -714,6 +714,35 @@ def test_aggregate_pairwise_form_matches_oracle():
             agent.aggregate(None, None, (row, col))
 
 
+@pytest.mark.parametrize("name", ["synth_b2_t8_l128_s1", "synth_b2_t70_l64_s12"])
+def test_profiling_covers_every_launch_sequence(name, ctx_cache):
+    """bench.py's per-kernel times come from HIP events around the launches (nnj_profile_enable / _read): every launch
+    sequence -- rollouts (two-pass up to 64 rows, star kernels above), the step API, the dense-state entry points --
+    must leave well-formed event pairs (profiling scopes do not nest)."""
+    z, cfgs, packed = load_golden(name)
+    g = ctx_cache(cfgs, packed)
+    codes, mask = torch.from_numpy(z["codes"]), torch.from_numpy(z["mask"])
+    B, T, L = z["codes"].shape
+    g.profile_enable(True)
+    try:
+        r = g.rollout_argmax(codes, mask)
+        merges = r["merges"].cpu().numpy()
+        u = torch.rand(B, T - 1)
+        g.rollout_sample(codes, mask, u)
+        _step_loop(g, codes, mask, T)
+        state = g.encode(codes, mask)
+        logits = g.pair_scores_full(state, mask)
+        ij = torch.from_numpy(merges[:, 0].copy())
+        g.aggregate(state, ij)
+        s1 = g.env_step(state, ij)
+        g.pair_scores_incr(s1, mask, ij, logits)
+        torch.cuda.synchronize()
+        prof = g.profile_read()
+    finally:
+        g.profile_enable(False)
+    assert sum(cnt for _, cnt in prof.values()) > 4 * T and all(ms >= 0.0 for ms, _ in prof.values())
+
+
 def _certify_sampled(ref, merges, logits_g, u, temperature, T, rtol=RTOL):
     """Sampled trajectories against the oracle twin (same uniforms): identical, except where the uniform lands within
     fp32 rounding of a CDF boundary of the oracle's own table -- at the first divergent step of a differing trajectory
