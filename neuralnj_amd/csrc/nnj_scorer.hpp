@@ -972,7 +972,7 @@ __global__ __launch_bounds__(256) void k_assemble_argmax(const float* __restrict
       float s = 0.f;
       if (r < n) {
         const int src = r - (r > ip ? 1 : 0);
-#pragma unroll 8
+#pragma unroll 32        // every partial of the thread in flight at once (B = 1: 128 partials, 32 per thread), added in order
         for (int sc = part; sc < nsc; sc += 4) s += score_part[((size_t)b * nsc + sc) * ppad + src];
       }
       pval[PCACHE - 256 + tid] = s;
@@ -1123,6 +1123,7 @@ __global__ __launch_bounds__(256) void k_assemble_argmax(const float* __restrict
     const size_t pp = (size_t)pair_index(n, pi_, pj_);
     float a = 0.f;
     if (r < n)
+#pragma unroll 16
       for (int k = part; k < so.nsc0; k += 4) a += so.alpha0[((bsrc * so.nsc0 + k) * so.ppad0 + pp) * 64 + r];
     pval[PCACHE - 256 + tid] = a;
     __syncthreads();
@@ -1134,6 +1135,7 @@ __global__ __launch_bounds__(256) void k_assemble_argmax(const float* __restrict
     float a = 0.f;
     if (r < n) {
       const int col = (mode == PAIRS_INCR && r == ip) ? 63 : r - ((mode == PAIRS_INCR && r > ip) ? 1 : 0);
+#pragma unroll 16
       for (int k = part; k < so.nblk; k += 4) a += so.acand_part[((size_t)b * so.nblk + k) * 64 + col];
     }
     pval[PCACHE - 256 + tid] = a;                           // (entries the table never reaches: np <= 2080 when src == 2)

@@ -673,7 +673,7 @@ __global__ __launch_bounds__(256) void k_step_softmax(RowSet rs, ScorerW w, cons
   }
   float a = 0.f;
   if (SPLIT) {
-#pragma unroll 8
+#pragma unroll 32        // (B = 1: 128 partials, 32 per wave: all in flight, added in order)
     for (int sc = wave; sc < nblk; sc += 4) a += alpha_part[(((size_t)b * nblk + sc) * 64 + q) * 64 + lane];
     part4[wave][lane] = a;
     __syncthreads();
