@@ -58,6 +58,13 @@ def main():
     g.check_numeric()
     res["search_8_rollouts"] = {"s": dt, "rollouts_per_sec": 8 / dt, "distinct_topologies": int(torch.unique(keys).numel())}
     print("search: 8 sampled rollouts of one 200 x 4096 alignment (encoded once):", res["search_8_rollouts"], flush=True)
+    g.profile_enable(True)
+    g.rollout_sample(codes, None, u, temperature=1.0, replicas=8)
+    torch.cuda.synchronize()
+    prof = g.profile_read()
+    g.profile_enable(False)
+    res["kernel_ms_search_round"] = {k: round(v[0], 2) for k, v in prof.items() if v[1]}
+    print("search round, per kernel kind:", res["kernel_ms_search_round"], flush=True)
     if want_oracle:
         from oracle_lib import Oracle
         m = r["merges"].cpu().numpy()
