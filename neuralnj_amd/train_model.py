@@ -94,6 +94,9 @@ def encode(model, onehot, pad):
     B, R, L, V = x.shape
     if model.patch_size != 1:
         raise NotImplementedError("patch_size 1 (the shipped model)")
+    if model.embed_dim != 64 or model.num_enc_heads != 8:
+        raise NotImplementedError("the Finetune operators cover the shipped model (embed_dim 64, 8 heads); narrower "
+                                  "models run in inference only")
     model.patch_num = math.ceil(L / model.patch_size)
     pad = None if pad is None else pad.to(dev)
     # activations the per-step scorer calls of a whole episode would keep (~14 tensors of [B, n, C, D] per step, twice:
