@@ -670,6 +670,57 @@ def test_reference_default_shape_through_the_model_api():
         assert_logits_close(logits.cpu().numpy(), tabs[step + 1], RTOL, f"nnj_step n={n}")
 
 
+def test_drop_in_loop_hands_the_table_over_only_when_asked_the_same_question():
+    """The reference's loop through model / environment at a size that crosses every tile tier (50 rows down to 2, 16
+    alignments): env.step + decode_zxr as one device step (PhyloATTN.fused_env_step) give the merges of the single-call
+    rollout; a decode_zxr that does NOT ask the question the fused step answered (a copy of the previous table, another
+    mask object, other merged pairs) gets the ordinary evaluation, which agrees with the handed-over table."""
+    from neuralnj_amd.environment import PhyInferEnv
+    from neuralnj_amd.model import PhyloATTN
+    from neuralnj_amd.rollout import argmax_rollout, reinforce_rollout_argmax
+    cfgs = utils.shipped_config()
+    agent = PhyloATTN(cfgs)
+    sd = weights.seeded_state(cfgs, 3, "sharp")
+    agent.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    agent = agent.to("cuda:0").eval()
+    B, T, L = 16, 50, 256
+    codes = synth.synth_codes_tree(B, T, L, 77)
+    batch = {"data": torch.from_numpy(synth.codes_to_onehot(codes)), "seqs": [[""] * T for _ in range(B)],
+             "seq_keys": [[f"t{i}" for i in range(T)] for _ in range(B)],
+             "seq_weights": torch.ones((B, L), dtype=torch.float32)}
+    _, best, merges = reinforce_rollout_argmax(batch, agent, PhyInferEnv(cfgs, "cuda:0"))
+    _, best2, merges2 = argmax_rollout(batch, agent, PhyInferEnv(cfgs, "cuda:0"))
+    assert np.array_equal(merges, merges2) and best == best2
+    # the hand-over and its refusals, on the first two steps
+    dev = "cuda:0"
+    mask = torch.zeros((B, L), dtype=torch.bool, device=dev)
+    env = PhyInferEnv(cfgs, dev)
+    with torch.no_grad():
+        st0 = agent.encode_zxr(batch["data"].to(dev), mask)
+        env.init_states(batch["seqs"], batch["seq_keys"], batch["data"])
+        env.state_tensor = st0
+        l0 = agent.decode_zxr(st0, mask, (None, None, None))["logits"]
+        act = torch.argmax(l0, dim=-1)
+        ij = torch.tensor([env.tree_pairs_dict[T][a] for a in act.tolist()], dtype=torch.int32, device=dev)
+        env.step(act, [(None, None)] * B, agent=agent)
+        st1 = env.state_tensor
+        assert agent._prefetch is not None and agent._prefetch[0] is st1
+        pf = agent._prefetch
+        other = ij.clone()
+        other[0] = torch.tensor([0, 1] if tuple(ij[0].tolist()) != (0, 1) else [0, 2], dtype=torch.int32)
+        for kind, args in (("copy of the table", (st1, mask, (ij, None, l0.clone()))),
+                           ("another mask object", (st1, mask.clone(), (ij, None, l0))),
+                           ("other pairs", (st1, mask, (other, None, l0)))):
+            agent._prefetch = pf
+            got = agent.decode_zxr(*args)["logits"]
+            assert got is not pf[6], kind
+            if kind != "other pairs":
+                assert_logits_close(got.cpu().numpy(), pf[6].cpu().numpy(), 0.2 * RTOL, kind)
+        agent._prefetch = pf
+        assert agent.decode_zxr(st1, mask, (ij, None, l0))["logits"] is pf[6]
+    agent._context().check_numeric()
+
+
 def test_aggregate_pairwise_form_matches_oracle():
     """PhyloATTN.aggregate(batchwise_ij_indices=False) (reference model.py:102-155 as decode_gg calls it): N pairs per
     alignment, 1-D indices (the same pairs for every alignment) and 2-D indices with rows that are NOT rows of the state."""
