@@ -362,6 +362,13 @@ def main():
         run_case("dim32_b1_t20_l160_s20", codes, mask, 20, "plain", ref, layers=3, patch=1, dim=32, heads=4)
     add("dim32_b1_t20_l160_s20", dim32_patch1)
 
+    def dim32_t50():
+        # the reference's default model at the size of its bundled examples (50 taxa x 1024 sites = 256 tokens of 4 sites)
+        codes = synth.synth_codes_tree(1, 50, 1024, 1022)
+        run_case("dim32_b1_t50_l1024_s22", codes, np.zeros((1, 1024), dtype=bool), 22, "plain", ref, layers=3, patch=4,
+                 dim=32, heads=4)
+    add("dim32_b1_t50_l1024_s22", dim32_t50)
+
     def dim16_small():
         codes = synth.synth_codes_tree(1, 9, 96, 1021)
         run_case("dim16_b1_t9_l96_s21", codes, np.zeros((1, 96), dtype=bool), 21, "sharp", ref, layers=2, patch=2, dim=16, heads=2)

@@ -79,7 +79,10 @@ def test_oracle_matches_reference_round3_wide_cases():
     _check("synth_b1_t200_l256_s13", "f64", rel=6e-4)
 
 
-@pytest.mark.parametrize("name", ["patch4_b2_t8_l128_s16", "patch4_b1_t20_l256_s17", "patch2_b1_t12_l96_s18"])
+@pytest.mark.parametrize("name", ["patch4_b2_t8_l128_s16", "patch4_b1_t20_l256_s17", "patch2_b1_t12_l96_s18",
+                                  # narrower models, incl. the reference's default shape (32 features, 4 heads, 3 layers,
+                                  # patch 4) at the size of its bundled examples
+                                  "dim32_b1_t50_l1024_s22"])
 def test_oracle_matches_reference_patched_tokens(name):
     """patch_size 4 and 2 (a token = several consecutive sites, model.py:72-79; the reference's utils.py default is 4):
     embed over the concatenated site vectors, the mask taken every patch_size-th site, alpha scaled by the patch count."""
