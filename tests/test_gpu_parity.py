@@ -248,6 +248,46 @@ def test_seeded_random_inputs_vs_oracle(ctx_cache):
         assert (merges[:, :, 1] < np.arange(T, 1, -1)[None, :]).all()
 
 
+def test_narrow_model_seeded_inputs_vs_oracle(ctx_cache):
+    """A model of 32 features / 4 heads / 2 layers / patch 2 (zero-padded onto the 64-feature kernels) on fresh seeded
+    inputs that reach every kernel family: 16-pair and 32-pair tiles, the two-pass step, the star kernels above 64 and
+    above 128 rows, a padded tail, sampled replicas of one alignment (first table computed once), the step API."""
+    cfgs = utils.shipped_config()
+    cfgs.model.embed_dim, cfgs.model.num_enc_heads, cfgs.model.num_enc_layers, cfgs.model.patch_size = 32, 4, 2, 2
+    packed = weights.pack(cfgs, weights.seeded_state(cfgs, 23, "sharp"))
+    g = ctx_cache(cfgs, packed)
+    o = _oracle(cfgs, packed)
+    for (B, T, L, seed) in ((2, 9, 40, 1), (1, 33, 64, 2), (2, 50, 96, 3), (1, 70, 48, 4), (1, 130, 32, 5)):
+        codes = synth.synth_codes_tree(B, T, L, 100 + seed)
+        mask = np.zeros((B, L), bool)
+        if seed % 2:
+            codes[:, :, L - 6:] = 5
+            mask[:, L - 6:] = True
+        tc, tm = torch.from_numpy(codes), torch.from_numpy(mask)
+        free = g.rollout_argmax(tc, tm, want_trace=True, want_state=True)
+        assert free["state"].shape == (B, T, L // 2, 32)
+        merges = free["merges"].cpu().numpy()
+        ref = o.rollout_argmax(synth.codes_to_onehot(codes).astype(np.float32), mask, forced_merges=merges)
+        assert_logits_close(free["logits"].cpu().numpy(), ref["logits"], RTOL, f"narrow model {B}x{T}x{L}")
+        scale = np.abs(ref["logits"]).max()
+        decisive = ref["top2_gap"] > 4 * RTOL * scale
+        assert (ref["merges"][decisive] == merges[decisive]).all()
+        if T <= 50:
+            tabs, picks = _step_loop(g, tc, tm, T)
+            ft = split_trace(free["logits"].cpu().numpy(), T)
+            for s_ in range(T - 1):
+                assert_logits_close(tabs[s_], ft[s_], 0.2 * RTOL, f"narrow model, step API table {s_}")
+    # sampled replicas of ONE alignment against the oracle twin on the same uniforms
+    T, L, R = 12, 48, 6
+    codes = synth.synth_codes_tree(1, T, L, 111)
+    u = np.random.default_rng(9).random((R, T - 1)).astype(np.float32)
+    rs = g.rollout_sample(torch.from_numpy(codes), None, torch.from_numpy(u), temperature=1.0, replicas=R, want_trace=True)
+    ref = o.rollout_sample(np.repeat(synth.codes_to_onehot(codes).astype(np.float32), R, 0), None, u, 1.0)
+    agree = _certify_sampled(ref, rs["merges"].cpu().numpy(), rs["logits"].cpu().numpy(), u, 1.0, T)
+    assert agree.sum() >= R - 1
+    g.check_numeric()
+
+
 @pytest.mark.parametrize("shape", [(3, 12, 40, 31), (2, 40, 72, 32), (1, 64, 48, 33), (2, 70, 32, 34)])
 def test_forced_random_merges_vs_oracle(shape, ctx_cache):
     """Teacher-forcing along RANDOM merge lists (valid pairs that are almost never the argmax): in the two-pass NJ step
