@@ -246,8 +246,24 @@ def compat_path(cfgs, packed, codes, T, L, dev):
     _, _, m = reinforce_rollout_argmax(batch, agent, env)
     torch.cuda.synchronize(dev)
     dt = time.perf_counter() - t0
-    return dict(workload=f"Batch={B}, {T}x{L}, reinforce_rollout_argmax (model/environment API, per-step host loop)",
-                trees_per_sec=B / dt, ms_per_rollout=1e3 * dt), m
+    out = dict(workload=f"Batch={B}, {T}x{L}, reinforce_rollout_argmax (model/environment API, per-step host loop)",
+               trees_per_sec=B / dt, ms_per_rollout=1e3 * dt)
+    # ... and the loop exactly as the reference writes it: host index map per step, one .item() per
+    # alignment and step (12,544 synchronising reads per rollout of 256), log-softmax of every table
+    from neuralnj_amd.rollout import reinforce_rollout_reference_pattern
+    env = PhyInferEnv(cfgs, dev)
+    reinforce_rollout_reference_pattern(batch, agent, env)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    env = PhyInferEnv(cfgs, dev)
+    _, _, m_ref = reinforce_rollout_reference_pattern(batch, agent, env)
+    torch.cuda.synchronize(dev)
+    dt2 = time.perf_counter() - t0
+    out["reference_loop_unchanged"] = dict(
+        workload="the same rollout driven as finetune_rl_search.py:100-189 drives it, host side unchanged: host-built index "
+                 "map uploaded per step, .item() per alignment, log-softmax of every table",
+        trees_per_sec=B / dt2, ms_per_rollout=1e3 * dt2, merges_equal=bool(np.array_equal(m_ref, m)))
+    return out, m
 
 
 def finetune_episode(cfgs, T, L, dev):
@@ -334,6 +350,10 @@ def main():
     ap.add_argument("--no-single-msa", action="store_true",
                     help="skip the Batch=1 latency figure (keeps a rocprofv3 summary of this command to the timed workload)")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel HIP events pass")
+    ap.add_argument("--data-rank", type=int, default=None,
+                    help="single-process runs: generate the data shard of THIS rank of a multi-rank run (seed 1000 + rank)")
+    ap.add_argument("--dump-merges", default=None,
+                    help="rank 0 writes the gathered merge lists of the last timed step, int32 [world, B, T-1, 2], to this .npy")
     ap.add_argument("--streams", type=int, default=int(os.environ.get("NNJ_BENCH_STREAMS", "2")),
                     help="sub-batches of a rollout that run on streams of their own (nnj_set_concurrency); 1 = one stream")
     args = ap.parse_args()
@@ -372,7 +392,8 @@ def main():
     g.set_concurrency(args.streams)
 
     B, T, L = args.batch, args.taxa, args.sites
-    codes = torch.from_numpy(synth.synth_codes(B, T, L, seed=1000 + rank, gap_frac=0.2)).to(dev)
+    data_rank = rank if args.data_rank is None else args.data_rank
+    codes = torch.from_numpy(synth.synth_codes(B, T, L, seed=1000 + data_rank, gap_frac=0.2)).to(dev)
     mask = torch.zeros((B, L), dtype=torch.uint8, device=dev)
     g.workspace(B, T, L)
 
@@ -450,6 +471,9 @@ def main():
             verified["worst_rank_score_err_rel_vs_fp32_oracle"] = float(errs[0])
             verified["worst_rank_score_err_rel_vs_fp64"] = float(errs[1])
             verified["ranks_verified"] = world
+    if args.dump_merges and rank == 0:
+        allm = torch.stack([x.cpu() for x in gathered]) if dist is not None else merges[None]
+        np.save(args.dump_merges, allm.numpy().astype(np.int32))
     trees = world * B * args.steps
     out = {
         "metric": "trees/sec (Argmax) on 50-taxa x 1024-site MSAs",
@@ -576,15 +600,13 @@ def main():
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
-    # exit code: a merge list that fails the RF gate, or a score error beyond twice the tolerance, aborts; an error
-    # between 1x and 2x the tolerance (the tail of the fp32-level noise of this workload: 4e-5 .. 9e-5 over 48 sampled
-    # trees, profiles/r03/e64_scan.txt) is reported as ok = false without voiding the timing
+    # exit code (ADVICE r3 / VERDICT r3 item 5): the run fails -- exit 3 -- exactly when the JSON says ok = false: a merge list
+    # that fails the RF gate, a sampled tree that differs from the timed run, or a scale-relative score error against the
+    # fp64 evaluation beyond 1x the tolerance, on any rank
     if verified is not None:
-        hard = (not verified["rf_gate_ok"]) or verified["score_err_rel_vs_fp64"] > 2 * verified["score_tolerance"] \
-            or not verified["same_merges_as_timed_run"]
+        hard = not verified["ok"]
         if dist is not None:
-            hard = hard or not verified.get("all_ranks_rf_gate_ok", True) \
-                or verified.get("worst_rank_score_err_rel_vs_fp64", 0.0) > 2 * verified["score_tolerance"]
+            hard = hard or not verified.get("all_ranks_ok", True)
         if hard:
             sys.exit(3)
 

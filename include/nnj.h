@@ -88,6 +88,13 @@ int nnj_load_weights(nnj_handle* h, const float* packed_host, size_t n);
 /* Scratch bytes needed by any entry point below for shapes up to (B,T,L). */
 int nnj_workspace_bytes(const nnj_handle* h, int32_t B, int32_t T, int32_t L, size_t* bytes);
 
+/* Host-only self check of the launch geometry behind nnj_workspace_bytes (no device, no handle): does every scorer
+ * launch of a rollout of B alignments x T rows x C tokens -- the batch itself and the one-alignment form
+ * nnj_rollout_sample uses for the first table of replicas -- fit the workspace regions reserved for it?  Returns 0 if
+ * so, NNJ_ERR_ARG for a bad shape, otherwise the (positive) number of the first region that is too small.  No
+ * reference counterpart: the reference allocates per operator (model.py:168-201). */
+int nnj_workspace_selfcheck(int32_t B, int32_t T, int32_t C);
+
 /* PhyloATTN.encode_zxr -- reference model.py:67-88 (+ msa_modules.py:62-151,
  * axial_attention.py:6-255).  Exactly one of codes_dev / onehot_dev is non-NULL: codes_dev takes the
  * 6-entry LUT fast path; onehot_dev (float [B,T,L,4], any values) runs the embed MLP on the device. */

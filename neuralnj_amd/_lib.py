@@ -36,6 +36,7 @@ _SIGS = {
     "nnj_num_params": ([C.POINTER(NnjConfig), C.POINTER(C.c_size_t)], C.c_int),
     "nnj_load_weights": ([_vp, _vp, C.c_size_t], C.c_int),
     "nnj_workspace_bytes": ([_vp, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_size_t)], C.c_int),
+    "nnj_workspace_selfcheck": ([C.c_int32, C.c_int32, C.c_int32], C.c_int),
     "nnj_encode": ([_vp, _vp, _vp, _vp, _vp, C.c_int32, C.c_int32, C.c_int32, _vp, C.c_size_t, _vp], C.c_int),
     "nnj_pair_scores_full": ([_vp, _vp, _vp, _vp, C.c_int32, C.c_int32, C.c_int32, _vp, C.c_size_t, _vp], C.c_int),
     "nnj_pair_scores_incr": ([_vp, _vp, _vp, _vp, _vp, _vp, C.c_int32, C.c_int32, C.c_int32, _vp, C.c_size_t, _vp], C.c_int),

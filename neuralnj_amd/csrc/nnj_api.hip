@@ -284,12 +284,15 @@ LoopWs loop_ws(int B, int T, int C) {
     }
   if (T > 64) {                                                    // the star kernels (more than 64 live rows)
     for (int full = 0; full < 2; ++full)
-      for (int n : {T, std::min(T, 128)}) {
-        const WideGeom g = wide_geom(n, B, C, full != 0);
-        ap = std::max(ap, (size_t)B * g.MB * g.nsc * g.RP * g.RP);
-        al = std::max(al, (size_t)B * g.MB * g.RP * g.RP);
-        sp = std::max(sp, (size_t)B * g.MB * g.nsc * g.RP);
-      }
+      for (int n : {T, std::min(T, 128)})
+        // Bg = 1: the first table of sampled replicas of ONE alignment is launched for alignment 0 only (rollout_core,
+        // rep0), with the geometry of a batch of one -- whose star blocks (MB) can be larger than B x MB(B)
+        for (int Bg : {B, 1}) {
+          const WideGeom g = wide_geom(n, Bg, C, full != 0);
+          ap = std::max(ap, (size_t)Bg * g.MB * g.nsc * g.RP * g.RP);
+          al = std::max(al, (size_t)Bg * g.MB * g.RP * g.RP);
+          sp = std::max(sp, (size_t)Bg * g.MB * g.nsc * g.RP);
+        }
     fu = (size_t)B * T * (T - 1) / 2;
   }
   w.alpha_part = take(ap);
@@ -521,6 +524,11 @@ int launch_pair_scores_wide(nnj_handle* h, const RowSet& rs, const int* ij_prev,
   const WideGeom wg = wide_geom(n, B, C, full);
   const ScorerW sw = scorer_ptrs(h);
   const int* ijp = full ? nullptr : ij_prev;
+  // the regions were sized by loop_ws for the batch the workspace belongs to; a launch for another batch size (the
+  // one-alignment form of sampled replicas) must fit them too -- never write past a region silently
+  if ((size_t)B * wg.MB * wg.nsc * wg.RP * wg.RP > w.alpha - w.alpha_part ||
+      (size_t)B * wg.MB * wg.RP * wg.RP > w.score_part - w.alpha || (size_t)B * wg.MB * wg.nsc * wg.RP > w.full - w.score_part)
+    return fail(h, NNJ_ERR_WORKSPACE, "star launch (n=%d, B=%d, C=%d) does not fit the workspace regions", n, B, C);
   const size_t lds_a = (size_t)(2 * IMG64 + 64 * wg.RP + SCORER_CONSTS) * sizeof(float);
   const size_t lds_s = (size_t)(3 * IMG64 + 64 * wg.RP + SCORER_CONSTS) * sizeof(float);
   launch_beta_sum(h, rs, base, w, B, C, st);
@@ -1146,6 +1154,34 @@ int nnj_load_weights(nnj_handle* h, const float* p, size_t n) {
   HIPCHK(h, hipMemcpy(h->d_w, host.data(), total * sizeof(float), hipMemcpyHostToDevice));
   h->have_w = true;
   return NNJ_OK;
+}
+
+// Host-only self check of the launch geometry (no device, no handle): every scorer launch of a rollout of B alignments of
+// T rows and C tokens -- the batch itself and the one-alignment form of sampled replicas -- fits the workspace regions
+// loop_ws(B, T, C) reserves.  0 = fits; otherwise the number of the first region that is too small.
+int nnj_workspace_selfcheck(int32_t B, int32_t T, int32_t C) {
+  if (B <= 0 || T < 2 || C <= 0 || T > 256) return NNJ_ERR_ARG;
+  const LoopWs w = loop_ws(B, T, C);
+  const size_t cap_ap = w.alpha - w.alpha_part, cap_al = w.score_part - w.alpha, cap_sp = w.full - w.score_part;
+  for (int Bg : {B, 1})
+    for (int n = T; n >= 2; --n) {
+      if (Bg == 1 && n != T) break;                          // (only the first table is launched for one alignment)
+      if (n > 64) {
+        for (int full = 0; full < 2; ++full) {
+          if ((full != 0) != (n == T)) continue;
+          const WideGeom g = wide_geom(n, Bg, C, full != 0);
+          if ((size_t)Bg * g.MB * g.nsc * g.RP * g.RP > cap_ap) return 1;
+          if ((size_t)Bg * g.MB * g.RP * g.RP > cap_al) return 2;
+          if ((size_t)Bg * g.MB * g.nsc * g.RP > cap_sp) return 3;
+        }
+      } else {
+        const PairGeom g = pair_geom(n == T ? PAIRS_FULL : PAIRS_INCR, n, Bg, C);
+        if ((size_t)Bg * g.nsc_a * g.ppad * 64 > cap_ap) return 1;
+        if ((size_t)Bg * g.ppad * 64 > cap_al) return 2;
+        if ((size_t)Bg * g.nsc * g.ppad > cap_sp) return 3;
+      }
+    }
+  return 0;
 }
 
 int nnj_workspace_bytes(const nnj_handle* h, int32_t B, int32_t T, int32_t L_sites, size_t* bytes) {

@@ -99,17 +99,18 @@ def format_rtree(tree, at_root=False, branch_length=None, sequence_keys=None):
 
 
 class PhylogeneticTreeState:
-    def __init__(self, subtrees: List[PhyloTree]):
+    def __init__(self, subtrees: List[PhyloTree], is_initial=None):
         self.subtrees = subtrees
         self.num_trees = len(subtrees)
         self.is_done = self.num_trees == 1
         self.last_state = isinstance(subtrees[0], UnrootedPhyloTree)
         self.log_score = subtrees[0].log_score if self.last_state else None
-
-    @property
-    def is_initial(self):
-        # (evaluated when read: a walk over the subtrees per state was half of env.step's host time at a batch of 256)
-        return all(t.left_tree_data is None for t in self.subtrees) and not self.last_state
+        # fixed at construction like the reference's flag (environment.py:334-338).  The callers on the hot path say
+        # what they build (init_states: True, a merge: False) -- the walk over the subtrees the reference does per state
+        # was half of env.step's host time at a batch of 256; anyone else gets the walk.
+        if is_initial is None:
+            is_initial = all(t.left_tree_data is None for t in subtrees) and not self.last_state
+        self.is_initial = bool(is_initial)
 
 
 class PhyInferEnv:
@@ -137,7 +138,7 @@ class PhyInferEnv:
         self.batch_size = len(batch_seqs)
         self.states = [
             PhylogeneticTreeState([PhyloTree(False, root_seq_data=[i], name=seq_keys[b][i], device=self.device)
-                                   for i in range(len(batch_seqs[b]))])
+                                   for i in range(len(batch_seqs[b]))], is_initial=True)
             for b in range(self.batch_size)]
         self.init_state_tensor = seq_arrays
         self.state_tensor = None
@@ -159,12 +160,13 @@ class PhyInferEnv:
             ut = UnrootedPhyloTree(new_tree)
             ut.utree_op_str = format_rtree(new_tree, True, None, keys)
             ut._keys = keys                                    # rtree_op_tuple / utree_op_tuple: built on first read
-            self.states[b] = PhylogeneticTreeState([ut])
+            self.states[b] = PhylogeneticTreeState([ut], is_initial=False)
             return True
-        trees = st.subtrees
+        # a new list: a state object the caller kept (the first state of a trajectory) is not changed behind its back
+        trees = list(st.subtrees)
         trees[i] = new_tree
         trees.pop(j)
-        self.states[b] = PhylogeneticTreeState(trees)
+        self.states[b] = PhylogeneticTreeState(trees, is_initial=False)
         return False
 
     def step(self, actions, edge_actions=None, parallel=True, branch_optimize=False, agent=None,

@@ -19,8 +19,9 @@ from ._lib import Nnj
 
 
 class _AttnParams(nn.Module):          # holds {k,v,q,out}_proj like the reference's attention modules
-    def __init__(self, d):
+    def __init__(self, d, heads=8):
         super().__init__()
+        self.num_heads = heads             # (axial_attention.py:18,153)
         self.k_proj = nn.Linear(d, d)
         self.v_proj = nn.Linear(d, d)
         self.q_proj = nn.Linear(d, d)
@@ -42,10 +43,10 @@ class _Residual(nn.Module):            # `.layer` + `.layer_norm`, as Normalized
 
 
 class _AxialLayerParams(nn.Module):
-    def __init__(self, d, f):
+    def __init__(self, d, f, heads=8):
         super().__init__()
-        self.row_self_attention = _Residual(_AttnParams(d), d)
-        self.column_self_attention = _Residual(_AttnParams(d), d)
+        self.row_self_attention = _Residual(_AttnParams(d, heads), d)
+        self.column_self_attention = _Residual(_AttnParams(d, heads), d)
         self.feed_forward_layer = _Residual(_FfnParams(d, f), d)
 
 
@@ -61,7 +62,7 @@ class PhyloATTN(nn.Module):
         self.num_enc_heads = m.num_enc_heads
         self.num_enc_layers = m.num_enc_layers
         self.dropout = 0.4                      # model.py:23; applied in train() mode with gradients (train_model.encode)
-        self.seq_emb_layers = nn.ModuleList([_AxialLayerParams(d, 4 * d) for _ in range(m.num_enc_layers)])
+        self.seq_emb_layers = nn.ModuleList([_AxialLayerParams(d, 4 * d, int(m.num_enc_heads)) for _ in range(m.num_enc_layers)])
         self.embed = nn.Sequential(nn.Linear(m.vocab_size * m.patch_size, d), nn.GELU(), nn.Linear(d, d))
         self.h_linear_last = nn.Linear(d, d)
         self.g_linear_last = nn.Linear(d, d)

@@ -51,6 +51,39 @@ def reinforce_rollout_argmax(batch, agent, env, device=None):
     return scores, best, np.array(merges, dtype=np.int32).transpose(1, 0, 2)
 
 
+def reinforce_rollout_reference_pattern(batch, agent, env, device=None):
+    """The same eval + argmax rollout driven the way the reference's UNMODIFIED loop drives it
+    (finetune_rl_search.py:100-189) -- for the figure bench.py reports beside `reinforce_rollout_argmax`: the host trees
+    first, then the encoder (:108-112); the old->new table map built on the host and uploaded every step (:121-123); a
+    log-softmax of every table (:140); the actions read back one `.item()` per alignment (:159-160); the merged pairs
+    uploaded from a numpy array (:160).  Nothing of the device path changes -- decode_zxr / env.step are the same calls --
+    only the host pattern around them, which is what a drop-in user who edits nothing gets."""
+    device = device or next(agent.parameters()).device
+    arr = batch["data"].to(device)
+    mask = batch["seq_weights"].to(device) == 0
+    env.init_states(batch["seqs"], batch["seq_keys"], arr)
+    agent.eval()
+    ij_prev, logits_prev, merges = None, None, []
+    with torch.no_grad():
+        env.state_tensor = agent.encode_zxr(env.init_state_tensor, mask)
+        while True:
+            B, n = env.state_tensor.shape[:2]
+            idx = None
+            if ij_prev is not None:
+                idx = torch.from_numpy(np.array(utils.get_score_indices_to_prev(ij_prev, env, n, B))).to(device)
+            logits = agent.decode_zxr(env.state_tensor, mask, (ij_prev, idx, logits_prev))["logits"]
+            torch.log_softmax(logits, dim=-1)
+            actions = torch.argmax(logits, dim=-1)
+            ij = [env.tree_pairs_dict[n][a.item()] for a in actions]
+            merges.append(ij)
+            ij_prev = torch.from_numpy(np.array(ij)).to(device).to(torch.int32)
+            if env.step(actions, [(None, None)] * B, branch_optimize=False, agent=agent):
+                break
+            logits_prev = logits
+    scores, _, _, best = env.evaluate_loglikelihood()
+    return scores, best, np.array(merges, dtype=np.int32).transpose(1, 0, 2)
+
+
 def argmax_rollout(batch, agent, env, device=None):
     """Fast path: whole rollout on the device, no per-step host round trip."""
     device = device or next(agent.parameters()).device
@@ -288,10 +321,19 @@ def rl_finetuning(cfgs, batch, agent, optimizer, env, stop_step=20, seed=0, mode
         return ll.to(torch.float32), br
 
     with torch.no_grad():
-        u0 = torch.from_numpy(rng.random((1, T - 1)).astype(np.float32))
+        # the first baseline is ONE sampled rollout shared by all episodes of the epoch (finetune_rl_search.py:213-222):
+        # drawn from a rank-independent stream so that every rank starts from the same baseline and the all-reduced
+        # gradient equals the single-process run's
+        u0 = torch.from_numpy(np.random.default_rng([seed]).random((1, T - 1)).astype(np.float32))
         first = ctx.rollout_sample(codes, mask, u0, temperature=temperature, replicas=1)["merges"]
-        baseline_val = float(score(first)[0][0])
-    best_tree, best_score, losses, batch_scores, step_cur = None, -np.inf, [], [], 0
+        sc0, br0 = score(first)
+        baseline_val = float(sc0[0])
+    # the baseline rollout is a scored tree like any other: it seeds the best tree, so a rank that is given no episode
+    # (more ranks than episodes) still returns a tree -- the same one on every rank -- instead of None
+    env.init_states([batch["seqs"][0]], [batch["seq_keys"][0]], None)
+    env.apply_merges(first[:1].cpu().numpy(), br0[:1].cpu().numpy(), sc0[:1].cpu().numpy())
+    best_tree, best_score = env.states[0].subtrees[0].utree_op_str, baseline_val
+    losses, batch_scores, step_cur = [], [], 0
     lo, hi = sharding.shard_bounds(int(cfgs.num_episodes), world, rank)
     E = hi - lo                              # a rank without an episode samples nothing: it joins the all-reduce with zeros
     reps = {k: (v[:1] * E if isinstance(v, list) else v[:1].expand(E, *v.shape[1:])) for k, v in batch.items()}

@@ -37,7 +37,7 @@ def _f32(t, dev):
 def row_attention(att, x, pad, p_drop=0.0):
     """RowSelfAttention.forward, tied over rows (axial_attention.py:66-138).  x [R,C,B,D]; pad bool [B,C] or None."""
     R, C, B, D = x.shape
-    H = 8
+    H = int(att.num_heads)
     dh = D // H
     scaling = dh ** -0.5 / math.sqrt(R)
     q = _lin(x, att.q_proj)
@@ -66,7 +66,7 @@ def row_attention(att, x, pad, p_drop=0.0):
 def column_attention(att, x, pad, p_drop=0.0):
     """ColumnSelfAttention.compute_attention_update (axial_attention.py:190-240).  x [R,C,B,D]."""
     R, C, B, D = x.shape
-    H = 8
+    H = int(att.num_heads)
     dh = D // H
     if R == 1:
         return _lin(_lin(x, att.v_proj), att.out_proj)
@@ -92,13 +92,19 @@ def encode(model, onehot, pad):
     dev = next(model.parameters()).device
     x = _f32(onehot, dev)
     B, R, L, V = x.shape
-    if model.patch_size != 1:
-        raise NotImplementedError("patch_size 1 (the shipped model)")
-    if model.embed_dim != 64 or model.num_enc_heads != 8:
-        raise NotImplementedError("the Finetune operators cover the shipped model (embed_dim 64, 8 heads); narrower "
-                                  "models run in inference only")
-    model.patch_num = math.ceil(L / model.patch_size)
-    pad = None if pad is None else pad.to(dev)
+    # Any model the reference's constructor accepts runs here: the operators are strided, batched products and
+    # row-wise kernels of any width (the 64 x 64 weight-gradient kernel is a fast path taken by shape, train_ops.Linear),
+    # so the narrow models the inference path pads onto its 64-feature kernels -- the reference's defaults (utils.py:45-52:
+    # 32 features, 4 heads, patch 4) included -- need no padding here.
+    P = int(model.patch_size)
+    if L % P:
+        raise ValueError(f"{L} sites are not a multiple of patch_size {P} (the reference's rearrange fails the same way, model.py:76)")
+    model.patch_num = L // P
+    if P > 1:
+        x = x.view(B, R, L // P, P * V)                                        # 'b r (c k) e -> b r c (k e)'
+        pad = None if pad is None else pad[:, ::P]                              # model.py:81
+        L = L // P
+    pad = None if pad is None else pad.to(dev).contiguous()
     # activations the per-step scorer calls of a whole episode would keep (~14 tensors of [B, n, C, D] per step, twice:
     # decode and merge): beyond a third of the device they run under activation checkpointing too (see decode)
     import os
@@ -180,6 +186,8 @@ def decode(model, state, pad, info):
     dev = state.device
     B, n, C, D = state.shape
     actions_ij_prev, score_indices_to_prev, logits_prev = info
+    if pad is not None and int(model.patch_size) > 1:
+        pad = pad[:, :: int(model.patch_size)]                                  # the tokens' mask (model.py:163)
     keep = torch.ones((B, C), dtype=torch.float32, device=dev) if pad is None else (~pad.to(dev)).to(torch.float32)
     keep = keep.contiguous()
     state = state.contiguous()

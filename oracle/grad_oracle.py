@@ -33,10 +33,10 @@ def _keep(x, drop, kind):
     return x * m.to(x.dtype) / (1.0 - p)
 
 
-def row_attention(x, sd, pre, pad, drop=None):
+def row_attention(x, sd, pre, pad, drop=None, heads=8):
     """axial_attention.py:66-138 (grad mode: no chunking).  x [R,C,B,D]; pad bool [B,C]."""
     R, C, B, D = x.shape
-    H, dh = 8, D // 8
+    H, dh = heads, D // heads
     q = _lin(x, sd, pre + ".q_proj").view(R, C, B, H, dh) * (dh ** -0.5 / math.sqrt(R))        # :31-33, 77
     k = _lin(x, sd, pre + ".k_proj").view(R, C, B, H, dh)
     v = _lin(x, sd, pre + ".v_proj").view(R, C, B, H, dh)
@@ -50,10 +50,10 @@ def row_attention(x, sd, pre, pad, drop=None):
     return _lin(ctx, sd, pre + ".out_proj")
 
 
-def column_attention(x, sd, pre, pad, drop=None):
+def column_attention(x, sd, pre, pad, drop=None, heads=8):
     """axial_attention.py:190-240."""
     R, C, B, D = x.shape
-    H, dh = 8, D // 8
+    H, dh = heads, D // heads
     q = _lin(x, sd, pre + ".q_proj").view(R, C, B, H, dh) * dh ** -0.5                            # :214
     k = _lin(x, sd, pre + ".k_proj").view(R, C, B, H, dh)
     v = _lin(x, sd, pre + ".v_proj").view(R, C, B, H, dh)
@@ -65,15 +65,19 @@ def column_attention(x, sd, pre, pad, drop=None):
     return _lin(ctx, sd, pre + ".out_proj")
 
 
-def encode(sd, onehot, pad, layers, drop=None):
-    """model.py:67-88 + msa_modules.py:62-125.  drop None: eval mode (dropout = identity); else see _keep."""
+def encode(sd, onehot, pad, layers, drop=None, heads=8, patch=1):
+    """model.py:67-88 + msa_modules.py:62-125.  drop None: eval mode (dropout = identity); else see _keep.
+    pad: the TOKEN mask (the caller takes every patch-th site, model.py:81)."""
+    if patch > 1:                                                                                 # model.py:76: 'b r (c k) e -> b r c (k e)'
+        B_, R_, L_, V_ = onehot.shape
+        onehot = onehot.reshape(B_, R_, L_ // patch, patch * V_)
     x = _lin(F.gelu(_lin(onehot, sd, "embed.0")), sd, "embed.2")                                  # model.py:39-43
     x = x.permute(1, 2, 0, 3)
     for l in range(layers):
         pre = f"seq_emb_layers.{l}."
-        y = row_attention(_ln(x, sd, pre + "row_self_attention.layer_norm"), sd, pre + "row_self_attention.layer", pad, drop)
+        y = row_attention(_ln(x, sd, pre + "row_self_attention.layer_norm"), sd, pre + "row_self_attention.layer", pad, drop, heads)
         x = x + _keep(y, drop, "out")                                                              # msa_modules.py:119-120
-        y = column_attention(_ln(x, sd, pre + "column_self_attention.layer_norm"), sd, pre + "column_self_attention.layer", pad, drop)
+        y = column_attention(_ln(x, sd, pre + "column_self_attention.layer_norm"), sd, pre + "column_self_attention.layer", pad, drop, heads)
         x = x + _keep(y, drop, "out")
         y = _ln(x, sd, pre + "feed_forward_layer.layer_norm")
         y = _keep(F.gelu(_lin(y, sd, pre + "feed_forward_layer.layer.fc1")), drop, "act")          # msa_modules.py:148-149
@@ -111,14 +115,17 @@ def _rows(state, idx):
 
 
 def reinforce_loss(sd, onehot, pad, merges, tree_scores, baseline, temperature, strength, layers, dtype=torch.float64,
-                   drop=None):
+                   drop=None, heads=8, patch=1):
     """The loop of reinforce_rollout with eval=False (finetune_rl_search.py:78-189) on forced actions and the loss of
     RL_finetuning (:292-307).  sd: {name: tensor requiring grad}.  Returns (loss, tables)."""
     from neuralnj_amd import utils
     onehot = torch.as_tensor(onehot).to(dtype)
     pad = torch.as_tensor(pad).bool()
     B, T, L, _ = onehot.shape
-    state = encode(sd, onehot, pad, layers, drop)
+    if patch > 1:
+        pad = pad[:, ::patch]                                                                     # model.py:81
+        L = -(-L // patch)                                                                        # patch_num (model.py:72)
+    state = encode(sd, onehot, pad, layers, drop, heads, patch)
     keep = (~pad).to(dtype)
     merges = np.asarray(merges)
     table, tables, selected, ents = None, [], [], []

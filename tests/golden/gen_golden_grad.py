@@ -29,13 +29,14 @@ import gen_golden as gg  # noqa: E402
 
 
 def run_case(name, codes, mask, merges, wseed, style, layers, ref, tree_scores, baseline=0.25, temperature=1.0,
-             strength=0.01, train=False):
+             strength=0.01, train=False, dim=64, heads=8, patch=1):
     import torch
     import torch.nn.functional as F
     from neuralnj_amd import synth, weights
 
     frs, utils_mod, PGPI, PhyInferEnv = ref
     cfgs = gg.make_cfg(utils_mod, layers)
+    cfgs.model.embed_dim, cfgs.model.num_enc_heads, cfgs.model.patch_size = dim, heads, patch
     agent = PGPI(cfgs)
     st = weights.seeded_state(cfgs, wseed, style)
     agent.load_state_dict({k: torch.from_numpy(v) for k, v in st.items()}, strict=True)
@@ -103,6 +104,7 @@ def run_case(name, codes, mask, merges, wseed, style, layers, ref, tree_scores, 
     np.savez_compressed(out, codes=codes, mask=mask, merges=merges, tree_scores=tree_scores.astype(np.float32),
                         baseline=np.float32(baseline), temperature=np.float32(temperature), strength=np.float32(strength),
                         wseed=np.int64(wseed), style=np.array(style), layers=np.int64(layers), loss=np.float32(loss.item()),
+                        dim=np.int64(dim), heads=np.int64(heads), patch=np.int64(patch),
                         policy_loss=np.float32(policy_loss.item()), entropy_reg=np.float32(entropy_reg.item()),
                         grads=grads.astype(np.float32), enc=enc[:, :, ::8].astype(np.float32),
                         tables=np.concatenate([t.reshape(B, -1) for t in tables], axis=1).astype(np.float32),
@@ -122,7 +124,9 @@ def main():
     for name, src, layers, pad in (("b2_t8_l128_s0", "synth_b2_t8_l128_s0", 6, 0), ("b2_t6_l48_pad", None, 2, 5),
                                    ("b1_t20_l256_s1", "synth_b1_t20_l256_s1", 6, 0),
                                    ("b1_t50_l1024_s0", "synth_b1_t50_l1024_s0", 6, 0),       # the bench shape (minutes of CPU)
-                                   ("train_b2_t6_l48_pad", None, 2, 5)):                     # train() mode: dropout 0.4
+                                   ("train_b2_t6_l48_pad", None, 2, 5),                      # train() mode: dropout 0.4
+                                   # the reference's DEFAULT model (utils.py:45-52): 32 features, 4 heads, 3 layers, patch 4
+                                   ("dim32_b2_t6_l48_pad", None, 3, 8)):
         if only and name != only:
             continue
         if src is not None:
@@ -141,7 +145,8 @@ def main():
                     merges[b, s] = (i, j)
             wseed, style = 17, "plain"
         scores = np.array([0.8, -0.4], dtype=np.float32)[:codes.shape[0]]
-        run_case(name, codes, mask, merges, wseed, style, layers, ref, scores, train=name.startswith("train_"))
+        narrow = dict(dim=32, heads=4, patch=4) if name.startswith("dim32_") else {}
+        run_case(name, codes, mask, merges, wseed, style, layers, ref, scores, train=name.startswith("train_"), **narrow)
 
 
 if __name__ == "__main__":

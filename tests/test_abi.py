@@ -98,3 +98,22 @@ def test_state_dict_layout_matches_spec():
     assert [tuple(v.shape) for v in sd.values()] == [s for _, s in spec]
     assert list(sd.keys())[0] == "seq_emb_layers.0.row_self_attention.layer.k_proj.weight"
     assert list(sd.keys())[-1] == "s_out.2.bias"
+
+
+def test_workspace_regions_hold_every_launch_geometry():
+    """the first table of sampled replicas of ONE alignment is launched with the geometry of a batch
+    of one, whose star blocks can exceed the regions sized for the batch (T > 128, C >= 6000, B not a power of two).
+    Host-only check of every scorer launch of a rollout against the regions loop_ws reserves -- no device needed."""
+    from neuralnj_amd import _lib
+    lib = _lib.load_library()
+    assert lib.nnj_workspace_selfcheck(0, 8, 128) == -1
+    bad = []
+    for T in (2, 3, 17, 50, 64, 65, 100, 128, 129, 200, 256):
+        for Cn in (128, 1024, 4096, 6000, 8192):
+            for B in (1, 2, 3, 5, 6, 7, 8, 9, 11, 16, 64, 256):
+                if T > 64 and B > 16:
+                    continue
+                rc = lib.nnj_workspace_selfcheck(B, T, Cn)
+                if rc != 0:
+                    bad.append((B, T, Cn, rc))
+    assert not bad, bad

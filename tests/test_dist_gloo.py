@@ -93,3 +93,39 @@ def test_gradient_bucket_allreduce(tmp_path):
     want = np.concatenate([np.full(15, 3.0), np.arange(7) * 3.0, np.ones(4)])
     for r in range(world):
         assert np.array_equal(np.load(tmp_path / f"g{r}.npy"), want)
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_on_the_device_match_single_rank_runs(tmp_path):
+    """the REAL `bench.py --gpus 2` under torch.distributed.run, both ranks computing on the HIP library
+    (one-GPU rehearsal: NNJ_BENCH_SHARE_GPU=1 puts both ranks on cuda:0, the tiny collectives run over gloo) -- the weight
+    broadcast, per-rank shards, per-rank oracle verification, the all-reduced flags, the max-over-ranks timing and the
+    all-gathered merge lists, which must equal two single-rank runs of the same shards.  The launcher starts before
+    anything in the children touches the GPU; this process initialises no GPU context either."""
+    import json
+    import subprocess
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    shape = ["--batch", "16", "--taxa", "20", "--sites", "256", "--steps", "1", "--warmup", "1", "--no-cpu-baseline",
+             "--no-compat", "--no-single-msa"]
+    env = dict(os.environ, NNJ_BENCH_SHARE_GPU="1", NNJ_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    two = tmp_path / "two.npy"
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(repo, "bench.py"),
+                        "--gpus", "2", "--dump-merges", str(two)] + shape,
+                       cwd=repo, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([x for x in r.stdout.splitlines() if x.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak"
+    assert len(line["per_rank"]["trees_per_sec"]) == 2 and min(line["per_rank"]["trees_per_sec"]) > 0
+    assert line["value"] <= sum(line["per_rank"]["trees_per_sec"]) * 1.0001      # whole-job rate over the SLOWEST rank's time
+    v = line["verified"]
+    assert v["ok"] and v["all_ranks_ok"] and v["all_ranks_rf_gate_ok"] and v["ranks_verified"] == 2
+    got = np.load(two)
+    assert got.shape == (2, 16, 19, 2)
+    for rank in range(2):
+        one = tmp_path / f"one{rank}.npy"
+        r1 = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "1", "--data-rank", str(rank),
+                             "--no-verify", "--no-profile", "--dump-merges", str(one)] + shape,
+                            cwd=repo, env=dict(os.environ), capture_output=True, text=True, timeout=900)
+        assert r1.returncode == 0, r1.stderr[-2000:]
+        assert np.array_equal(np.load(one)[0], got[rank]), f"rank {rank}'s gathered merge lists differ from its single-rank run"

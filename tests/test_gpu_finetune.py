@@ -81,7 +81,8 @@ def test_operators_match_torch():
     _grad_pair(lambda a, b: T.Bmm.apply(a, b, False, 1.0), lambda a, b: a @ b, [R(1, 1, 3), R(1, 3, 4096)], tol=5e-5)
 
 
-@pytest.mark.parametrize("name", ["b2_t6_l48_pad", "b2_t8_l128_s0", "b1_t20_l256_s1", "b1_t50_l1024_s0"])
+@pytest.mark.parametrize("name", ["b2_t6_l48_pad", "b2_t8_l128_s0", "b1_t20_l256_s1", "b1_t50_l1024_s0",
+                                  "dim32_b2_t6_l48_pad"])      # the reference's default model: 32 / 4 heads / 3 layers / patch 4
 def test_finetune_gradients_match_the_reference(name):
     from neuralnj_amd.environment import PhyInferEnv
     from neuralnj_amd.model import PhyloATTN
@@ -89,6 +90,8 @@ def test_finetune_gradients_match_the_reference(name):
     z = np.load(os.path.join(GOLD, f"grad_{name}.npz"), allow_pickle=True)
     cfgs = utils.shipped_config()
     cfgs.model.num_enc_layers = int(z["layers"])
+    if "dim" in z.files:
+        cfgs.model.embed_dim, cfgs.model.num_enc_heads, cfgs.model.patch_size = int(z["dim"]), int(z["heads"]), int(z["patch"])
     agent = PhyloATTN(cfgs)
     sd = weights.seeded_state(cfgs, int(z["wseed"]), str(z["style"]))
     agent.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
