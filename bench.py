@@ -311,14 +311,19 @@ def finetune_episode(cfgs, T, L, dev):
 
 
 def search_config5(cfgs, packed, dev, replicas=8):
-    """BASELINE configs[4] beside the headline: infer_opt=Search at 200 taxa x 4096 sites -- `replicas` sampled rollouts of
-    ONE alignment (encoded once, nnj_rollout_sample), duplicate topologies dropped by the device-side keys.  A side
-    figure (scoring of the distinct trees by likelihood is the next stage of Search and is not in this number)."""
+    """BASELINE configs[4] beside the headline: infer_opt=Search at 200 taxa x 4096 sites.  Two figures:
+      s_per_round               `replicas` sampled rollouts of ONE alignment (encoded once, nnj_rollout_sample) + the device-side
+                                topology keys -- the sampling half of a round;
+      s_per_round_with_scoring  a COMPLETE round of the reference's RL_Search (finetune_rl_search.py:338-427) through
+                                neuralnj_amd.rollout.search_rollouts: sample, drop duplicate topologies, estimate the GTR+I+G
+                                parameters (`opt_model=True`), optimise the branch lengths in three sweeps (`iters=3`), score
+                                every distinct tree on the GPU (nnj_tree_optimize), rank, build the host trees."""
     try:
         g5 = Nnj(cfgs, dev)
         g5.load_weights(packed)
         T5, L5 = 200, 4096
-        one = torch.from_numpy(synth.synth_codes_tree(1, T5, L5, seed=4242)).to(dev)
+        c5 = synth.synth_codes_tree(1, T5, L5, seed=4242)
+        one = torch.from_numpy(c5).to(dev)
         u = torch.from_numpy(np.random.default_rng(5).random((replicas, T5 - 1)).astype(np.float32))
         g5.rollout_sample(one, None, u, temperature=1.0, replicas=replicas)["merges"].cpu()
         torch.cuda.synchronize(dev)
@@ -331,6 +336,28 @@ def search_config5(cfgs, packed, dev, replicas=8):
         out = {"workload": f"Search mode, {T5} taxa x {L5} sites, {replicas} sampled rollouts of one alignment (BASELINE configs[4])",
                "s_per_round": dt, "rollouts_per_sec": replicas / dt, "distinct_topologies": int(torch.unique(keys).numel())}
         g5.close()
+        from neuralnj_amd.environment import PhyInferEnv
+        from neuralnj_amd.model import PhyloATTN
+        from neuralnj_amd.rollout import search_rollouts
+        agent = PhyloATTN(cfgs)
+        sd = weights.seeded_state(cfgs, 0, "sharp")
+        agent.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+        agent = agent.to(dev)
+        batch = {"codes": torch.from_numpy(c5), "seqs": [[""] * T5], "seq_keys": [[f"taxon{i + 1}" for i in range(T5)]],
+                 "seq_weights": torch.ones((1, L5), dtype=torch.float32)}
+        times = []
+        for rep in range(2):                                  # (the first round also sizes the workspaces)
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            det = {}
+            _, best_ll, trees = search_rollouts(batch, agent, PhyInferEnv(cfgs, dev), replicas, seed=5, temperature=1.0,
+                                                model="auto", sweeps=3, details=det)
+            torch.cuda.synchronize(dev)
+            times.append(time.perf_counter() - t0)
+        out.update(s_per_round_with_scoring=times[-1], first_round_s=times[0], trees_scored=len(trees),
+                   best_loglik=float(best_ll),
+                   scoring="GTR+I+G by maximum likelihood on the most sampled topology (2 rounds of bounded Brent searches), "
+                           "3 Gauss-Seidel sweeps of Newton branch lengths per tree, fp64 pruning (DESIGN.md 11)")
         return out
     except Exception as e:                                    # pragma: no cover
         return {"error": f"{type(e).__name__}: {e}"}

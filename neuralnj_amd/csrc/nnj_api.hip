@@ -18,7 +18,7 @@
 #include "nnj_scorer.hpp"
 #include "nnj_scorer16.hpp"
 #include "nnj_scorer_wide.hpp"
-#include "nnj_step2.hpp"
+#include "nnj_step_g.hpp"
 #include "nnj_likelihood.hpp"
 
 namespace {
@@ -734,6 +734,24 @@ int launch_step2(nnj_handle* h, RowSet rs, const int* live_old, const int* ij, c
     if (int rc = set_lds(h, (k_step_alpha_w<NT, NW>), lds)) return rc;                                          \
     hipLaunchKernelGGL((k_step_alpha_w<NT, NW>), grid, dim3(64 * NW), lds, st, rs, sw, io, n, C, g.cs);         \
   } break;
+    // shared tiles + the merged rows of a group of sites as one tile (nnj_step_g.hpp).  NNJ_ALPHA_G: bit mask of the
+    // tiers that use it (as NNJ_SCORE_G): 1 = up to 4 pairs (four sites per group), 2 = 5..8 (two), 4 = 17..24 (two),
+    // 8 = the remaining tiers with one site per group
+    static const int alpha_g = getenv("NNJ_ALPHA_G") ? atoi(getenv("NNJ_ALPHA_G")) : 0;
+#define NNJ_AG(NT, G, IR, NW)                                                                                   \
+  {                                                                                                            \
+    const size_t lds = (size_t)step_alpha_g_lds(NT, G, IR, NW) * sizeof(float);                                \
+    if (int rc = set_lds(h, (k_step_alpha_g<NT, G, IR, NW>), lds)) return rc;                                  \
+    hipLaunchKernelGGL((k_step_alpha_g<NT, G, IR, NW>), grid, dim3(64 * NW), lds, st, rs, sw, io, n, C, g.cs); \
+  }
+    if (n > 2 && np <= 4 && (alpha_g & 1)) NNJ_AG(1, 4, 8, 8)
+    else if (n > 2 && np > 4 && np <= 8 && (alpha_g & 2)) NNJ_AG(1, 2, 8, 8)
+    else if (np > 16 && np <= 24 && (alpha_g & 4)) NNJ_AG(3, 2, 24, 8)
+    else if (n > 2 && np <= 16 && (alpha_g & 8)) NNJ_AG(1, 1, 16, 8)
+    else if (np > 16 && np <= 32 && (alpha_g & 8)) NNJ_AG(2, 1, 32, 8)
+    else if (np > 32 && np <= 48 && (alpha_g & 8)) NNJ_AG(3, 1, 48, 8)
+    else
+#undef NNJ_AG
     if (h->step_w && (ng == 2 || ng == 3)) {
       switch (ng) { NNJ_SW(2, 8) NNJ_SW(3, 8) }
     } else {
@@ -755,6 +773,27 @@ int launch_step2(nnj_handle* h, RowSet rs, const int* live_old, const int* ij, c
   {
     Scope sc(h, st, PK_PAIR_SCORE_INCR);
     const dim3 blk16(64 * T16_WAVES);
+    // shared 16-pair tiles (nnj_scorer_g.hpp): G sites per tile group where the pairs of one site leave a tile part
+    // empty.  NNJ_SCORE_G is a bit mask of the tiers that use it: 1 = up to 4 pairs (four sites per tile), 2 = 5..8 (two),
+    // 4 = 17..24 (three tiles for two sites), 8 = the remaining tiers with one site per group (its transposed-read
+    // image alone, for comparisons)
+    static const int score_g = getenv("NNJ_SCORE_G") ? atoi(getenv("NNJ_SCORE_G")) : 22;
+#define NNJ_SG(NT, G, IR, NW, ...)                                                                              \
+  {                                                                                                            \
+    const size_t lds = (size_t)inc_score_g_lds(NT, G, IR, NW) * sizeof(float);                                 \
+    if (int rc = set_lds(h, (k_inc_score_g<NT, G, IR, NW, ##__VA_ARGS__>), lds)) return rc;                    \
+    hipLaunchKernelGGL((k_inc_score_g<NT, G, IR, NW, ##__VA_ARGS__>), grid, dim3(64 * NW), lds, st, rs, sw, ij, \
+                       base + w.alpha, mask, base + w.score_part, n, C, g.cs);                                 \
+  }
+    if (has_ctx && np <= 4 && (score_g & 16)) NNJ_SG(1, 4, 8, 8)
+    else if (has_ctx && np <= 4 && (score_g & 1)) NNJ_SG(1, 4, 8, 12, 1)
+    else if (has_ctx && np <= 8 && np > 4 && (score_g & 2)) NNJ_SG(1, 2, 8, 12)
+    else if (np > 16 && np <= 24 && (score_g & 4)) NNJ_SG(3, 2, 24, 8)
+    else if (has_ctx && np <= 16 && (score_g & 8)) NNJ_SG(1, 1, 16, 12)
+    else if (np > 16 && np <= 32 && (score_g & 8)) NNJ_SG(2, 1, 32, 8)
+    else if (np > 32 && np <= 48 && (score_g & 8)) NNJ_SG(3, 1, 48, 8)
+    else
+#undef NNJ_SG
     if (np <= 16) {
       const size_t lds = (size_t)(3 * IMG64 + T16_WAVES * 512 * NPL + 16 + SCORER_CONSTS) * sizeof(float);
       if (has_ctx) {

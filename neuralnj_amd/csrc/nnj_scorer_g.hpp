@@ -1,0 +1,260 @@
+// nnj_scorer_g.hpp -- scores of the new pairs of an NJ step with SHARED 16-pair tiles (round 4).
+//
+// k_inc_score16 / k_inc_score_w give every site its own ceil(P / 16) tiles (P = n - 1 new pairs): over the 48 steps of a
+// 50-taxon rollout 23 % of the pair columns are padding, and the time of these kernels follows the number of tiles, not
+// the number of pairs (0.54 ms per step for every P <= 16, 1.10 for 17..32, 1.82 for 33..48 at a batch of 256).  Here a
+// wave owns G consecutive sites at a time and lays their G * P pairs out as ONE column list q2 = g * P + p over
+// NT = ceil(G P / 16) tiles: P <= 4 -> four sites per tile, P <= 8 -> two, 17..24 pairs -> three tiles for two sites
+// instead of four.  Everything of the chain is column local (gate, W_g, mix, s_out, GELU: the weights are shared) except
+// the context x_g^T = S^T alpha^T, whose A operand is the image of the COLUMN's site: a tile that holds columns of
+// several sites runs that product once per site with the alpha fragments of the other sites' columns replaced by zeros
+// (more MFMAs on a pipe that idles, no vector work).
+//
+// The site image is stored ROW MAJOR -- [2 planes][IR rows r'][64 d] fp16, a lane writes the pieces of its own row as
+// four 8-byte granules per plane -- and read TRANSPOSED by ds_read_b64_tr_b16 (cdna_hip_programming.md T10): the
+// 16 scalar ds_write_b16 per plane, tile and lane of the older kernels (and their address arithmetic) are gone.
+// Granule (row r, unit v = feature / 4) sits at unit v ^ bp(r & 15), bp = the row's low four bits with bits 1 and 2
+// exchanged: the 16 rows of a store group land on 16 different granule positions (conflict free on the 32-bank write
+// path) and the eight rows {r0 .. r0+3, r0+8 .. r0+11} a 32-lane half of a transposed read covers land on all 64 banks.
+#pragma once
+#include "nnj_step2.hpp"
+
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+template <int OFF>
+__device__ __forceinline__ void lds_read_tr16(u32x2& d, unsigned byte_addr) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(d) : "v"(byte_addr), "n"(OFF) : "memory");
+#endif
+}
+__device__ __forceinline__ int img_bp(int r) { return (r & 9) | ((r & 2) << 1) | ((r & 4) >> 1); }
+
+// xg[mt] += S^T alpha^T for one site image at LDS byte address `base`.  `ro` = the lane's two read offsets (sec = 0, 1:
+// rows 8 kq + 4 sec + (l15 >> 2), granule l15 & 3, swizzled; the row tile mt is an XOR of bits 5..6), `bfr` = the alpha
+// fragments of the lane's column (zeros where the column belongs to another site).  Reads PF row tiles ahead.
+template <int N>
+__device__ __forceinline__ void lds_wait_le_nb() {   // counted LDS wait without a scheduling barrier: the consumers below are
+#if defined(__HIP_DEVICE_COMPILE__)                  // pinned behind it one by one (pin_frag), everything else may move
+  asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
+#endif
+}
+template <int KSX, int PLB, int PF>
+__device__ __forceinline__ void xg_from_image(f32x4 (&xg)[4], unsigned base, const unsigned (&ro)[2],
+                                              const Frag3 (&bfr)[KSX]) {
+  constexpr int NS = 4 * KSX;                              // step s: ks = s / 4, mt = s % 4
+  u32x2 ah[PF][2], am[PF][2];                              // [buffer][sec]
+  auto issue = [&](auto si) {
+    constexpr int s = decltype(si)::value;
+    if constexpr (s < NS) {
+      constexpr int ks = s / 4, mt = s % 4;
+      const unsigned a0 = base + (ro[0] ^ (32u * mt)), a1 = base + (ro[1] ^ (32u * mt));
+      lds_read_tr16<ks * 4096>(ah[s % PF][0], a0);
+      lds_read_tr16<ks * 4096>(ah[s % PF][1], a1);
+      lds_read_tr16<ks * 4096 + PLB>(am[s % PF][0], a0);
+      lds_read_tr16<ks * 4096 + PLB>(am[s % PF][1], a1);
+    }
+  };
+  static_for<0, PF>([&](auto si) { issue(si); });
+  static_for<0, NS>([&](auto si) {
+    constexpr int s = decltype(si)::value;
+    constexpr int ks = s / 4, mt = s % 4;
+    constexpr int ahead = (s + PF - 1 < NS - 1 ? s + PF - 1 : NS - 1) - s;      // steps whose reads are younger than step s
+    lds_wait_le_nb<4 * ahead>();
+    Frag3 a;
+    a.h = (u32x4){ah[s % PF][0][0], ah[s % PF][0][1], ah[s % PF][1][0], ah[s % PF][1][1]};
+    a.m = (u32x4){am[s % PF][0][0], am[s % PF][0][1], am[s % PF][1][0], am[s % PF][1][1]};
+    pin_frag(a);
+    xg[mt] = mfma16_b6(a, bfr[ks], xg[mt]);
+    issue(std::integral_constant<int, s + PF>{});
+  });
+}
+
+// which sites of a group can own columns of tile t (compile time: the launch guarantees the pair range of a tier):
+// one site per group: itself; one tile per group: all G; three tiles for two sites (17..24 pairs): {0}, {0,1}, {1}
+template <int NT, int G>
+__host__ __device__ constexpr int tile_glo(int t) { return (G == 1 || NT == 1) ? 0 : (t == 2 ? 1 : 0); }
+template <int NT, int G>
+__host__ __device__ constexpr int tile_ghi(int t) { return G == 1 ? 0 : (NT == 1 ? G - 1 : (t == 0 ? 0 : 1)); }
+
+// NT tiles per group of G sites, images of IR rows (IR >= P, a multiple of 8), NW waves per workgroup.
+// part[b][sc][pair p].  Requires n >= 3 (a context exists) and G (n - 1) <= 16 NT.
+template <int NT, int G, int IR, int NW, int PF = 2>
+__global__ __launch_bounds__(64 * NW) void k_inc_score_g(RowSet rs, ScorerW w, const int* __restrict__ ij_prev,
+                                                        const float* __restrict__ alpha,
+                                                        const uint8_t* __restrict__ mask,
+                                                        float* __restrict__ score_part, int n, int C, int cs) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int WPF = 2;
+  constexpr int KSX = (IR + 31) / 32;                      // k-steps of the x_g product (32 r' each)
+  constexpr int PLB = IR * 128;                            // bytes of an image plane
+  constexpr int SITEB = 2 * PLB;                           // bytes of a site image
+  constexpr int IMGF = G * SITEB / 4;                      // floats of a wave's images
+  constexpr int SLACK = (32 * KSX - IR) * 32 + 32 + 64;    // floats behind the last image: zeroed slack (rows IR .. 32 KSX - 1 of it) + 256 B where padding columns write
+  static_assert(G == 1 || NT == 1 || (NT == 3 && G == 2), "tile_glo / tile_ghi know these groupings");
+  constexpr int APR = 16 * NT;                             // alpha rows in LDS (+ a zero row at APR)
+  constexpr int APN = APR + 1;                             // rows of an alpha plane in LDS
+  constexpr int APL = APN * 64;                            // fp16 elements of an alpha plane
+  float* Wg_l = smem;
+  float* S0_l = smem + IMG64;
+  float* Wh_l = smem + 2 * IMG64;
+  const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, kq = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  float* imgs = smem + 3 * IMG64;
+  float* cv = imgs + NW * IMGF + SLACK;
+  unsigned short* alds = reinterpret_cast<unsigned short*>(cv + SCORER_CONSTS);
+  const int sc = blockIdx.x, b = blockIdx.y;
+  const int c0 = sc * cs, c1 = min(C, c0 + cs);
+  const int P = n - 1;
+  stage_weight_t16(Wg_l, w.Wg, 64, tid, 64 * NW);
+  stage_weight_t16(S0_l, w.S0, 64, tid, 64 * NW);
+  stage_weight_t16(Wh_l, w.Wh, 64, tid, 64 * NW);
+  stage_scorer_consts(cv, w, tid);
+  // image rows beyond the pairs are never written: they meet alpha = 0 and must be finite
+  for (int i = tid; i < NW * IMGF + SLACK; i += 64 * NW) imgs[i] = 0.f;
+  {
+    const long apl = (long)gridDim.y * 4096;
+    const unsigned short* ag = reinterpret_cast<const unsigned short*>(alpha) + (size_t)b * 4096;
+    for (int i = tid; i < 2 * APN * 8; i += 64 * NW) {                     // 16-byte chunks of both planes
+      const int pl = i / (APN * 8), rc = i % (APN * 8), r = rc >> 3, ch = rc & 7;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (r < APR) v = *reinterpret_cast<const u32x4*>(ag + pl * apl + r * 64 + 8 * ch);
+      *reinterpret_cast<u32x4*>(alds + pl * APL + r * 64 + 8 * (ch ^ (r & 7))) = v;
+    }
+  }
+  __syncthreads();
+  const size_t bo = (size_t)b * rs.bstride;
+  const int m = min(max(ij_prev[2 * b], 0), n - 1);
+  const float* Sm = rs.S + bo + (size_t)slot_of(rs, b, m) * C * 64;
+  const float* Um = rs.U + bo + (size_t)slot_of(rs, b, m) * C * 64;
+  const unsigned img0 = lds_addr(imgs) + (unsigned)wave * (unsigned)(G * SITEB);
+  char* imw = reinterpret_cast<char*>(imgs) + wave * (G * SITEB);
+  // ---- per tile and lane: the column (site g of the group, pair p)
+  const float* Sr[NT];
+  float sgn[NT], score[NT];
+  int gq[NT], pq[NT];
+  unsigned wo[NT], wm[NT];                                 // image write offset of the lane's row; distance of its m plane
+  bool valid[NT];
+  const unsigned dump = (unsigned)((NW - wave) * (G * SITEB)) + (unsigned)((32 * KSX - IR) * 128 + 128);   // (from imw)
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int q2 = 16 * t + l15;
+    int g = 0;
+#pragma unroll
+    for (int k = 1; k < G; ++k) g += q2 >= k * P ? 1 : 0;
+    g += q2 >= G * P ? 1 : 0;                              // g == G: a padding column
+    valid[t] = g < G;
+    if (!valid[t]) g = 0;
+    const int p = valid[t] ? q2 - g * P : 0;
+    const int r = q_to_r(p, m);
+    gq[t] = g; pq[t] = p;
+    sgn[t] = r < m ? 1.0f : -1.0f;
+    score[t] = 0.f;
+    Sr[t] = rs.S + bo + (size_t)slot_of(rs, b, r) * C * 64;
+    // a padding column writes its (finite, never read) pieces to the dump line instead of branching around the stores
+    wo[t] = valid[t] ? (unsigned)(g * SITEB + p * 128) + 8u * (unsigned)(kq ^ img_bp(p & 15)) : dump + 8u * (unsigned)kq;
+    wm[t] = valid[t] ? (unsigned)PLB : 128u;
+  }
+  // read bases of the transposed fragments (site 0 of the group): row 8 kq + 4 sec + (l15 >> 2), unit l15 & 3
+  unsigned ro[2];
+#pragma unroll
+  for (int sec = 0; sec < 2; ++sec) {
+    const int row = 8 * kq + 4 * sec + (l15 >> 2);
+    ro[sec] = (unsigned)(row * 128) + 8u * (unsigned)((l15 & 3) ^ img_bp(row & 15));
+  }
+  for (int cg = c0 + G * wave; cg < c1; cg += G * NW) {
+    asm volatile("" ::: "memory");
+    V64 x[NT];
+    float mc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int cs_ = min(cg + gq[t], c1 - 1);                             // (sites beyond the chunk: clamped, weight 0)
+      mc[t] = (!valid[t] || cg + gq[t] >= c1 || mask[(size_t)b * C + cs_]) ? 0.f : 1.f;   // seq_mask (model.py:96)
+      V64 sr, sm, um;
+      load_v64(sr, Sr[t] + (size_t)cs_ * 64, kq);
+      load_v64(sm, Sm + (size_t)cs_ * 64, kq);
+      load_v64(um, Um + (size_t)cs_ * 64, kq);
+      Frag3 sf[2];
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) split_8<false>(sf[ks], sr.t[2 * ks], sr.t[2 * ks + 1]);
+      V64 ur;
+      gate_init16(ur, um, cv, sgn[t], kq);
+      linear_t16p_core<4, WPF>(ur.t, sf, Wh_l, lane, [] {});
+      gate16(x[t], sr, ur, sm);
+      // the lane's row of its site's image: features 32 ks + 16 u + 4 kq .. + 3 = granule 4 (2 ks + u) + kq
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const unsigned o = wo[t] ^ (32u * (2 * ks + u));
+          *reinterpret_cast<u32x2*>(imw + o) = (u32x2){sf[ks].h[2 * u], sf[ks].h[2 * u + 1]};
+          *reinterpret_cast<u32x2*>(imw + o + wm[t]) = (u32x2){sf[ks].m[2 * u], sf[ks].m[2 * u + 1]};
+        }
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // ---- per tile: x_g^T = S^T alpha^T (once per site the tile's columns belong to), W_g, mix, s_out
+    static_for<0, NT>([&](auto tc) {
+      constexpr int t = decltype(tc)::value;
+      V64 xg, gg;
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) xg.t[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      static_for<tile_glo<NT, G>(t), tile_ghi<NT, G>(t) + 1>([&](auto gic) {
+        constexpr int gi = decltype(gic)::value;
+        Frag3 bfr[KSX];
+        const int ar = (valid[t] && gq[t] == gi) ? pq[t] : APR;           // other sites' columns: the zero row
+#pragma unroll
+        for (int ks = 0; ks < KSX; ++ks) {
+          const unsigned short* ap_ = alds + ar * 64 + 8 * ((4 * ks + kq) ^ (ar & 7));
+          bfr[ks].h = *reinterpret_cast<const u32x4*>(ap_);
+          bfr[ks].m = *reinterpret_cast<const u32x4*>(ap_ + APL);
+        }
+        xg_from_image<KSX, PLB, PF>(xg.t, img0 + (unsigned)(gi * SITEB), ro, bfr);
+      });
+      linear_t16p<4, false, true, WPF, false>(gg.t, xg, Wg_l, cv + 64, lane);
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float wg = sigmoid_l2(gg.t[mt][e]);
+          x[t].t[mt][e] += wg * (xg.t[mt][e] - x[t].t[mt][e]);            // (1-w)*x + w*x_g
+        }
+      V64 s1;
+      linear_t16p<4, false, true, WPF, false>(s1.t, x[t], S0_l, cv + 128, lane);
+      f32x2v s2 = {0.f, 0.f};
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) {
+        const f32x4 w4 = *reinterpret_cast<const f32x4*>(cv + 192 + 16 * mt + 4 * kq);
+        gelu_dot4(s2, s1.t[mt], w4);
+      }
+      float s = s2[0] + s2[1];
+      s += __shfl_xor(s, 16);
+      s += __shfl_xor(s, 32);
+      score[t] += (s + w.s2b) * mc[t];
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+    });
+  }
+  // one partial set per WORKGROUP: per wave the columns of a pair are added site by site, then the waves in wave order
+  __syncthreads();
+  float* red = smem + 3 * IMG64;                           // [NW][64] (the images are dead)
+  red[wave * 64 + lane] = 0.f;
+  __syncthreads();
+  for (int gi = 0; gi < G; ++gi) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+      if (kq == 0 && valid[t] && gq[t] == gi) red[wave * 64 + pq[t]] += score[t];
+    asm volatile("" ::: "memory");
+  }
+  __syncthreads();
+  if (tid < 64) {
+    float v = 0.f;
+#pragma unroll
+    for (int s_ = 0; s_ < NW; ++s_) v += red[s_ * 64 + tid];
+    score_part[((size_t)b * gridDim.x + sc) * 64 + tid] = v;
+  }
+}
+
+// floats of dynamic LDS k_inc_score_g<NT, G, IR, NW> needs
+constexpr int inc_score_g_lds(int NT, int G, int IR, int NW) {
+  return 3 * IMG64 + NW * G * IR * 64 + ((32 * ((IR + 31) / 32) - IR) * 32 + 32 + 64) + SCORER_CONSTS + 2 * (16 * NT + 1) * 32;
+}

@@ -343,24 +343,27 @@ __global__ __launch_bounds__(256) void k_sum_rows(const float* __restrict__ x, f
   if (rg == 0 && c < cols) out[c] = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
 }
 
-// ------------------------------------------------------------------ LayerNorm over 64 features: one wavefront per row
+// ------------------------------------------------------------------ LayerNorm over D <= 64 features: one wavefront per row
+// (lane = feature; the lanes beyond a narrower model's width add nothing to the sums)
 __global__ __launch_bounds__(256) void k_ln_fwd(const float* __restrict__ x, const float* __restrict__ gamma,
                                                 const float* __restrict__ beta, float* __restrict__ y,
-                                                float* __restrict__ mean, float* __restrict__ rstd, int64_t rows) {
+                                                float* __restrict__ mean, float* __restrict__ rstd, int64_t rows, int D) {
   const int lane = threadIdx.x & 63;
   const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (r >= rows) return;
-  const float v = x[r * 64 + lane];
+  const bool in = lane < D;
+  const float inv_d = 1.0f / (float)D;
+  const float v = in ? x[r * D + lane] : 0.f;
   float s = v;
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o);
-  const float mu = s * (1.0f / 64.0f);
-  const float d = v - mu;
+  const float mu = s * inv_d;
+  const float d = in ? v - mu : 0.f;
   float q = d * d;
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) q += __shfl_xor(q, o);
-  const float rs = rsqrtf(q * (1.0f / 64.0f) + 1e-5f);
-  y[r * 64 + lane] = d * rs * gamma[lane] + beta[lane];
+  const float rs = rsqrtf(q * inv_d + 1e-5f);
+  if (in) y[r * D + lane] = d * rs * gamma[lane] + beta[lane];
   if (lane == 0) { mean[r] = mu; rstd[r] = rs; }
 }
 // dx = rstd * (g - mean(g) - xhat * mean(g * xhat)), g = dy * gamma; dgamma += sum dy * xhat; dbeta += sum dy.
@@ -368,24 +371,28 @@ __global__ __launch_bounds__(256) void k_ln_fwd(const float* __restrict__ x, con
 __global__ __launch_bounds__(256) void k_ln_bwd(const float* __restrict__ dy, const float* __restrict__ x,
                                                 const float* __restrict__ gamma, const float* __restrict__ mean,
                                                 const float* __restrict__ rstd, float* __restrict__ dx,
-                                                float* dgamma, float* dbeta, int64_t rows) {
+                                                float* dgamma, float* dbeta, int64_t rows, int D) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const float gm = gamma[lane];
+  const bool in = lane < D;
+  const float inv_d = 1.0f / (float)D;
+  const float gm = in ? gamma[lane] : 0.f;
   float ag = 0.f, ab = 0.f;
   const int64_t r0 = ((int64_t)blockIdx.x * 4 + wave) * 64;
   for (int64_t r = r0; r < r0 + 64 && r < rows; ++r) {
-    const float xh = (x[r * 64 + lane] - mean[r]) * rstd[r];
-    const float d = dy[r * 64 + lane];
+    const float xh = in ? (x[r * D + lane] - mean[r]) * rstd[r] : 0.f;
+    const float d = in ? dy[r * D + lane] : 0.f;
     const float g = d * gm;
     float s1 = g, s2 = g * xh;
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
-    dx[r * 64 + lane] = rstd[r] * (g - s1 * (1.0f / 64.0f) - xh * s2 * (1.0f / 64.0f));
+    if (in) dx[r * D + lane] = rstd[r] * (g - s1 * inv_d - xh * s2 * inv_d);
     ag += d * xh;
     ab += d;
   }
-  atomicAdd(dgamma + lane, ag);
-  atomicAdd(dbeta + lane, ab);
+  if (in) {
+    atomicAdd(dgamma + lane, ag);
+    atomicAdd(dbeta + lane, ab);
+  }
 }
 
 // ------------------------------------------------------------------ elementwise
@@ -588,17 +595,17 @@ int nnjt_sum_rows(const float* x, float* out, int64_t rows, int64_t cols, void* 
 }
 int nnjt_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
                        int64_t rows, int32_t cols, void* stream) {
-  if (cols != 64) return fail(-2, "nnjt_layernorm: 64 features (embed_dim of the shipped model), got %d", cols);
+  if (cols < 1 || cols > 64) return fail(-2, "nnjt_layernorm: 1 .. 64 features (one lane per feature), got %d", cols);
   hipLaunchKernelGGL(k_ln_fwd, dim3(blocks_for(rows, 4)), dim3(256), 0, static_cast<hipStream_t>(stream), x, gamma, beta, y,
-                     mean, rstd, rows);
+                     mean, rstd, rows, (int)cols);
   CHK_LAUNCH();
   return 0;
 }
 int nnjt_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
                        float* dx, float* dgamma, float* dbeta, int64_t rows, int32_t cols, void* stream) {
-  if (cols != 64) return fail(-2, "nnjt_layernorm: 64 features, got %d", cols);
+  if (cols < 1 || cols > 64) return fail(-2, "nnjt_layernorm: 1 .. 64 features, got %d", cols);
   hipLaunchKernelGGL(k_ln_bwd, dim3(blocks_for(rows, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), dy, x, gamma,
-                     mean, rstd, dx, dgamma, dbeta, rows);
+                     mean, rstd, dx, dgamma, dbeta, rows, (int)cols);
   CHK_LAUNCH();
   return 0;
 }

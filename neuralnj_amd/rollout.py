@@ -127,7 +127,8 @@ def sample_rollouts(batch, agent, env, n_rollouts, seed=0, temperature=1.0, devi
     return trees, merges
 
 
-def search_rollouts(batch, agent, env, n_rollouts, seed=0, temperature=1.0, model=None, sweeps=3, device=None):
+def search_rollouts(batch, agent, env, n_rollouts, seed=0, temperature=1.0, model=None, sweeps=3, device=None,
+                    details=None):
     """One round of the reference's RL_Search / "NeuralNJ-MC" (finetune_rl_search.py:338-427) on the GPU: sample
     `n_rollouts` trees of ONE alignment (encoded once), drop duplicate topologies (device keys), optimise the branch
     lengths of the distinct trees and score them by log-likelihood under GTR+I+G (neuralnj_amd.likelihood, where the
@@ -160,6 +161,10 @@ def search_rollouts(batch, agent, env, n_rollouts, seed=0, temperature=1.0, mode
     env.init_states([batch["seqs"][0]] * k, [batch["seq_keys"][0]] * k, None)
     env.apply_merges(m_np, br_np, ll_np)
     trees = [(st.subtrees[0].utree_op_str, float(s), int(c)) for st, s, c in zip(env.states, ll_np, cnt)]
+    if details is not None:
+        # what the round scored, best first (tests feed it to the likelihood oracle): merge lists, optimised branch
+        # lengths, log-likelihoods, multiplicities and the substitution model they were scored under
+        details.update(merges=m_np, brlen=br_np, loglik=ll_np, counts=cnt, model=model, rollouts=int(n_rollouts))
     return trees[0][0], trees[0][1], trees
 
 

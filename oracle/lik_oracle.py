@@ -97,6 +97,39 @@ def tree_loglik(codes, merges, brlen, model, mask=None):
     return total
 
 
+def tree_loglik_sites(codes, merges, brlen, model, mask=None):
+    """The same pruning recursion as tree_loglik with the SITES as an array axis (numpy float64): what makes one
+    200 x 4096 tree a second of CPU instead of minutes.  Pinned to the per-site loop above in tests/test_likelihood.py."""
+    codes = np.asarray(codes).astype(np.int64)
+    T, L = codes.shape
+    Q, pi = rate_matrix(model["rates"], model["freqs"])
+    rates = gamma_rates(model["alpha"], model["ncat"])
+    pinv = model["pinv"]
+    prog = program(merges, T)
+    if brlen is None:
+        brlen = np.full((T - 1, 2), 0.1)
+    tips = np.zeros((T, L, 4))
+    for k in range(4):
+        tips[:, :, k] = (codes == k) | (codes > 3)
+    lik = np.zeros(L)
+    for r in rates:
+        part = {}
+        for s, (a, b) in enumerate(prog):
+            Pa, Pb = expm(Q * r * float(brlen[s][0])), expm(Q * r * float(brlen[s][1]))
+            xa = tips[a] if a < T else part.pop(a)
+            xb = tips[b] if b < T else part.pop(b)
+            part[T + s] = (xa @ Pa.T) * (xb @ Pb.T)
+        lik += part[2 * T - 2] @ pi
+    lik *= (1.0 - pinv) / len(rates)
+    obs = np.where(codes <= 3, codes, -1)
+    first = obs.max(0)
+    const = ((obs == first[None]) | (obs < 0)).all(0)            # every taxon shows the same state or a gap
+    inv = np.where(const, np.where(first >= 0, pi[np.maximum(first, 0)], 1.0), 0.0)
+    lik += pinv * inv
+    keep = np.ones(L, bool) if mask is None else ~np.asarray(mask, bool)
+    return float(np.log(lik[keep]).sum())
+
+
 def brute_force_loglik(codes, merges, brlen, model):
     """Sum over every assignment of states to the internal nodes (tiny trees only): no pruning, no recursion."""
     T, L = codes.shape

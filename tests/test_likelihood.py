@@ -52,6 +52,23 @@ def test_oracle_pruning_equals_brute_force_and_gamma_rates():
     assert abs(LO.tree_loglik(codes, merges, br2, GTR) - a) < 1e-10
 
 
+def test_oracle_site_vectorised_form_equals_the_site_loop():
+    """tree_loglik_sites (sites as an array axis: the oracle of the configs[4] Search test) == the per-site recursion."""
+    rng = np.random.default_rng(11)
+    for (T, L, model) in ((2, 9, JC), (6, 50, GTR), (13, 41, dict(GTR, ncat=6)), (9, 33, dict(GTR, pinv=0.0, alpha=0.0, ncat=1))):
+        codes = rng.integers(0, 6, size=(T, L)).astype(np.uint8)
+        codes[:, :5] = codes[:1, :5]                           # constant columns (the +I term), some of them gaps only
+        codes[:, 5] = 4
+        mask = np.zeros(L, bool)
+        mask[-4:] = True
+        merges = _random_tree(T, rng)
+        br = rng.uniform(0.01, 0.5, size=(T - 1, 2))
+        for mk in (None, mask):
+            a = LO.tree_loglik(codes, merges, br, model, mk)
+            b = LO.tree_loglik_sites(codes, merges, br, model, mk)
+            assert abs(a - b) <= 1e-10 * max(1.0, abs(a)), (T, L, a, b)
+
+
 @pytest.mark.gpu
 def test_hip_loglik_matches_numpy_oracle():
     import torch
