@@ -569,7 +569,25 @@ def main():
                     meas_total = (sum(mt * prof[k][1] / prof_steps for k, mt in
                                       zip([k for k in step_kinds if k in prof and prof[k][1]], meas))
                                   if meas and all(isinstance(x, (int, float)) for x in meas) else None)
+                    # What is REACHABLE: the loop carries sum_n [n C (8 D^2 + 4 n D) + 2 C D^2] flops of
+                    # contraction per tree beside its bytes -- at the f16x3 matrix peak that alone takes mfma_floor_ms; and
+                    # its pair chains (gate, mix, GELU, three operand splits: ~360 vector + 96 transcendental + ~90 MFMA
+                    # issue slots per 16-pair tile and site and pass) bound it at vector_issue_floor_ms on
+                    # 1024 SIMDs at 2.4 GHz with no padding and perfect overlap.  The 0.40 target is below both floors.
+                    loop_flops = B * sum(n * C * (8.0 * D * D + 4.0 * n * D) + 2.0 * C * D * D for n in range(T - 1, 1, -1))
+                    mfma_floor_ms = loop_flops / (PEAK_F32_VIA_F16X3_TFLOPS * 1e12) * 1e3
+                    tile_sites = B * C * sum(n - 1 for n in range(T - 1, 1, -1)) / 16.0
+                    issue_cycles = 360 * 4 + 96 * 8 + 90 * 8
+                    vec_floor_ms = 2 * tile_sites * issue_cycles / (1024 * 2.4e9) * 1e3
+                    reachable = {"loop_flops_per_rollout": loop_flops, "mfma_floor_ms": mfma_floor_ms,
+                                 "frac_at_mfma_floor": step_bytes / (mfma_floor_ms / 1e3) / 1e9 / PEAK_HBM_GBS,
+                                 "vector_issue_floor_ms": vec_floor_ms,
+                                 "frac_at_vector_issue_floor": step_bytes / (vec_floor_ms / 1e3) / 1e9 / PEAK_HBM_GBS,
+                                 "note": "the BASELINE target of 0.40 of HBM would need the loop in %.1f ms; the matrix pipe "
+                                         "alone needs %.1f ms, the vector issue of the pair chains about %.0f ms"
+                                         % (step_bytes / (0.40 * PEAK_HBM_GBS * 1e9) * 1e3, mfma_floor_ms, vec_floor_ms)}
                     roof["nj_loop_hbm"] = {"kernels": [k for k in step_kinds if k in prof and prof[k][1]],
+                                           "reachable": reachable,
                                            "ms_per_rollout": step_ms,
                                            "algorithmic_bytes_per_rollout": step_bytes, "achieved": gbs,
                                            "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,

@@ -320,13 +320,29 @@ LoopWs loop_ws(int B, int T, int C) {
   return w;
 }
 
+// Zero fill as a KERNEL.  The small-batch rollout is captured into a hipGraph and replayed (rollout_impl): with the three
+// hipMemsetAsync calls of the path captured as memset nodes every second replay returned wrong score tables for C >= 256
+// (round 4: tools/graph_check2.py, profiles/r04/graph_check.txt -- the encoder output right, the tables wrong: the zero
+// mask / the beta tail were not zero when the scorer read them); as kernel nodes they are ordered like everything else.
+__global__ void k_zero_bytes(uint8_t* __restrict__ p, size_t n) {
+  const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 16;
+  if (i + 16 <= n) *reinterpret_cast<u32x4*>(p + i) = (u32x4){0u, 0u, 0u, 0u};
+  else for (size_t k = i; k < n; ++k) p[k] = 0;
+}
+// (p 16-byte aligned: every caller passes a workspace region)
+static void zero_async(void* p, size_t bytes, hipStream_t st) {
+  if (!bytes) return;
+  const size_t threads = (bytes + 15) / 16;
+  hipLaunchKernelGGL(k_zero_bytes, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, static_cast<uint8_t*>(p), bytes);
+}
+
 // the scorer kernels read the site mask unconditionally (no branch in their site loops): a caller without a mask
 // gets a zero-filled one from the workspace
 int scorer_mask(nnj_handle* h, const uint8_t* mask, float* base, const LoopWs& w, int B, int C, hipStream_t st,
                 const uint8_t** out) {
   if (mask) { *out = mask; return NNJ_OK; }
   uint8_t* z = reinterpret_cast<uint8_t*>(base + w.zmask);
-  HIPCHK(h, hipMemsetAsync(z, 0, (size_t)B * C, st));
+  zero_async(z, (size_t)B * C, st);
   *out = z;
   return NNJ_OK;
 }
@@ -398,7 +414,7 @@ int launch_encoder(nnj_handle* h, const uint8_t* codes, const float* onehot, con
     hipLaunchKernelGGL(k_key_classes, dim3((unsigned)(((size_t)B * g6.Cp + 255) / 256)), dim3(256), 0, st, mask, cls, B,
                        C, g6.Cp);
     // V6 keys beyond the alignment meet probabilities that are exactly 0: they only have to be finite
-    if (g6.Cp != C) HIPCHK(h, hipMemsetAsync(V6, 0, (size_t)nbh * g6.v_bh, st));
+    if (g6.Cp != C) zero_async(V6, (size_t)nbh * g6.v_bh, st);
   }
   // reference no-grad chunking: one masked_fill(-10000) per row chunk, summed (axial_attention.py:35-64)
   int nchunks = 1;
@@ -421,7 +437,17 @@ int launch_encoder(nnj_handle* h, const uint8_t* codes, const float* onehot, con
     {
       Scope sc(h, st, PK_ROW_S);
       const float qs = LOG2E / (sqrtf((float)NNJ_DH) * sqrtf((float)T));
-      if (T <= 64) {
+      // NNJ_ROWS_RS=1: operand tiles staged through registers instead of the LDS-DMA ring (round 4: correct, 33.5 vs 32.2 ms
+      // per rollout, profiles/r04/ab_rowattn_regstage.txt -- the ring stays)
+      static const bool rows_rs = getenv("NNJ_ROWS_RS") && atoi(getenv("NNJ_ROWS_RS")) != 0;
+      if (T <= 64 && rows_rs) {
+        constexpr int QW = 128;
+        const size_t lds = (size_t)RsShape<QW>::NST * RsShape<QW>::STAGE;
+        if (int rc = set_lds(h, (k_row_s<QW, 0, true>), lds)) return rc;
+        const unsigned grid = (unsigned)((long)(nbh + 7) / 8 * 8 * g6.nrb * (g6.Cp / QW));
+        hipLaunchKernelGGL((k_row_s<QW, 0, true>), dim3(grid), dim3(256), lds, st, (const uint8_t*)Q6, (const uint8_t*)K6,
+                           (const uint8_t*)cls, Sbuf, Mbuf, g6, nbh, fill, qs);
+      } else if (T <= 64) {
         constexpr int QW = 128;
         const size_t lds = (size_t)RsShape<QW>::NST * RsShape<QW>::STAGE;
         if (int rc = set_lds(h, k_row_s<QW>, lds)) return rc;
@@ -429,7 +455,7 @@ int launch_encoder(nnj_handle* h, const uint8_t* codes, const float* onehot, con
         hipLaunchKernelGGL(k_row_s<QW>, dim3(grid), dim3(256), lds, st, (const uint8_t*)Q6, (const uint8_t*)K6,
                            (const uint8_t*)cls, Sbuf, Mbuf, g6, nbh, fill, qs);
       } else {              // more than 64 rows: chunked accumulation of the 8R-term logits (see k_row_s)
-        constexpr int QW = 64, CHK = 8;
+        constexpr int QW = 64, CHK = NNJ_RS_CHK;
         const size_t lds = (size_t)RsShape<QW>::NST * RsShape<QW>::STAGE;
         if (int rc = set_lds(h, (k_row_s<QW, CHK>), lds)) return rc;
         const unsigned grid = (unsigned)((long)(nbh + 7) / 8 * 8 * g6.nrb * (g6.Cp / QW));
@@ -440,12 +466,21 @@ int launch_encoder(nnj_handle* h, const uint8_t* codes, const float* onehot, con
     {
       Scope sc(h, st, PK_ROW_PV);
       const unsigned grid = (unsigned)((nbh + 7) / 8 * 8 * (g6.Cp / 128) * g6.nech);
+      // NNJ_PV_RS=1: V tiles staged through registers instead of the LDS-DMA ring.  Built and measured in round 4
+      // (profiles/r04/ab_rowattn_regstage.txt): correct, 36.7 vs 36.0 ms per rollout -- not faster, so the ring stays
+      static const bool pv_rs = getenv("NNJ_PV_RS") && atoi(getenv("NNJ_PV_RS")) != 0;
 #define NNJ_PV_CASE(N)                                                                                   \
   case N: {                                                                                              \
     const size_t stg = (N * NPL * 1024 + 4095) / 4096 * 4096, lds = (4 * stg <= 163840 ? 4 : 3) * stg;        \
-    if (int rc = set_lds(h, k_row_pv<N>, lds)) return rc;                                                \
-    hipLaunchKernelGGL(k_row_pv<N>, dim3(grid), dim3(256), lds, st, (const uint8_t*)V6, (const float*)Sbuf, \
-                       (const float*)Mbuf, ctx, g6, nbh);                                                \
+    if (pv_rs && 4 * stg <= 163840) {                                                                    \
+      if (int rc = set_lds(h, (k_row_pv<N, (N <= 13)>), lds)) return rc;                                 \
+      hipLaunchKernelGGL((k_row_pv<N, (N <= 13)>), dim3(grid), dim3(256), lds, st, (const uint8_t*)V6,   \
+                         (const float*)Sbuf, (const float*)Mbuf, ctx, g6, nbh);                          \
+    } else {                                                                                             \
+      if (int rc = set_lds(h, k_row_pv<N>, lds)) return rc;                                              \
+      hipLaunchKernelGGL(k_row_pv<N>, dim3(grid), dim3(256), lds, st, (const uint8_t*)V6, (const float*)Sbuf, \
+                         (const float*)Mbuf, ctx, g6, nbh);                                              \
+    }                                                                                                    \
   } break;
       switch (g6.ETc) {
         NNJ_PV_CASE(1) NNJ_PV_CASE(2) NNJ_PV_CASE(4) NNJ_PV_CASE(6) NNJ_PV_CASE(8) NNJ_PV_CASE(10) NNJ_PV_CASE(13)
@@ -497,7 +532,7 @@ int run_encoder(nnj_handle* h, const uint8_t* codes, const uint8_t* mask, float*
 int launch_row_xf(nnj_handle* h, const float* S, float* U, float* Kp, float* beta, long bstride, int slots,
                   int rows, int B, int C, hipStream_t st) {
   // (beta entries beyond the 32-site tiles of a row stay 0: see beta_stride)
-  HIPCHK(h, hipMemsetAsync(beta, 0, (size_t)B * slots * beta_stride(B, C) * sizeof(float), st));
+  zero_async(beta, (size_t)B * slots * beta_stride(B, C) * sizeof(float), st);
   Scope sc(h, st, PK_ROW_XF);
   const int nt32 = (C + 31) / 32;
   const size_t lds = 2 * 4096 * sizeof(float);
@@ -737,7 +772,7 @@ int launch_step2(nnj_handle* h, RowSet rs, const int* live_old, const int* ij, c
     // shared tiles + the merged rows of a group of sites as one tile (nnj_step_g.hpp).  NNJ_ALPHA_G: bit mask of the
     // tiers that use it (as NNJ_SCORE_G): 1 = up to 4 pairs (four sites per group), 2 = 5..8 (two), 4 = 17..24 (two),
     // 8 = the remaining tiers with one site per group
-    static const int alpha_g = getenv("NNJ_ALPHA_G") ? atoi(getenv("NNJ_ALPHA_G")) : 0;
+    static const int alpha_g = getenv("NNJ_ALPHA_G") ? atoi(getenv("NNJ_ALPHA_G")) : 3;
 #define NNJ_AG(NT, G, IR, NW)                                                                                   \
   {                                                                                                            \
     const size_t lds = (size_t)step_alpha_g_lds(NT, G, IR, NW) * sizeof(float);                                \
@@ -1067,6 +1102,7 @@ int nnj_create(const nnj_config* cfg, nnj_handle** out) {
   if (const char* e = getenv("NNJ_TWO_PASS")) h->two_pass = atoi(e);
   if (const char* e = getenv("NNJ_TWO_PASS_CAND")) h->two_pass_cand = atoi(e);
   if (const char* e = getenv("NNJ_STEP_W")) h->step_w = atoi(e);
+  if (const char* e = getenv("NNJ_GRAPH")) h->use_graph = atoi(e);     // NNJ_GRAPH=0: small-batch rollouts are never replayed from a hipGraph
   h->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   if (hipSetDevice(cfg->device) != hipSuccess || hipMalloc(&h->d_flag, sizeof(int)) != hipSuccess ||
       hipMemset(h->d_flag, 0, sizeof(int)) != hipSuccess) {
@@ -1716,6 +1752,8 @@ static int rollout_impl(nnj_handle* h, const uint8_t* codes, const uint8_t* mask
     }
     const nnj_handle::GraphKey key{codes, mask_in, forced, uniforms, merges_out, trace, gap, state_out, ws,
                                    B, T, L, n_encode, h->debug_stop, inv_temp};
+    static const bool gtrace = getenv("NNJ_GRAPH_TRACE") != nullptr;     // diagnostics: which branch a small-batch call takes
+    if (gtrace) fprintf(stderr, "[nnj graph] B=%d: %s\n", B, (h->gexec && key == h->gkey) ? "replay" : (key == h->gcand ? "capture" : "plain"));
     if (!(h->gexec && key == h->gkey) && !(key == h->gcand)) {
       // first call with these arguments: plain launches; a graph is built only when a call repeats (a caller that
       // passes fresh buffers every time would otherwise pay a capture per call)

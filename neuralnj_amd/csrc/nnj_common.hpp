@@ -341,7 +341,11 @@ __device__ __forceinline__ f32x16 mfma_f16(u32x4 a, u32x4 b, f32x16 c) {
                                                  0, 0, 0);
 }
 // c += A*B from the three leading piece products (m.h, h.m, h.h), smallest first
+// (-DNNJ_MM4: a diagnostic build that adds the fourth piece product m.m -- tools/noise_ab.py, DESIGN.md parity section)
 __device__ __forceinline__ f32x16 mfma_b6(const Frag3& a, const Frag3& b, f32x16 c) {
+#ifdef NNJ_MM4
+  c = mfma_f16(a.m, b.m, c);
+#endif
   c = mfma_f16(a.m, b.h, c);
   c = mfma_f16(a.h, b.m, c);
   c = mfma_f16(a.h, b.h, c);
@@ -594,6 +598,9 @@ __device__ __forceinline__ f32x4 mfma16_f16(u32x4 a, u32x4 b, f32x4 c) {
                                                  0);
 }
 __device__ __forceinline__ f32x4 mfma16_b6(const Frag3& a, const Frag3& b, f32x4 c) {
+#ifdef NNJ_MM4
+  c = mfma16_f16(a.m, b.m, c);
+#endif
   c = mfma16_f16(a.m, b.h, c);
   c = mfma16_f16(a.h, b.m, c);
   c = mfma16_f16(a.h, b.h, c);

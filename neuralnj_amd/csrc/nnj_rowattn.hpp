@@ -216,7 +216,16 @@ struct RsShape {
 // accumulated CHK at a time into a zeroed accumulator and the chunk sums are added to the total by the vector
 // unit: the many roundings happen on small partial sums, only KS/CHK on the large one (same error as the
 // reference's order).  The second accumulator set is paid for by the narrower wave tile (128 keys x 32 queries).
-template <int QW, int CHK = 0>
+#ifndef NNJ_RS_COMP
+#define NNJ_RS_COMP 0
+#endif
+#ifndef NNJ_RS_CHK
+#define NNJ_RS_CHK 8
+#endif
+// RS (round 4): the operand tiles are staged through registers instead of by LDS-DMA (see k_row_pv): tile ks+2 is loaded
+// (global_load_dwordx4, a few issue cycles) behind the first MFMA groups of k-step ks, written to its ring stage
+// (ds_write_b128) behind the later groups of k-step ks+1, read in k-step ks+2.
+template <int QW, int CHK = 0, bool RS = false>
 __global__ __launch_bounds__(256, 2) void k_row_s(const uint8_t* __restrict__ Q6, const uint8_t* __restrict__ K6,
                                                              const uint8_t* __restrict__ cls, float* __restrict__ S,
                                                              float* __restrict__ M, Ra6 g, int nbh, float fill, float qs) {
@@ -259,6 +268,27 @@ __global__ __launch_bounds__(256, 2) void k_row_s(const uint8_t* __restrict__ Q6
   auto issue = [&](int ks, int stage) {
     static_for<0, NP>([&](auto pi) { issue_piece(pi, ks, stage); });
   };
+  u32x4 R[RS ? 2 : 1][RS ? NP : 1];                        // register staging: piece i of tile t -> R[t & 1][i]
+  auto stage_load = [&](auto pi, auto parc, int ks) {
+    constexpr int i = decltype(pi)::value, par = decltype(parc)::value;
+    const int kk = ks < KS ? ks : KS - 1;
+    const int I = wave * NP + i;
+    const uint8_t* src;
+    if (I < NPK) {
+      src = Kt + I * 1024;
+    } else {
+      const int J = I - NPK, pl = J / (QW / 32), pc = J % (QW / 32);
+      src = Qt + (size_t)pl * 8192 + pc * 1024;
+    }
+    const u32x4 v = *reinterpret_cast<const u32x4*>(src + (size_t)kk * ks_stride + lane * 16);
+    if constexpr (RS) R[par][i] = v;
+  };
+  auto stage_store = [&](auto pi, auto parc, int stage) {
+    constexpr int i = decltype(pi)::value, par = decltype(parc)::value;
+    const int I = wave * NP + i;
+    if constexpr (RS)
+      *reinterpret_cast<u32x4*>(reinterpret_cast<uint8_t*>(smem) + stage * STAGE + I * 1024 + lane * 16) = R[par][i];
+  };
   const unsigned half = 16u * (unsigned)(HH ^ ((l31 >> 3) & 1));
   const unsigned aA = lds_addr(smem) + (unsigned)(kh * 128 + l31) * 32u + half;
   const unsigned aB = lds_addr(smem) + KTB + (unsigned)(qh * 32 * NJ + l31) * 32u + half;
@@ -270,13 +300,20 @@ __global__ __launch_bounds__(256, 2) void k_row_s(const uint8_t* __restrict__ Q6
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   f32x16 tot[CHK > 0 ? 4 : 1][CHK > 0 ? NJ : 1];          // chunk sums are folded into this (CHK > 0)
+  // COMP: the fold is an error-free addition (Knuth's two-sum): what the fp32 sum of total and chunk loses goes to a
+  // second word that is added once at the end -- the roundings at the magnitude of the whole logit are gone too
+  constexpr bool COMP = CHK > 0 && NNJ_RS_COMP != 0;
+  f32x16 lo[COMP ? 4 : 1][COMP ? NJ : 1];
   if constexpr (CHK > 0) {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int j = 0; j < NJ; ++j)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) tot[i][j][r] = 0.f;
+        for (int r = 0; r < 16; ++r) {
+          tot[i][j][r] = 0.f;
+          if constexpr (COMP) lo[i][j][r] = 0.f;
+        }
   }
   Frag3 A[4], Bf[2];
   auto readA = [&](unsigned base) {
@@ -291,11 +328,19 @@ __global__ __launch_bounds__(256, 2) void k_row_s(const uint8_t* __restrict__ Q6
     lds_read_frag<j * 1024>(bfr.h, base);
     lds_read_frag<j * 1024 + QPL>(bfr.m, base);
   };
-  issue(0, 0);
-  if constexpr (NST == 3) issue(1, 1);
-  for (int ks = 0; ks < KS; ++ks) {
+  if constexpr (RS) {
+    static_for<0, NP>([&](auto pi) { stage_load(pi, std::integral_constant<int, 0>{}, 0); });
+    static_for<0, NP>([&](auto pi) { stage_load(pi, std::integral_constant<int, 1>{}, 1); });
+    static_for<0, NP>([&](auto pi) { stage_store(pi, std::integral_constant<int, 0>{}, 0); });
+  } else {
+    issue(0, 0);
+    if constexpr (NST == 3) issue(1, 1);
+  }
+  auto kstep = [&](int ks, auto parc) {
+    constexpr int PAR = decltype(parc)::value;               // ks & 1 (compile time: it picks the staging registers)
     const unsigned so = (unsigned)(ks % NST) * STAGE;
-    if constexpr (NST == 3) wait_vmem_le<NP>(); else wait_vmem_le<0>();   // tile ks has landed
+    if constexpr (RS) lds_wait_all();        // this wave's stores of tile ks (written during k-step ks-1) are in LDS
+    else if constexpr (NST == 3) wait_vmem_le<NP>(); else wait_vmem_le<0>();   // tile ks has landed
     barrier_nofence();                       // ... for every wave; every wave is done with tile ks-1
     const int st2 = (ks + NST - 1) % NST;    // the stage of tile ks-1 takes tile ks+NST-1
     readA(aA + so);
@@ -316,7 +361,15 @@ __global__ __launch_bounds__(256, 2) void k_row_s(const uint8_t* __restrict__ Q6
         constexpr int grp = 4 * j + i, per = (NP + 4 * NJ - 2) / (4 * NJ - 1);
         static_for<0, per>([&](auto ee) {
           constexpr int piece = grp * per + decltype(ee)::value;
-          if constexpr (piece < NP) issue_piece(std::integral_constant<int, piece>{}, ks + NST - 1, st2);
+          if constexpr (RS) {
+            // loads of tile ks+2 behind the first groups, stores of tile ks+1 (loaded a k-step ago) behind the last ones
+            if constexpr (piece < NP) stage_load(std::integral_constant<int, piece>{}, parc, ks + 2);
+            constexpr int sp = piece - (4 * NJ * per - NP);
+            if constexpr (sp >= 0 && sp < NP)
+              stage_store(std::integral_constant<int, sp>{}, std::integral_constant<int, PAR ^ 1>{}, (ks + 1) % NST);
+          } else {
+            if constexpr (piece < NP) issue_piece(std::integral_constant<int, piece>{}, ks + NST - 1, st2);
+          }
         });
       });
     });
@@ -326,18 +379,37 @@ __global__ __launch_bounds__(256, 2) void k_row_s(const uint8_t* __restrict__ Q6
         for (int i = 0; i < 4; ++i)
 #pragma unroll
           for (int j = 0; j < NJ; ++j) {
-            tot[i][j] += acc[i][j];
+            if constexpr (COMP) {
+#pragma unroll
+              for (int r = 0; r < 16; ++r) {
+                const float a = tot[i][j][r], c = acc[i][j][r];
+                const float s_ = a + c;
+                const float bb = s_ - a;
+                lo[i][j][r] += (a - (s_ - bb)) + (c - bb);
+                tot[i][j][r] = s_;
+              }
+            } else {
+              tot[i][j] += acc[i][j];
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
           }
       }
     }
+  };
+  for (int ks = 0; ks + 1 < KS; ks += 2) {
+    kstep(ks, std::integral_constant<int, 0>{});
+    kstep(ks + 1, std::integral_constant<int, 1>{});
   }
+  if (KS & 1) kstep(KS - 1, std::integral_constant<int, 0>{});
   if constexpr (CHK > 0) {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int j = 0; j < NJ; ++j) acc[i][j] = tot[i][j];
+      for (int j = 0; j < NJ; ++j) {
+        acc[i][j] = tot[i][j];
+        if constexpr (COMP) acc[i][j] += lo[i][j];
+      }
   }
   wait_vmem_le<0>();                         // nothing of the ring may still be landing when the workgroup ends
   // ---- epilogue: key classes, tile maxima, register images
@@ -393,7 +465,13 @@ __global__ __launch_bounds__(256, 2) void k_row_s(const uint8_t* __restrict__ Q6
 // one workgroup per (query block, chunk) -- each recomputes the probabilities (the exponentials are cheap next to
 // the ET x 3 MFMAs per 16 keys) and owns its slice of the context rows; the chunks of a query block sit on
 // consecutive workgroup slots of one XCD, so the score images they share are served by its L2.
-template <int ET>
+// RS (round 4): the V6 tiles are staged THROUGH REGISTERS instead of by LDS-DMA (cdna_hip_programming.md T14: issue
+// early, write late).  At one wave per SIMD an LDS-DMA instruction holds the wave for 60-185 cycles (MI355X_MICROARCH.md,
+// row "LDS-DMA piece issue cost"), seven per wave and 16 keys -- round 2's knock-out put a quarter of the kernel there.
+// A global_load_dwordx4 issues in a few cycles; the tile of k-step k+2 is loaded into registers during k-step k and
+// written to its ring stage (ds_write_b128, same linear image) during k+1, the tile of k+3 loaded during k+1 and written
+// at its end, in front of the barrier that opens k+2 (four-stage ring, one barrier per two k-steps, as before).
+template <int ET, bool RS = false>
 __global__ __launch_bounds__(256) void k_row_pv(const uint8_t* __restrict__ V6, const float* __restrict__ S,
                                                 const float* __restrict__ M, float* __restrict__ ctx, Ra6 g,
                                                 int nbh) {
@@ -425,6 +503,20 @@ __global__ __launch_bounds__(256) void k_row_pv(const uint8_t* __restrict__ V6, 
   auto issue = [&](int k, int stage) {
     static_for<0, NIW>([&](auto pi) { issue_piece(pi, k, stage); });
   };
+  // register staging (RS): piece i of tile k -> R[k & 1][i]; stage_store writes a loaded tile into its ring stage
+  u32x4 R[RS ? 2 : 1][RS ? NIW : 1];
+  auto stage_load = [&](auto pi, auto par, int k) {
+    constexpr int i = decltype(pi)::value, P = decltype(par)::value;
+    const int kk = k < nk16 ? k : nk16 - 1;
+    const unsigned I = (unsigned)(wave * NIW + i);
+    const size_t so = I * 1024u < TILE ? (size_t)(I / ET) * plane_g + (size_t)(I % ET) * 1024u : 0u;
+    R[RS ? P : 0][RS ? i : 0] = *reinterpret_cast<const u32x4*>(Vt + (size_t)kk * tile_g + so + lane * 16);
+  };
+  auto stage_store = [&](auto pi, auto par, int stage) {
+    constexpr int i = decltype(pi)::value, P = decltype(par)::value;
+    const unsigned I = (unsigned)(wave * NIW + i);
+    *reinterpret_cast<u32x4*>(reinterpret_cast<uint8_t*>(smem) + stage * STG + I * 1024u + lane * 16) = R[RS ? P : 0][RS ? i : 0];
+  };
   const float* Sq = S + (size_t)bh * g.s_bh + (size_t)qt * g.nt32 * 1024 + lane * 4;
   const float* Mq = M + (size_t)bh * g.m_bh + (size_t)qt * g.nt32 * 32 + l31;
   float m = -INFINITY;
@@ -444,9 +536,18 @@ __global__ __launch_bounds__(256) void k_row_pv(const uint8_t* __restrict__ V6, 
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
   float lsum = 0.f;
   f32x16 s_cur, s_nxt;
-  issue(0, 0);
-  loadS(s_cur, 0);
-  issue(1, 1);
+  if constexpr (RS) {
+    static_assert(NST == 4, "register staging is written for the four-stage ring");
+    static_for<0, NIW>([&](auto pi) { stage_load(pi, std::integral_constant<int, 0>{}, 0); });
+    static_for<0, NIW>([&](auto pi) { stage_load(pi, std::integral_constant<int, 1>{}, 1); });
+    loadS(s_cur, 0);
+    static_for<0, NIW>([&](auto pi) { stage_store(pi, std::integral_constant<int, 0>{}, 0); });
+    static_for<0, NIW>([&](auto pi) { stage_store(pi, std::integral_constant<int, 1>{}, 1); });
+  } else {
+    issue(0, 0);
+    loadS(s_cur, 0);
+    issue(1, 1);
+  }
   s_nxt = s_cur;
   const unsigned aA = lds_addr(smem) + (unsigned)l31 * 32u + 16u * (unsigned)(HH ^ ((l31 >> 3) & 1));
   Frag3 bfr[2];
@@ -458,7 +559,8 @@ __global__ __launch_bounds__(256) void k_row_pv(const uint8_t* __restrict__ V6, 
       // this wave has in flight), the barrier makes that true for every wave and tells that tiles k-2, k-1 are
       // read: their stages take tiles k+2 (issued during k) and k+3 (during k+1).
       if constexpr (P == 0) {
-        wait_vmem_le<0>();
+        if constexpr (RS) lds_wait_all();         // this wave's stage stores of tiles k, k+1 (and everything else of it in LDS)
+        else wait_vmem_le<0>();
         barrier_nofence();
       }
     } else {
@@ -498,8 +600,21 @@ __global__ __launch_bounds__(256) void k_row_pv(const uint8_t* __restrict__ V6, 
       pin_frag(a[t % 3]);
       if constexpr (t + 2 < ET) rd(std::integral_constant<int, t + 2>{});
       acc[t] = mfma_b6(a[t % 3], bf, acc[t]);
-      if constexpr (t < NIW) issue_piece(std::integral_constant<int, t>{}, k + 2, st2);
+      if constexpr (RS) {
+        // loads of tile k+2 behind the first MFMA groups; at odd k the tile loaded during k-1 (R[0], tile k+1 ... of the
+        // NEXT pair: k+1 is odd, so that is tile (k-1)+2) goes to its stage behind the later groups -- its loads have had
+        // a whole k-step to land (the compiler's own vmcnt wait in front of the store names exactly them)
+        if constexpr (t < NIW) stage_load(std::integral_constant<int, t>{}, par, k + 2);
+        if constexpr (P == 1 && t >= ET - NIW && t < ET)
+          stage_store(std::integral_constant<int, t - (ET - NIW)>{}, std::integral_constant<int, 0>{}, (k + 1) % NST);
+      } else {
+        if constexpr (t < NIW) issue_piece(std::integral_constant<int, t>{}, k + 2, st2);
+      }
     });
+    if constexpr (RS && P == 1) {
+      // the tile loaded during this k-step (k+2, odd) goes to its stage now, in front of the barrier of the next step
+      static_for<0, NIW>([&](auto pi) { stage_store(pi, std::integral_constant<int, 1>{}, (k + 2) % NST); });
+    }
     if constexpr (P == 1) s_cur = s_nxt;
   };
   for (int k = 0; k < nk16; k += 2) {          // nk16 is even (Cp is a multiple of 256)

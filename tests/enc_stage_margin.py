@@ -45,6 +45,9 @@ def run(T, L, style="sharp"):
 
 
 if __name__ == "__main__":
-    run(200, 160)
-    run(50, 1024)
-    run(256, 20)
+    if len(sys.argv) >= 3:                                   # python tests/enc_stage_margin.py T L [style]
+        run(int(sys.argv[1]), int(sys.argv[2]), *(sys.argv[3:4]))
+    else:
+        run(200, 160)
+        run(50, 1024)
+        run(256, 20)
