@@ -496,9 +496,17 @@ int launch_encoder(nnj_handle* h, const uint8_t* codes, const float* onehot, con
       constexpr int NSLOT = 8 / NT;
       const unsigned grid1 = (unsigned)std::min<long>((long)(((size_t)B * C + NSLOT - 1) / NSLOT), (long)h->num_cu);
       const size_t lds = (size_t)(5 * 4096 + NSLOT * (32 * NT * 32 + 32 * NT * 32) + 16 + 448) * sizeof(float);
-      if (int rc = set_lds(h, k_tok1p<NT>, lds)) return rc;
-      hipLaunchKernelGGL(k_tok1p<NT>, dim3(grid1), dim3(512), lds, st, ctx, mask, x, attn_ptrs(h, h->lo[l].row),
-                         attn_ptrs(h, h->lo[l].col), B, T, C, d.Epad, dbg, h->d_flag);
+      // (NNJ_TOK_SK=0: the form that computes the padded keys' exponentials too)
+      static const bool tok_sk = !(getenv("NNJ_TOK_SK") && atoi(getenv("NNJ_TOK_SK")) == 0);
+      if (NT <= 2 && tok_sk && T <= 32 * NT - 8) {
+        if (int rc = set_lds(h, (k_tok1p<NT, (NT <= 2)>), lds)) return rc;
+        hipLaunchKernelGGL((k_tok1p<NT, (NT <= 2)>), dim3(grid1), dim3(512), lds, st, ctx, mask, x, attn_ptrs(h, h->lo[l].row),
+                           attn_ptrs(h, h->lo[l].col), B, T, C, d.Epad, dbg, h->d_flag);
+      } else {
+        if (int rc = set_lds(h, k_tok1p<NT>, lds)) return rc;
+        hipLaunchKernelGGL(k_tok1p<NT>, dim3(grid1), dim3(512), lds, st, ctx, mask, x, attn_ptrs(h, h->lo[l].row),
+                           attn_ptrs(h, h->lo[l].col), B, T, C, d.Epad, dbg, h->d_flag);
+      }
     }
     if (l == 0 && (h->debug_stop == 1 || h->debug_stop == 2)) break;
     {
@@ -1975,9 +1983,10 @@ int lik_eval(nnj_handle* h, const uint8_t* codes, int nA, const LikModel& md, co
   const int NN = 2 * T - 2, nc = md.ncat;
   const int total = B * NN * nc;
   hipLaunchKernelGGL(k_lik_pmats, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, brlen, md, base + w.pmat, total);
-  hipLaunchKernelGGL(k_lik_down, dim3((unsigned)((L + 127) / 128), (unsigned)B), dim3(128), 0, st, codes, nA,
-                     (const double*)(base + w.inv), reinterpret_cast<const int*>(base + w.prog), (const double*)(base + w.pmat),
-                     md, base + w.down, base + w.site, T, L);
+  hipLaunchKernelGGL(k_lik_down, dim3((unsigned)((L + 127) / 128), (unsigned)B, (unsigned)nc), dim3(128), 0, st, codes, nA,
+                     reinterpret_cast<const int*>(base + w.prog), (const double*)(base + w.pmat), md, base + w.down, T, L);
+  hipLaunchKernelGGL(k_lik_site_ll, dim3((unsigned)((L + 127) / 128), (unsigned)B), dim3(128), 0, st,
+                     (const double*)(base + w.inv), nA, md, (const double*)(base + w.down), base + w.site, T, L);
   hipLaunchKernelGGL(k_lik_sum_sites, dim3((unsigned)B), dim3(256), 0, st, (const double*)(base + w.site), ll_out, L);
   return NNJ_OK;
 }
@@ -1995,7 +2004,7 @@ int lik_common(nnj_handle* h, const uint8_t* codes, int nA, const uint8_t* mask,
   h->sess.valid = false;
   base = static_cast<double*>(ws);
   int* prog = reinterpret_cast<int*>(base + w.prog);
-  hipLaunchKernelGGL(k_lik_program, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, st, merges, prog,
+  hipLaunchKernelGGL(k_lik_program, dim3((unsigned)B), dim3(256), 0, st, merges, prog,
                      reinterpret_cast<int*>(base + w.colour), B, T);
   const int ne = B * (T - 1) * 2;
   hipLaunchKernelGGL(k_lik_brlen_init, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, st, (const int*)prog, brlen_in, 0.1,
@@ -2080,7 +2089,7 @@ int nnj_tree_optimize(nnj_handle* h, const uint8_t* codes, int32_t n_align, cons
     // lengths (pmat and down are current), one Newton-Raphson solve per edge of the colour, the step taken in full if
     // the likelihood does not drop, else halved (per tree, decided on the device), then the partials refreshed
     for (int c = 0; c < 4; ++c) {
-      hipLaunchKernelGGL(k_lik_outer, dim3((unsigned)((L + 127) / 128), (unsigned)B), dim3(128), 0, st, codes, n_align, prog,
+      hipLaunchKernelGGL(k_lik_outer, dim3((unsigned)((L + 127) / 128), (unsigned)B, (unsigned)md.ncat), dim3(128), 0, st, codes, n_align, prog,
                          (const double*)(base + w.pmat), md, (const double*)(base + w.down), base + w.outer, T, L);
       hipLaunchKernelGGL(k_lik_newton, dim3((unsigned)NN, (unsigned)B), dim3(256), 0, st, codes, n_align,
                          (const double*)(base + w.inv), (const double*)(base + w.down), (const double*)(base + w.outer), md,

@@ -144,7 +144,10 @@ __device__ __forceinline__ void ko_keep(T_& x) {
   asm volatile("" : "+v"(x));
 #endif
 }
-template <int NWC>                                      // waves per column: 1 (R <= 32), 2 (<= 64), 4 (<= 128), 8 (<= 256)
+// SK (NWC <= 2): the last eight keys of the last 32-key tile are beyond the rows for EVERY lane (R <= 32 NWC - 8, e.g. the
+// 50 rows of the bench: keys 56..63) -- their maximum / exponential / sum / split instructions are compiled out (round 4:
+// the knock-outs of profiles/r04/ko_tok1p.txt put the softmax at 6.2 of the kernel's 34.8 ms; an eighth of it was padding)
+template <int NWC, bool SK = false>                     // waves per column: 1 (R <= 32), 2 (<= 64), 4 (<= 128), 8 (<= 256)
 __global__ __launch_bounds__(512) void k_tok1p(const float* __restrict__ ctx, const uint8_t* __restrict__ mask,
                                                float* __restrict__ x, AttnW wr, AttnW wc, int B, int R, int C,
                                                int Epad, int skip_col, int* __restrict__ status) {
@@ -343,6 +346,7 @@ __global__ __launch_bounds__(512) void k_tok1p(const float* __restrict__ ctx, co
         for (int jt = 0; jt < NWC; ++jt)
 #pragma unroll
           for (int k = 0; k < 16; ++k) {
+            if (SK && jt == NWC - 1 && k >= 12) continue;       // keys 32 jt + 24 .. + 31: beyond the rows in every lane
             float v = sc_[jt][k];
             if (jt == NWC - 1 && 32 * jt + (k & 3) + 8 * (k >> 2) + 4 * hh >= R) v = -INFINITY;
             sc_[jt][k] = v;
@@ -353,6 +357,7 @@ __global__ __launch_bounds__(512) void k_tok1p(const float* __restrict__ ctx, co
         for (int jt = 0; jt < NWC; ++jt)
 #pragma unroll
           for (int k = 0; k < 16; ++k) {
+            if (SK && jt == NWC - 1 && k >= 12) { sc_[jt][k] = 0.f; continue; }
             const float p = __builtin_amdgcn_exp2f(sc_[jt][k] - m);
             sc_[jt][k] = p;
             l += p;
@@ -372,6 +377,12 @@ __global__ __launch_bounds__(512) void k_tok1p(const float* __restrict__ ctx, co
             pf.h = (u32x4){__builtin_bit_cast(unsigned, sc_[ks >> 1][8 * (ks & 1)]), __builtin_bit_cast(unsigned, sc_[ks >> 1][8 * (ks & 1) + 2]),
                            __builtin_bit_cast(unsigned, sc_[ks >> 1][8 * (ks & 1) + 4]), __builtin_bit_cast(unsigned, sc_[ks >> 1][8 * (ks & 1) + 6])};
             pf.m = pf.h;
+          } else if constexpr (SK && ks == 2 * NWC - 1) {
+            // the last k-step: probabilities 12..15 of the tile are exact zeros (keys beyond the rows): no split
+            unsigned h, m_;
+            split2(sc_[ks >> 1][8], sc_[ks >> 1][9], h, m_); pf.h[0] = h; pf.m[0] = m_;
+            split2(sc_[ks >> 1][10], sc_[ks >> 1][11], h, m_); pf.h[1] = h; pf.m[1] = m_;
+            pf.h[2] = 0u; pf.h[3] = 0u; pf.m[2] = 0u; pf.m[3] = 0u;
           } else {
             split8<8 * (ks & 1)>(pf, sc_[ks >> 1]);
           }

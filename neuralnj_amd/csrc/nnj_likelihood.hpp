@@ -35,28 +35,43 @@ constexpr int LIK_MAXCAT = 8;
 // of one colour never share a node -- siblings differ in the second term, parent and child in the first -- so the
 // edges of a colour can be optimised at once from the same partial likelihoods without fighting each other, and
 // four colour steps are one Gauss-Seidel pass over the tree.
-__global__ void k_lik_program(const int* __restrict__ merges, int* __restrict__ prog, int* __restrict__ colour, int B, int T) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+// One WORKGROUP per tree (round 4; it was one thread with a 256-entry private list in scratch memory: 658 us per call
+// at 200 taxa -- a seventh of a Search round's model optimisation, which calls it for every trial value): the position
+// list lives in LDS and "position j leaves the list" (environment.py:764-768) is a parallel shift.
+__global__ __launch_bounds__(256) void k_lik_program(const int* __restrict__ merges, int* __restrict__ prog,
+                                                     int* __restrict__ colour, int B, int T) {
+  __shared__ int ids[256];
+  __shared__ int pl[512];                                  // the tree's child ids per join (for the colour pass)
+  __shared__ int cl[512];
+  const int b = blockIdx.x, tid = threadIdx.x;
   if (b >= B) return;
-  int ids[256];
-  for (int i = 0; i < T; ++i) ids[i] = i;
+  ids[tid] = tid;
   const int* m = merges + (size_t)b * (T - 1) * 2;
   int* p = prog + (size_t)b * (T - 1) * 2;
+  __syncthreads();
   int n = T;
   for (int s = 0; s < T - 1; ++s, --n) {
     const int i = min(max(m[2 * s], 0), n - 1), j = min(max(m[2 * s + 1], 0), n - 1);
-    p[2 * s] = ids[i]; p[2 * s + 1] = ids[j];
-    ids[i] = T + s;
-    for (int q = j; q < n - 1; ++q) ids[q] = ids[q + 1];
+    if (tid == 0) { pl[2 * s] = ids[i]; pl[2 * s + 1] = ids[j]; }
+    int v = (tid >= j && tid < n - 1) ? ids[tid + 1] : ids[tid];
+    if (tid == i) v = T + s;                                // (a merge with i >= j is malformed; as before, position i wins)
+    __syncthreads();
+    ids[tid] = v;
+    __syncthreads();
   }
+  for (int e = tid; e < 2 * (T - 1); e += 256) p[e] = pl[e];
   if (!colour) return;
-  int* col = colour + (size_t)b * (2 * T - 2);
   // top-down: the depth parity of a join is kept in the colour entry of the join itself (the last join is the root)
-  for (int s = T - 2; s >= 0; --s) {
-    const int par = s == T - 2 ? 0 : (col[T + s] >> 1);      // depth parity of join T + s
-    const int cp = par ^ 1;
-    col[p[2 * s]] = 2 * cp; col[p[2 * s + 1]] = 2 * cp + 1;
+  if (tid == 0) {
+    for (int s = T - 2; s >= 0; --s) {
+      const int par = s == T - 2 ? 0 : (cl[T + s] >> 1);    // depth parity of join T + s
+      const int cp = par ^ 1;
+      cl[pl[2 * s]] = 2 * cp; cl[pl[2 * s + 1]] = 2 * cp + 1;
+    }
   }
+  __syncthreads();
+  int* col = colour + (size_t)b * (2 * T - 2);
+  for (int e = tid; e < 2 * T - 2; e += 256) col[e] = cl[e];
 }
 
 // child-edge lengths in merge order [B][T-1][2] (or a constant) -> per-node lengths [B][2T-2]
@@ -142,51 +157,53 @@ __global__ void k_lik_invariant(const uint8_t* __restrict__ codes, const uint8_t
   inv[i] = s;
 }
 
-// Post-order pass: one thread per (tree, site) walks the joins in merge order (children always come first).
-// site_ll [B][L]: log-likelihood of the site (0 for masked / padded sites); codes [nA][T][L], nA = 1 or B.
+// Post-order pass: one thread per (tree, site, RATE CATEGORY) walks the joins in merge order (children always come
+// first).  Round 4: the categories are a grid dimension (they are independent until the site likelihood is formed) --
+// one alignment of 4096 sites was 32 waves on 256 CUs, each a chain of 199 joins x 4 categories of dependent loads;
+// k_lik_site_ll then forms site_ll [B][L] (0 for masked / padded sites) from the root partials.
+// codes [nA][T][L], nA = 1 or B.  grid (ceil(L / 128), B, ncat).
 __global__ __launch_bounds__(128) void k_lik_down(const uint8_t* __restrict__ codes, int n_align,
-                                                  const double* __restrict__ inv, const int* __restrict__ prog,
-                                                  const double* __restrict__ pmat, LikModel md,
-                                                  double* __restrict__ down, double* __restrict__ site_ll, int T, int L) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+                                                  const int* __restrict__ prog, const double* __restrict__ pmat,
+                                                  LikModel md, double* __restrict__ down, int T, int L) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y, cat = blockIdx.z;
   if (c >= L) return;
   const int nc = md.ncat, NN = 2 * T - 2;
   const uint8_t* cd = codes + (size_t)(n_align == 1 ? 0 : b) * T * L + c;
   const int* pg = prog + (size_t)b * (T - 1) * 2;
   const double* Pb = pmat + (size_t)b * NN * nc * 16;
   double* Db = down + (size_t)b * (T - 1) * nc * 4 * L + c;
-  double root[LIK_MAXCAT][4];
   for (int s = 0; s < T - 1; ++s) {
     const int ch[2] = {pg[2 * s], pg[2 * s + 1]};
-    for (int cat = 0; cat < nc; ++cat) {
-      double acc[4] = {1.0, 1.0, 1.0, 1.0};
+    double acc[4] = {1.0, 1.0, 1.0, 1.0};
 #pragma unroll
-      for (int side = 0; side < 2; ++side) {
-        const int v = ch[side];
-        double x[4], y[4];
-        if (v < T) lik_tip(x, cd[(size_t)v * L]);
-        else {
+    for (int side = 0; side < 2; ++side) {
+      const int v = ch[side];
+      double x[4], y[4];
+      if (v < T) lik_tip(x, cd[(size_t)v * L]);
+      else {
 #pragma unroll
-          for (int k = 0; k < 4; ++k) x[k] = Db[((size_t)(v - T) * nc * 4 + cat * 4 + k) * L];
-        }
-        lik_apply(y, Pb + ((size_t)v * nc + cat) * 16, x);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) acc[k] *= y[k];
+        for (int k = 0; k < 4; ++k) x[k] = Db[((size_t)(v - T) * nc * 4 + cat * 4 + k) * L];
       }
-      if (s == T - 2) {
+      lik_apply(y, Pb + ((size_t)v * nc + cat) * 16, x);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) root[cat][k] = acc[k];
-      } else {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) Db[((size_t)s * nc * 4 + cat * 4 + k) * L] = acc[k];
-      }
+      for (int k = 0; k < 4; ++k) acc[k] *= y[k];
     }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) Db[((size_t)s * nc * 4 + cat * 4 + k) * L] = acc[k];      // (the root join too)
   }
-  // site likelihood: pinv * [constant site] + (1 - pinv) / ncat * sum_cat sum_k pi_k root_k
+}
+// site likelihood: pinv * [constant site] + (1 - pinv) / ncat * sum_cat sum_k pi_k root_k (categories added in order)
+__global__ __launch_bounds__(128) void k_lik_site_ll(const double* __restrict__ inv, int n_align, LikModel md,
+                                                     const double* __restrict__ down, double* __restrict__ site_ll,
+                                                     int T, int L) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+  if (c >= L) return;
+  const int nc = md.ncat;
+  const double* Rb = down + ((size_t)b * (T - 1) + (T - 2)) * nc * 4 * L + c;
   double g = 0.0;
   for (int cat = 0; cat < nc; ++cat)
 #pragma unroll
-    for (int k = 0; k < 4; ++k) g += md.freqs[k] * root[cat][k];
+    for (int k = 0; k < 4; ++k) g += md.freqs[k] * Rb[(size_t)(cat * 4 + k) * L];
   g *= (1.0 - md.pinv) / (double)nc;
   const double iv = inv[(size_t)(n_align == 1 ? 0 : b) * L + c];
   g += md.pinv * fmax(iv, 0.0);
@@ -214,7 +231,7 @@ __global__ __launch_bounds__(128) void k_lik_outer(const uint8_t* __restrict__ c
                                                    const int* __restrict__ prog, const double* __restrict__ pmat,
                                                    LikModel md, const double* __restrict__ down,
                                                    double* __restrict__ outer, int T, int L) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+  const int c = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y, cat = blockIdx.z;     // (categories: a grid dimension)
   if (c >= L) return;
   const int nc = md.ncat, NN = 2 * T - 2;
   const uint8_t* cd = codes + (size_t)(n_align == 1 ? 0 : b) * T * L + c;
@@ -225,7 +242,7 @@ __global__ __launch_bounds__(128) void k_lik_outer(const uint8_t* __restrict__ c
   for (int s = T - 2; s >= 0; --s) {
     const int p = T + s;                                   // this join; its own O_p was written by its parent's turn
     const int ch[2] = {pg[2 * s], pg[2 * s + 1]};
-    for (int cat = 0; cat < nc; ++cat) {
+    {
       double up[4] = {1.0, 1.0, 1.0, 1.0};
       if (s != T - 2) {
         double op[4];
