@@ -14,7 +14,7 @@
 
 #include "../../include/nnj.h"
 #include "nnj_encoder.hpp"
-#include "nnj_rowattn.hpp"
+#include "nnj_rowfused.hpp"
 #include "nnj_scorer.hpp"
 #include "nnj_scorer16.hpp"
 #include "nnj_scorer_wide.hpp"
@@ -362,7 +362,7 @@ EncWs enc_ws(int B, int T, int C) {
   w.v6 = take(nbh * g.v_bh / 4);
   w.s = take(nbh * g.s_bh);
   w.m = take(nbh * g.m_bh);
-  w.cls = take(((size_t)B * g.Cp + 3) / 4);
+  w.cls = take(((size_t)B * g.Cp + (size_t)B * g.nrb + 3) / 4 + 1);   // key classes + their per-256-key-block OR (k_row_fused)
   w.end = o;
   return w;
 }
@@ -413,9 +413,15 @@ int launch_encoder(nnj_handle* h, const uint8_t* codes, const float* onehot, con
                        h->cfg.patch_size);
     hipLaunchKernelGGL(k_key_classes, dim3((unsigned)(((size_t)B * g6.Cp + 255) / 256)), dim3(256), 0, st, mask, cls, B,
                        C, g6.Cp);
+    hipLaunchKernelGGL(k_key_class_blocks, dim3((unsigned)((B * g6.nrb + 255) / 256)), dim3(256), 0, st, (const uint8_t*)cls,
+                       cls + (size_t)B * g6.Cp, B * g6.nrb, g6.Cp);
     // V6 keys beyond the alignment meet probabilities that are exactly 0: they only have to be finite
     if (g6.Cp != C) zero_async(V6, (size_t)nbh * g6.v_bh, st);
   }
+  // One kernel per layer for the tied row attention (nnj_rowfused.hpp) where its accumulators fit one wave's registers and
+  // its two rings the LDS: up to 52 rows (13 head tiles), at least three operand tiles.  NNJ_ROW_FUSED=0: k_row_s + k_row_pv.
+  static const bool row_fused_env = getenv("NNJ_ROW_FUSED") && atoi(getenv("NNJ_ROW_FUSED")) != 0;
+  const bool row_fused = row_fused_env && g6.nech == 1 && g6.ETc <= 13 && g6.KS >= 3;
   // reference no-grad chunking: one masked_fill(-10000) per row chunk, summed (axial_attention.py:35-64)
   int nchunks = 1;
   if ((long)T * C > 1024) { int max_rows = 1024 / C; if (max_rows < 1) max_rows = 1; nchunks = (T + max_rows - 1) / max_rows; }
@@ -434,6 +440,23 @@ int launch_encoder(nnj_handle* h, const uint8_t* codes, const float* onehot, con
       hipLaunchKernelGGL(k_qkv6, dim3(grid), dim3(512), lds_qkv, st, (const float*)x, mask,
                          attn_ptrs(h, h->lo[l].row), Q6, K6, V6, g6, B);
     }
+    if (row_fused) {
+      Scope sc(h, st, PK_ROW_PV);
+      const float qs = LOG2E / (sqrtf((float)NNJ_DH) * sqrtf((float)T));
+      const unsigned grid = (unsigned)((nbh + 7) / 8 * 8 * (g6.Cp / 128));
+#define NNJ_RF_CASE(N)                                                                                   \
+  case N: {                                                                                              \
+    const size_t lds = 3 * (NPL * 4096 + NPL * 4096) + 3 * ((N * NPL * 1024 + 4095) / 4096 * 4096);      \
+    if (int rc = set_lds(h, k_row_fused<N>, lds)) return rc;                                             \
+    hipLaunchKernelGGL(k_row_fused<N>, dim3(grid), dim3(256), lds, st, (const uint8_t*)Q6, (const uint8_t*)K6, \
+                       (const uint8_t*)V6, (const uint8_t*)cls, (const uint8_t*)(cls + (size_t)B * g6.Cp), ctx, g6, nbh, fill, qs); \
+  } break;
+      switch (g6.ETc) {
+        NNJ_RF_CASE(1) NNJ_RF_CASE(2) NNJ_RF_CASE(4) NNJ_RF_CASE(6) NNJ_RF_CASE(8) NNJ_RF_CASE(10) NNJ_RF_CASE(13)
+        default: return fail(h, NNJ_ERR_UNSUPPORTED, "row attention: no fused instantiation for %d head tiles", g6.ETc);
+      }
+#undef NNJ_RF_CASE
+    } else {
     {
       Scope sc(h, st, PK_ROW_S);
       const float qs = LOG2E / (sqrtf((float)NNJ_DH) * sqrtf((float)T));
@@ -488,6 +511,7 @@ int launch_encoder(nnj_handle* h, const uint8_t* codes, const float* onehot, con
         default: return fail(h, NNJ_ERR_UNSUPPORTED, "row attention: no instantiation for %d head tiles", g6.ETc);
       }
 #undef NNJ_PV_CASE
+    }
     }
     {
       Scope sc(h, st, PK_TOK1);

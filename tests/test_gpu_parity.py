@@ -905,8 +905,24 @@ def test_sampling_mode_matches_oracle_and_replicates(ctx_cache):
     # oracle's own table: at the first divergent step of a differing trajectory the two picks must be
     # NEIGHBOURS in the flat pair order and the target u * total within the tables' rounding of the boundary
     agree = _certify_sampled(ref, merges, r_all["logits"].cpu().numpy(), u, 3.0, T)
+    # (under the sharpened weights a table's scale is ~400: fp32 rounding of 1e-4 of it moves the CDF by up to 2.7 % of
+    # the mass per step, so a good part of 19-step trajectories meets a boundary case -- each one certified above.  The
+    # reference-scale case below is where agreement itself is asserted.)
     assert agree.mean() >= 0.5
     assert_logits_close(r_all["logits"].cpu().numpy()[agree], ref["logits"][agree], RTOL, "sampled tables")
+    # reference-scale ("plain") weights: the tables' rounding is 1e-6 of a small scale, a boundary case is rare --
+    # at least 90 % of 48 trajectories identical to the oracle twin, every other one certified (VERDICT r3 "weak" 6)
+    zp, cfgp, packp = load_golden("plain_b1_t12_l96_s4")
+    gp, op = ctx_cache(cfgp, packp), _oracle(cfgp, packp)
+    Bp, Tp = 48, zp["codes"].shape[1]
+    up = np.random.default_rng(12).random((Bp, Tp - 1)).astype(np.float32)
+    rp = gp.rollout_sample(torch.from_numpy(zp["codes"]), torch.from_numpy(zp["mask"]), up, temperature=1.0, replicas=Bp,
+                           want_trace=True)
+    refp = op.rollout_sample(synth.codes_to_onehot(np.repeat(zp["codes"], Bp, 0)).astype(np.float32),
+                             np.repeat(zp["mask"], Bp, 0), up, temperature=1.0)
+    agree_p = _certify_sampled(refp, rp["merges"].cpu().numpy(), rp["logits"].cpu().numpy(), up, 1.0, Tp)
+    assert agree_p.mean() >= 0.9, f"only {agree_p.sum()} of {Bp} sampled trajectories equal the oracle's under plain weights"
+    assert len({tuple(m.reshape(-1)) for m in rp["merges"].cpu().numpy()}) > 4
     cold = g.rollout_sample(torch.from_numpy(codes1), torch.from_numpy(mask1), u[:1], temperature=1e-4)
     assert np.array_equal(cold["merges"].cpu().numpy(), z["merges"])
     with pytest.raises(RuntimeError):
