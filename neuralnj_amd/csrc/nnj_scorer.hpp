@@ -963,8 +963,26 @@ __global__ __launch_bounds__(256) void k_assemble_argmax(const float* __restrict
   const size_t bsrc = so.rep0 ? 0 : b;                      // whose all-pairs partials this table is assembled from
   const int np = num_pairs(n), np_prev = num_pairs(n + 1);
   int ip = 0, jp = 0;
+  if (mode == PAIRS_INCR) { ip = ij_prev[2 * b]; jp = ij_prev[2 * b + 1]; }
+  // Round 4 (one alignment per rollout: this kernel is a chain of dependent L2 round trips, 11.8 us of a 46 us step):
+  // everything the two-pass tail needs that does NOT depend on the pick is fetched here, behind the table pass -- the
+  // carried candidate's pair, its logits' partial sums (used only if the pick turns out to be that pair: same sums, same
+  // order), the per-row bias of every position.
+  int cc0 = -2, cc1 = -2;
+  float a_cand = 0.f, beta_r = 0.f;
+  if (so.am) {
+    if (so.acand_part && so.cand_cur) {
+      cc0 = so.cand_cur[2 * b]; cc1 = so.cand_cur[2 * b + 1];
+      const int r = tid & 63, part = tid >> 6;
+      if (r < n) {
+        const int col = (mode == PAIRS_INCR && r == ip) ? 63 : r - ((mode == PAIRS_INCR && r > ip) ? 1 : 0);
+#pragma unroll 16
+        for (int k = part; k < so.nblk; k += 4) a_cand += so.acand_part[((size_t)b * so.nblk + k) * 64 + col];
+      }
+    }
+    if (tid < 64 && tid < n) beta_r = so.beta_slot[(size_t)b * so.nslot + live_cur[(size_t)b * live_stride + tid]];
+  }
   if (mode == PAIRS_INCR) {
-    ip = ij_prev[2 * b]; jp = ij_prev[2 * b + 1];
     if (qn && nsc > 8) {
       // many partials (small batch: many workgroups per alignment) and at most 64 new scores: four threads per score,
       // every 4th partial each, the four sums added in order
@@ -1111,7 +1129,7 @@ __global__ __launch_bounds__(256) void k_assemble_argmax(const float* __restrict
     src = 1;
     const int rs_ = pi_ == ip ? pj_ : pi_;
     qs = rs_ - (rs_ > ip ? 1 : 0);
-  } else if (so.acand_part && so.cand_cur && so.cand_cur[2 * b] == pi_ && so.cand_cur[2 * b + 1] == pj_) {
+  } else if (so.acand_part && so.cand_cur && cc0 == pi_ && cc1 == pj_) {
     src = 2;
   } else if (mode == PAIRS_FULL && so.alpha0) {
     src = 3;                                               // step 0: every pair was scored in this step
@@ -1130,15 +1148,8 @@ __global__ __launch_bounds__(256) void k_assemble_argmax(const float* __restrict
   }
   if (src == 2) {
     // the candidate's logits: the partials of the k_step_alpha workgroups, four threads per row (every 4th block
-    // each), the four sums added in order by wave 0 below
-    const int r = tid & 63, part = tid >> 6;
-    float a = 0.f;
-    if (r < n) {
-      const int col = (mode == PAIRS_INCR && r == ip) ? 63 : r - ((mode == PAIRS_INCR && r > ip) ? 1 : 0);
-#pragma unroll 16
-      for (int k = part; k < so.nblk; k += 4) a += so.acand_part[((size_t)b * so.nblk + k) * 64 + col];
-    }
-    pval[PCACHE - 256 + tid] = a;                           // (entries the table never reaches: np <= 2080 when src == 2)
+    // each; summed at the top of the kernel), the four sums added in order by wave 0 below
+    pval[PCACHE - 256 + tid] = a_cand;                      // (entries the table never reaches: np <= 2080 when src == 2)
     __syncthreads();
   }
   if (tid < 64) {
@@ -1149,7 +1160,7 @@ __global__ __launch_bounds__(256) void k_assemble_argmax(const float* __restrict
       float a;
       if (src == 1) a = so.lam[((size_t)b * 64 + qs) * 64 + (r - (r > ip ? 1 : 0))];
       else a = ((pval[PCACHE - 256 + r] + pval[PCACHE - 192 + r]) + pval[PCACHE - 128 + r]) + pval[PCACHE - 64 + r];   // src 2, 3
-      v = (a + so.beta_slot[(size_t)b * so.nslot + live_cur[(size_t)b * live_stride + r]]) * so.inv_scale;
+      v = (a + beta_r) * so.inv_scale;
     }
     float mx = v;
 #pragma unroll
