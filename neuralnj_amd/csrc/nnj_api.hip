@@ -47,6 +47,7 @@ struct nnj_handle {
   nnj_config cfg;
   bool have_w = false;
   float* d_w = nullptr;          // packed weights followed by derived tensors
+  float* d_wimg = nullptr;       // the scorer's four 64 x 64 operands as ready LDS images (k_build_scorer_images)
   size_t n_packed = 0;
   std::vector<LayerOff> lo;
   size_t oE0, oe0, oE2, oe2, oWh, obh, oWg, obg, oWgq, obgq, oWgk, obgk, oS0, os0, os2w, os2b;
@@ -136,6 +137,7 @@ ScorerW scorer_ptrs(const nnj_handle* h) {
   s.Wh = w + h->oWhS; s.bh = w + h->obhS; s.Wg = w + h->oWgS; s.bg = w + h->obgS;   // pre-scaled by -log2(e)
   s.A = w + h->oA; s.a0 = w + h->oa0; s.u = w + h->ou; s.t0 = h->t0;
   s.S0 = w + h->oS0; s.s0 = w + h->os0; s.s2w = w + h->os2w; s.s2b = h->s2b;
+  s.imgAt = h->d_wimg; s.imgWh = h->d_wimg + IMG64; s.imgWg = h->d_wimg + 2 * IMG64; s.imgS0 = h->d_wimg + 3 * IMG64;
   return s;
 }
 
@@ -1149,6 +1151,7 @@ int nnj_destroy(nnj_handle* h) {
   if (!h) return NNJ_OK;
   hipSetDevice(h->cfg.device);
   if (h->d_w) hipFree(h->d_w);
+  if (h->d_wimg) hipFree(h->d_wimg);
   if (h->d_flag) hipFree(h->d_flag);
   if (h->gexec) hipGraphExecDestroy(h->gexec);
   for (int k = 0; k < 4; ++k) {
@@ -1259,6 +1262,9 @@ int nnj_load_weights(nnj_handle* h, const float* p, size_t n) {
   if (h->gexec) { hipGraphExecDestroy(h->gexec); h->gexec = nullptr; }      // captured launches point at the old weights
   HIPCHK(h, hipMalloc(&h->d_w, total * sizeof(float)));
   HIPCHK(h, hipMemcpy(h->d_w, host.data(), total * sizeof(float), hipMemcpyHostToDevice));
+  if (!h->d_wimg) HIPCHK(h, hipMalloc(&h->d_wimg, 4 * (size_t)IMG64 * sizeof(float)));
+  hipLaunchKernelGGL(k_build_scorer_images, dim3(1), dim3(512), 0, nullptr, scorer_ptrs(h), h->d_wimg);
+  HIPCHK(h, hipDeviceSynchronize());
   h->have_w = true;
   return NNJ_OK;
 }
@@ -1290,6 +1296,17 @@ int nnj_workspace_selfcheck(int32_t B, int32_t T, int32_t C) {
     }
   return 0;
 }
+
+#ifdef NNJ_STAMP
+// diagnostic builds only (tools/stamp_run.py): read and clear the in-kernel stamp accumulators of k_inc_score_w
+int nnj_debug_read_stamps(unsigned long long* out8) {
+  if (hipDeviceSynchronize() != hipSuccess) return NNJ_ERR_HIP;
+  if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_stamp), 8 * sizeof(unsigned long long)) != hipSuccess) return NNJ_ERR_HIP;
+  unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (hipMemcpyToSymbol(HIP_SYMBOL(g_stamp), z, sizeof(z)) != hipSuccess) return NNJ_ERR_HIP;
+  return NNJ_OK;
+}
+#endif
 
 int nnj_workspace_bytes(const nnj_handle* h, int32_t B, int32_t T, int32_t L_sites, size_t* bytes) {
   if (!h || !bytes || B <= 0 || T < 1 || L_sites <= 0) return fail(const_cast<nnj_handle*>(h), NNJ_ERR_ARG, "nnj_workspace_bytes: bad argument");

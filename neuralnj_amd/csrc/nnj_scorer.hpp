@@ -23,7 +23,25 @@ struct ScorerW {
   float t0;                    // b_q . b_k
   const float *S0, *s0, *s2w;  // s_out.0 weight/bias, s_out.2 weight
   float s2b;                   // s_out.2 bias
+  // round 4: the four 64 x 64 operands of the 16-token kernels as ready LDS images (stage_weight_t16's layout: two fp16
+  // planes, swizzled), built ONCE on the device when the weights are loaded (k_build_scorer_images): a workgroup copies
+  // 16 KiB per matrix instead of loading, splitting and storing it -- at one alignment per rollout the split was a
+  // quarter of every NJ-step kernel.  imgAt = the image of A^T.
+  const float *imgAt, *imgWh, *imgWg, *imgS0;
 };
+// copy of a ready [64][64] operand image (IMG64 floats) into LDS
+__device__ __forceinline__ void stage_image_t16(float* lds, const float* __restrict__ gimg, int tid, int nthreads) {
+  const f32x4* g4 = reinterpret_cast<const f32x4*>(gimg);
+  f32x4* l4 = reinterpret_cast<f32x4*>(lds);
+  for (int i = tid; i < IMG64 / 4; i += nthreads) l4[i] = g4[i];
+}
+// the images themselves (one workgroup; `out` = 4 x IMG64 floats: A^T | W_h | W_g | S0)
+__global__ void k_build_scorer_images(ScorerW w, float* __restrict__ out) {
+  stage_weight_t16(out, w.A, 64, threadIdx.x, blockDim.x, true);
+  stage_weight_t16(out + IMG64, w.Wh, 64, threadIdx.x, blockDim.x);
+  stage_weight_t16(out + 2 * IMG64, w.Wg, 64, threadIdx.x, blockDim.x);
+  stage_weight_t16(out + 3 * IMG64, w.S0, 64, threadIdx.x, blockDim.x);
+}
 
 struct RowSet {                // where the rows of one call live
   const float* S;              // [B][slots][C][64]

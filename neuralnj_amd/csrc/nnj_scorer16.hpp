@@ -88,8 +88,8 @@ __global__ __launch_bounds__(64 * NW) void k_inc_alpha16(RowSet rs, ScorerW w, c
   int* cnt0 = reinterpret_cast<int*>(smem + 2 * IMG64 + NSLOT * IMG);
   const int sc = blockIdx.x, b = blockIdx.y;
   const int c0 = sc * cs, c1 = min(C, c0 + cs);
-  stage_weight_t16(At_l, w.A, 64, tid, 64 * NW, true);
-  stage_weight_t16(Wh_l, w.Wh, 64, tid, 64 * NW);
+  stage_image_t16(At_l, w.imgAt, tid, 64 * NW);
+  stage_image_t16(Wh_l, w.imgWh, tid, 64 * NW);
   float* cv = smem + 2 * IMG64 + NSLOT * IMG + 16;
   stage_scorer_consts(cv, w, tid);
   if (tid < NSLOT) cnt0[tid] = 0;
@@ -190,9 +190,9 @@ __global__ __launch_bounds__(64 * T16_WAVES) void k_inc_score16(RowSet rs, Score
   float* img = smem + 3 * IMG64 + slot * IMG;
   const int sc = blockIdx.x, b = blockIdx.y;
   const int c0 = sc * cs, c1 = min(C, c0 + cs);
-  stage_weight_t16(Wg_l, w.Wg, 64, tid, 64 * T16_WAVES);
-  stage_weight_t16(S0_l, w.S0, 64, tid, 64 * T16_WAVES);
-  stage_weight_t16(Wh_l, w.Wh, 64, tid, 64 * T16_WAVES);
+  stage_image_t16(Wg_l, w.imgWg, tid, 64 * T16_WAVES);
+  stage_image_t16(S0_l, w.imgS0, tid, 64 * T16_WAVES);
+  stage_image_t16(Wh_l, w.imgWh, tid, 64 * T16_WAVES);
   float* cv = smem + 3 * IMG64 + NSLOT * IMG + 16;
   stage_scorer_consts(cv, w, tid);
   if constexpr (NG == 3) {                                 // columns 48..63 are never written: they meet alpha = 0 but must be finite
@@ -321,6 +321,17 @@ __global__ __launch_bounds__(64 * T16_WAVES) void k_inc_score16(RowSet rs, Score
   }
 }
 
+// -DNNJ_STAMP: a DIAGNOSTIC build (never shipped: tools/stamp_run.py) that stamps the site loop of k_inc_score_w with
+// s_memtime and adds the per-phase cycle counts of every wave into g_stamp (cdna_hip_programming.md section 7, "In-kernel
+// stamps"): [0] iterations, [1] row loads until they have landed, [2] phase A (U_r, gate, image) of all tiles,
+// [3 + t] phase B (x_g, W_g, mix, s_out, GELU) of tile t.
+#ifdef NNJ_STAMP
+__device__ unsigned long long g_stamp[8];
+__device__ __forceinline__ unsigned long long stamp_now() {
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  return __builtin_amdgcn_s_memtime();
+}
+#endif
 // ------------------------------------------------------------------ k_inc_score_w
 // scores of the new pairs with ONE WAVE PER SITE: the wave walks the NT 16-pair tiles of its site itself, so the
 // site image S^T [2 planes][64 d][16*NT r'] is private to the wave and nothing in the loop synchronises with
@@ -349,9 +360,9 @@ __global__ __launch_bounds__(64 * NW) void k_inc_score_w(RowSet rs, ScorerW w, c
   float* img = smem + 3 * IMG64 + wave * IMG;
   const int sc = blockIdx.x, b = blockIdx.y;
   const int c0 = sc * cs, c1 = min(C, c0 + cs);
-  stage_weight_t16(Wg_l, w.Wg, 64, tid, 64 * NW);
-  stage_weight_t16(S0_l, w.S0, 64, tid, 64 * NW);
-  stage_weight_t16(Wh_l, w.Wh, 64, tid, 64 * NW);
+  stage_image_t16(Wg_l, w.imgWg, tid, 64 * NW);
+  stage_image_t16(S0_l, w.imgS0, tid, 64 * NW);
+  stage_image_t16(Wh_l, w.imgWh, tid, 64 * NW);
   float* cv = smem + 3 * IMG64 + NW * IMG;
   stage_scorer_consts(cv, w, tid);
   // the alpha pieces of this alignment's pairs sit in LDS for the lifetime of the workgroup (two planes of
@@ -390,8 +401,14 @@ __global__ __launch_bounds__(64 * NW) void k_inc_score_w(RowSet rs, ScorerW w, c
   auto wsw = [](int d, int chunk) { if constexpr (NT == 3) return chunk; else return tswz<NT>(d, chunk); };
   unsigned short* t16 = reinterpret_cast<unsigned short*>(img);
   const u32x4* im4 = reinterpret_cast<const u32x4*>(img);
+#ifdef NNJ_STAMP
+  unsigned long long st_n = 0, st_load = 0, st_a = 0, st_b[4] = {0, 0, 0, 0};
+#endif
   for (int c = c0 + wave; c < c1; c += NW) {
     asm volatile("" ::: "memory");
+#ifdef NNJ_STAMP
+    const unsigned long long T0 = stamp_now();
+#endif
     const float mc = mask[(size_t)b * C + c] ? 0.f : 1.f;               // seq_mask (model.py:96); first load of the iteration
     V64 x[NT];
     {
@@ -400,6 +417,10 @@ __global__ __launch_bounds__(64 * NW) void k_inc_score_w(RowSet rs, ScorerW w, c
       for (int t = 0; t < NT; ++t) load_v64(sr[t], Sr[t] + (size_t)c * 64, kq);
       load_v64(sm, Sm + (size_t)c * 64, kq);
       load_v64(um, Um + (size_t)c * 64, kq);
+#ifdef NNJ_STAMP
+      const unsigned long long T1 = stamp_now();
+      st_load += T1 - T0; ++st_n;
+#endif
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
         // fp16 pieces of S_r: B operand of U_r = W_h S_r (recomputed, see k_inc_alpha16) and, transposed, the
@@ -430,6 +451,10 @@ __global__ __launch_bounds__(64 * NW) void k_inc_score_w(RowSet rs, ScorerW w, c
         __builtin_amdgcn_sched_barrier(0);
       }
     }
+#ifdef NNJ_STAMP
+    unsigned long long TP = stamp_now();
+    st_a += TP - T0;                                        // (includes the loads: [2] - [1] is phase A proper)
+#endif
     // x_g^T = S^T alpha^T, W_g, mix, s_out per tile.  Image rows are 16*NT fp16 (96 bytes at NT = 3: rows d and
     // d+8 share banks, the 16 lanes of a read group hold 8 distinct d per chunk parity -- conflict free without
     // a swizzle).  Lanes whose chunk lies beyond a short row read the row's last chunk: finite data against
@@ -482,8 +507,17 @@ __global__ __launch_bounds__(64 * NW) void k_inc_score_w(RowSet rs, ScorerW w, c
       score[t] += (s + w.s2b) * mc;
       asm volatile("" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
+#ifdef NNJ_STAMP
+      { const unsigned long long TN = stamp_now(); st_b[t < 4 ? t : 3] += TN - TP; TP = TN; }
+#endif
     }
   }
+#ifdef NNJ_STAMP
+  if (lane == 0) {
+    atomicAdd(&g_stamp[0], st_n); atomicAdd(&g_stamp[1], st_load); atomicAdd(&g_stamp[2], st_a);
+    for (int t = 0; t < NT && t < 4; ++t) atomicAdd(&g_stamp[3 + t], st_b[t]);
+  }
+#endif
   // one partial set per WORKGROUP: the waves' sums meet in LDS (the images are dead) and are added in wave order
   __syncthreads();
   float* red = smem + 3 * IMG64;                           // [NW][64]

@@ -105,9 +105,9 @@ __global__ __launch_bounds__(64 * NW) void k_inc_score_g(RowSet rs, ScorerW w, c
   const int sc = blockIdx.x, b = blockIdx.y;
   const int c0 = sc * cs, c1 = min(C, c0 + cs);
   const int P = n - 1;
-  stage_weight_t16(Wg_l, w.Wg, 64, tid, 64 * NW);
-  stage_weight_t16(S0_l, w.S0, 64, tid, 64 * NW);
-  stage_weight_t16(Wh_l, w.Wh, 64, tid, 64 * NW);
+  stage_image_t16(Wg_l, w.imgWg, tid, 64 * NW);
+  stage_image_t16(S0_l, w.imgS0, tid, 64 * NW);
+  stage_image_t16(Wh_l, w.imgWh, tid, 64 * NW);
   stage_scorer_consts(cv, w, tid);
   // image rows beyond the pairs are never written: they meet alpha = 0 and must be finite
   for (int i = tid; i < NW * IMGF + SLACK; i += 64 * NW) imgs[i] = 0.f;

@@ -59,8 +59,8 @@ __global__ __launch_bounds__(512) void k_wide_alpha(RowSet rs, ScorerW w, const 
   const bool full = ij_prev == nullptr;
   const WideStar st = wide_star(rs, ij_prev, m0, b, n);
   const int c0 = sc * cs, c1 = min(C, c0 + cs);
-  stage_weight_t16(At_l, w.A, 64, tid, 512, true);
-  stage_weight_t16(Wh_l, w.Wh, 64, tid, 512);
+  stage_image_t16(At_l, w.imgAt, tid, 512);
+  stage_image_t16(Wh_l, w.imgWh, tid, 512);
   float* cv = smem + 2 * IMG64 + 64 * RP;
   stage_scorer_consts(cv, w, tid);
   const size_t bo = (size_t)b * rs.bstride;
@@ -210,9 +210,9 @@ __global__ __launch_bounds__(512) void k_wide_score(RowSet rs, ScorerW w, const 
   const bool full = ij_prev == nullptr;
   const WideStar st = wide_star(rs, ij_prev, m0, b, n);
   const int c0 = sc * cs, c1 = min(C, c0 + cs);
-  stage_weight_t16(Wg_l, w.Wg, 64, tid, 512);
-  stage_weight_t16(S0_l, w.S0, 64, tid, 512);
-  stage_weight_t16(Wh_l, w.Wh, 64, tid, 512);
+  stage_image_t16(Wg_l, w.imgWg, tid, 512);
+  stage_image_t16(S0_l, w.imgS0, tid, 512);
+  stage_image_t16(Wh_l, w.imgWh, tid, 512);
   float* cv = smem + 3 * IMG64 + 64 * RP;
   stage_scorer_consts(cv, w, tid);
   const size_t bo = (size_t)b * rs.bstride;

@@ -126,9 +126,9 @@ __global__ __launch_bounds__(64 * NW) void k_step_alpha(RowSet rs, ScorerW w, St
   float* epi = cv + SCORER_CONSTS;                         // [NSLOT][64 + 2] sums of the epilogue
   const int sc = blockIdx.x, b = blockIdx.y;
   const int c0 = sc * cs, c1 = min(C, c0 + cs);
-  stage_weight_t16(At_l, w.A, 64, tid, 64 * NW, true);
-  stage_weight_t16(Wh_l, w.Wh, 64, tid, 64 * NW);
-  stage_weight_t16(Wg_l, w.Wg, 64, tid, 64 * NW);
+  stage_image_t16(At_l, w.imgAt, tid, 64 * NW);
+  stage_image_t16(Wh_l, w.imgWh, tid, 64 * NW);
+  stage_image_t16(Wg_l, w.imgWg, tid, 64 * NW);
   stage_scorer_consts(cv, w, tid);
   if (tid < NSLOT) cnt0[tid] = 0;
   __syncthreads();
@@ -399,9 +399,9 @@ __global__ __launch_bounds__(64 * NW) void k_step_alpha_w(RowSet rs, ScorerW w, 
   float* epi = cv + SCORER_CONSTS;                         // [NW][64 + 2] sums of the epilogue
   const int sc = blockIdx.x, b = blockIdx.y;
   const int c0 = sc * cs, c1 = min(C, c0 + cs);
-  stage_weight_t16(At_l, w.A, 64, tid, 64 * NW, true);
-  stage_weight_t16(Wh_l, w.Wh, 64, tid, 64 * NW);
-  stage_weight_t16(Wg_l, w.Wg, 64, tid, 64 * NW);
+  stage_image_t16(At_l, w.imgAt, tid, 64 * NW);
+  stage_image_t16(Wh_l, w.imgWh, tid, 64 * NW);
+  stage_image_t16(Wg_l, w.imgWg, tid, 64 * NW);
   stage_scorer_consts(cv, w, tid);
   __syncthreads();
   const int m = min(max(io.ij[2 * b], 0), n - 1);

@@ -43,9 +43,9 @@ __global__ __launch_bounds__(64 * NW) void k_step_alpha_g(RowSet rs, ScorerW w, 
   const int sc = blockIdx.x, b = blockIdx.y;
   const int c0 = sc * cs, c1 = min(C, c0 + cs);
   const int P = n - 1;
-  stage_weight_t16(At_l, w.A, 64, tid, 64 * NW, true);
-  stage_weight_t16(Wh_l, w.Wh, 64, tid, 64 * NW);
-  stage_weight_t16(Wg_l, w.Wg, 64, tid, 64 * NW);
+  stage_image_t16(At_l, w.imgAt, tid, 64 * NW);
+  stage_image_t16(Wh_l, w.imgWh, tid, 64 * NW);
+  stage_image_t16(Wg_l, w.imgWg, tid, 64 * NW);
   stage_scorer_consts(cv, w, tid);
   const int m = min(max(io.ij[2 * b], 0), n - 1);
   if (tid < 64) {
@@ -152,7 +152,7 @@ __global__ __launch_bounds__(64 * NW) void k_step_alpha_g(RowSet rs, ScorerW w, 
   for (int cg = c0 + G * wave; cg < c1; cg += G * NW) {
     asm volatile("" ::: "memory");
     // ---- 1. the rows of the group's sites -> images (fp16 pieces)
-    V64 srk[NT == 1 ? 1 : 1];                              // one tile per group: the rows stay in registers for step 4
+    V64 srk[1];                                            // one tile per group (NT == 1): the rows stay in registers for step 4
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       const int cs_ = min(cg + gq[t], c1 - 1);
