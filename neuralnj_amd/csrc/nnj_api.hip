@@ -797,12 +797,12 @@ int launch_step2(nnj_handle* h, RowSet rs, const int* live_old, const int* ij, c
     if (int rc = set_lds(h, (k_step_alpha<NG, NW>), lds)) return rc;                                            \
     hipLaunchKernelGGL((k_step_alpha<NG, NW>), grid, dim3(64 * NW), lds, st, rs, sw, io, n, C, g.cs, h->d_flag); \
   } break;
-#define NNJ_SW(NT, NW)                                                                                          \
-  case NT: {                                                                                                    \
+#define NNJ_SW(NT, NW, IL)                                                                                      \
+  {                                                                                                             \
     const size_t lds = (size_t)(3 * IMG64 + NW * (1024 * NT + 64 * 5) + SCORER_CONSTS + NW * 66 + 16) * sizeof(float); \
-    if (int rc = set_lds(h, (k_step_alpha_w<NT, NW>), lds)) return rc;                                          \
-    hipLaunchKernelGGL((k_step_alpha_w<NT, NW>), grid, dim3(64 * NW), lds, st, rs, sw, io, n, C, g.cs);         \
-  } break;
+    if (int rc = set_lds(h, (k_step_alpha_w<NT, NW, IL>), lds)) return rc;                                      \
+    hipLaunchKernelGGL((k_step_alpha_w<NT, NW, IL>), grid, dim3(64 * NW), lds, st, rs, sw, io, n, C, g.cs);     \
+  }
     // shared tiles + the merged rows of a group of sites as one tile (nnj_step_g.hpp).  NNJ_ALPHA_G: bit mask of the
     // tiers that use it (as NNJ_SCORE_G): 1 = up to 4 pairs (four sites per group), 2 = 5..8 (two), 4 = 17..24 (two),
     // 8 = the remaining tiers with one site per group
@@ -822,7 +822,11 @@ int launch_step2(nnj_handle* h, RowSet rs, const int* live_old, const int* ij, c
     else
 #undef NNJ_AG
     if (h->step_w && (ng == 2 || ng == 3)) {
-      switch (ng) { NNJ_SW(2, 8) NNJ_SW(3, 8) }
+      // NNJ_ALPHA_IL (bit 2: 17..32 pairs): step 3 of the two tiles stage by stage (three tiles: 52 registers spilled)
+      static const int alpha_il = getenv("NNJ_ALPHA_IL") ? atoi(getenv("NNJ_ALPHA_IL")) : 2;
+      if (ng == 2 && (alpha_il & 2)) NNJ_SW(2, 8, true)
+      else if (ng == 2) NNJ_SW(2, 8, false)
+      else NNJ_SW(3, 8, false)
     } else {
       switch (ng) { NNJ_SA(1, 12) NNJ_SA(2, 12) NNJ_SA(3, 12) NNJ_SA(4, 12) }
     }
@@ -875,10 +879,20 @@ int launch_step2(nnj_handle* h, RowSet rs, const int* live_old, const int* ij, c
                            base + w.score_part, n, C, g.cs, 1);
       }
     } else if (np > 32 && np <= 48) {
+      // NNJ_SCORE_IL (bit 1: 33..48 pairs, bit 2: 17..32; default 2): the tiles of a site stage by stage (k_inc_score_wi).
+      // Same box, ms per rollout of 256: two tiles 8.7 -> 7.9; three tiles as a group of two and a single 27 -> 28.4
+      // (all three at once: 45 registers spilled, 36) -- profiles/r04/ab_stage_by_stage.txt
+      static const int score_il = getenv("NNJ_SCORE_IL") ? atoi(getenv("NNJ_SCORE_IL")) : 2;
       const size_t lds = (size_t)(3 * IMG64 + 8 * (64 * 48 * NPL / 2) + SCORER_CONSTS + 3 * 1024) * sizeof(float);
-      if (int rc = set_lds(h, k_inc_score_w<3, true>, lds)) return rc;
-      hipLaunchKernelGGL((k_inc_score_w<3, true>), grid, dim3(512), lds, st, rs, sw, ij, base + w.alpha, mask,
-                         base + w.score_part, n, C, g.cs, 1);
+      if (score_il & 1) {
+        if (int rc = set_lds(h, (k_inc_score_wi<3>), lds)) return rc;
+        hipLaunchKernelGGL((k_inc_score_wi<3>), grid, dim3(512), lds, st, rs, sw, ij, base + w.alpha, mask,
+                           base + w.score_part, n, C, g.cs, 1);
+      } else {
+        if (int rc = set_lds(h, k_inc_score_w<3, true>, lds)) return rc;
+        hipLaunchKernelGGL((k_inc_score_w<3, true>), grid, dim3(512), lds, st, rs, sw, ij, base + w.alpha, mask,
+                           base + w.score_part, n, C, g.cs, 1);
+      }
     } else if (np > 32) {
       const size_t lds = (size_t)(3 * IMG64 + 4 * b6_floats(64, 64) + 16 + SCORER_CONSTS) * sizeof(float);
       if (int rc = set_lds(h, k_inc_score<2, true>, lds)) return rc;
@@ -888,10 +902,17 @@ int launch_step2(nnj_handle* h, RowSet rs, const int* live_old, const int* ij, c
       // 17..32 pairs: one wave per site walks two 16-pair tiles (k_inc_score_w<2>), like the three-tile tier -- 0.8 % faster
       // than the 32-pair kernel with its group barriers, 192 registers and no scratch instead of 256 + 16 bytes
       // (NNJ_SCORE_W2=0: the 32-pair kernel)
+      static const int score_il2 = getenv("NNJ_SCORE_IL") ? atoi(getenv("NNJ_SCORE_IL")) : 2;
       const size_t lds = (size_t)(3 * IMG64 + 8 * (64 * 32 * NPL / 2) + SCORER_CONSTS + 2 * 1024) * sizeof(float);
+      if (score_il2 & 2) {
+        if (int rc = set_lds(h, (k_inc_score_wi<2>), lds)) return rc;
+        hipLaunchKernelGGL((k_inc_score_wi<2>), grid, dim3(512), lds, st, rs, sw, ij, base + w.alpha, mask,
+                           base + w.score_part, n, C, g.cs, 1);
+      } else {
       if (int rc = set_lds(h, (k_inc_score_w<2, true>), lds)) return rc;
       hipLaunchKernelGGL((k_inc_score_w<2, true>), grid, dim3(512), lds, st, rs, sw, ij, base + w.alpha, mask,
                          base + w.score_part, n, C, g.cs, 1);
+      }
     } else {
       const size_t lds = (size_t)(3 * IMG64 + 8 * b6_floats(64, 32) + 16 + SCORER_CONSTS) * sizeof(float);
       if (int rc = set_lds(h, k_inc_score<1, true>, lds)) return rc;

@@ -713,6 +713,49 @@ __device__ __forceinline__ void linear_t16p_core(f32x4 (&out)[MT], const Frag3 (
     issue(std::integral_constant<int, s + PF>{});
   });
 }
+// NT token tiles through ONE 64 x 64 linear: every weight fragment is read once and multiplies the NT tiles' B
+// fragments -- a third of the fragment reads at NT = 3, and between two waits the matrix pipe has 3 NT products on NT
+// independent accumulators (piece products outermost, so consecutive MFMAs never depend on each other; per accumulator
+// the order is the one of mfma16_b6: bit-identical results).
+template <int NT, int PF = 2, typename PRE>
+__device__ __forceinline__ void linear_t16p_multi(V64 (&out)[NT], Frag3 (&bfr)[NT][2], const float* W, int lane,
+                                                  PRE&& pre) {
+  const int l15 = lane & 15, kq = lane >> 4;
+  constexpr int MT = 4, NS = 2 * MT;
+  constexpr int PLANE = 16 * MT * 8 * 16;                  // bytes
+  const int sw = (l15 >> 1) & 7;
+  const unsigned ad[2] = {lds_addr(W) + (unsigned)(l15 * 8 + (kq ^ sw)) * 16u,
+                          lds_addr(W) + (unsigned)(l15 * 8 + ((4 + kq) ^ sw)) * 16u};
+  Frag3 a[PF];
+  auto issue = [&](auto si) {
+    constexpr int s = decltype(si)::value;
+    if constexpr (s < NS) {
+      constexpr int ks = s / MT, mt = s % MT;
+      lds_read_frag<mt * 2048>(a[s % PF].h, ad[ks]);
+      lds_read_frag<mt * 2048 + PLANE>(a[s % PF].m, ad[ks]);
+    }
+  };
+  static_for<0, PF>([&](auto si) { issue(si); });
+  static_for<0, NS>([&](auto si) {
+    constexpr int s = decltype(si)::value;
+    constexpr int ks = s / MT, mt = s % MT;
+    constexpr int ahead = (s + PF - 1 < NS - 1 ? s + PF - 1 : NS - 1) - s;
+    if constexpr (mt == 0) pre(std::integral_constant<int, ks>{});     // the caller forms the B fragments of k-step ks (pure vector work)
+    lds_wait_le<2 * ahead>();
+    pin_frag(a[s % PF]);
+#ifdef NNJ_MM4
+#pragma unroll
+    for (int t = 0; t < NT; ++t) out[t].t[mt] = mfma16_f16(a[s % PF].m, bfr[t][ks].m, out[t].t[mt]);
+#endif
+#pragma unroll
+    for (int t = 0; t < NT; ++t) out[t].t[mt] = mfma16_f16(a[s % PF].m, bfr[t][ks].h, out[t].t[mt]);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) out[t].t[mt] = mfma16_f16(a[s % PF].h, bfr[t][ks].m, out[t].t[mt]);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) out[t].t[mt] = mfma16_f16(a[s % PF].h, bfr[t][ks].h, out[t].t[mt]);
+    issue(std::integral_constant<int, s + PF>{});
+  });
+}
 template <int MT, bool ACC, bool BIAS = true, int PF = 2, bool MIX = true>
 __device__ __forceinline__ void linear_t16p(f32x4 (&out)[MT], const V64& in, const float* W, const float* bias,
                                             int lane) {

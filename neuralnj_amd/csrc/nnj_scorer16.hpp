@@ -535,3 +535,221 @@ __global__ __launch_bounds__(64 * NW) void k_inc_score_w(RowSet rs, ScorerW w, c
     score_part[((size_t)b * gridDim.x + sc) * 64 + tid] = v;
   }
 }
+
+// ------------------------------------------------------------------ k_inc_score_wi
+// k_inc_score_w with the tiles of a site walked STAGE BY STAGE in groups of NI instead of tile by tile: each of the
+// four GEMMs of the chain (U_r, x_g, W_g, s_out.0) runs over the NI tiles of a group at once (linear_t16p_multi), so a
+// weight or image fragment is read from LDS once per group instead of once per tile and the matrix pipe always has NI
+// independent accumulator chains; the vector stages between them (split, gate, mix, GELU) are NI independent streams
+// as well.  NI = NT = 3 does not fit 256 registers (45 spilled, 36 ms per rollout against 27): three tiles run as a
+// group of two and a single.  Same image, same operation order per accumulator: results are bit-identical to
+// k_inc_score_w.
+template <int NT, int NI = 2, int NW = 8>
+__global__ __launch_bounds__(64 * NW) void k_inc_score_wi(RowSet rs, ScorerW w, const int* __restrict__ ij_prev,
+                                                      const float* __restrict__ alpha,
+                                                      const uint8_t* __restrict__ mask,
+                                                      float* __restrict__ score_part, int n, int C, int cs, int qn) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int WPF = 2;
+  constexpr int RL = 16 * NT;
+  constexpr int CH = 2 * NT;
+  constexpr int KSX = (NT + 1) / 2;
+  constexpr int IMG = 64 * RL * NPL / 2;
+  constexpr int PLH = 64 * RL;
+  constexpr int PL4 = 64 * CH;
+  constexpr int NGRP = (NT + NI - 1) / NI;
+  float* Wg_l = smem;
+  float* S0_l = smem + IMG64;
+  float* Wh_l = smem + 2 * IMG64;
+  const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, kq = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  float* img = smem + 3 * IMG64 + wave * IMG;
+  const int sc = blockIdx.x, b = blockIdx.y;
+  const int c0 = sc * cs, c1 = min(C, c0 + cs);
+  stage_image_t16(Wg_l, w.imgWg, tid, 64 * NW);
+  stage_image_t16(S0_l, w.imgS0, tid, 64 * NW);
+  stage_image_t16(Wh_l, w.imgWh, tid, 64 * NW);
+  float* cv = smem + 3 * IMG64 + NW * IMG;
+  stage_scorer_consts(cv, w, tid);
+  const long apl = (long)gridDim.y * 4096;
+  constexpr int APL = 16 * NT * 64;
+  unsigned short* alds = reinterpret_cast<unsigned short*>(cv + SCORER_CONSTS);
+  {
+    const unsigned short* ag = reinterpret_cast<const unsigned short*>(alpha) + (size_t)b * 4096;
+    for (int i = tid; i < 2 * 16 * NT * 8; i += 64 * NW) {
+      const int pl = i / (16 * NT * 8), rc = i % (16 * NT * 8), r = rc >> 3, ch = rc & 7;
+      *reinterpret_cast<u32x4*>(alds + pl * APL + r * 64 + 8 * (ch ^ (r & 7))) =
+          *reinterpret_cast<const u32x4*>(ag + pl * apl + r * 64 + 8 * ch);
+    }
+  }
+  __syncthreads();
+  const size_t bo = (size_t)b * rs.bstride;
+  const float* Sr[NT];
+  float sgn[NT], score[NT];
+  int rr[NT];
+  const float *Sm, *Um;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const Inc16 L = inc16(rs, ij_prev, b, n, 16 * t + l15, qn);
+    Sr[t] = rs.S + bo + (size_t)L.slot_r * C * 64;
+    sgn[t] = L.sgn;
+    rr[t] = L.r;
+    score[t] = 0.f;
+    if (t == 0) {
+      Sm = rs.S + bo + (size_t)L.slot_m * C * 64;
+      Um = rs.U + bo + (size_t)L.slot_m * C * 64;
+    }
+  }
+  auto wsw = [](int d, int chunk) { if constexpr (NT == 3) return chunk; else return tswz<NT>(d, chunk); };
+  unsigned short* t16 = reinterpret_cast<unsigned short*>(img);
+  const u32x4* im4 = reinterpret_cast<const u32x4*>(img);
+  for (int c = c0 + wave; c < c1; c += NW) {
+    asm volatile("" ::: "memory");
+    const float mc = mask[(size_t)b * C + c] ? 0.f : 1.f;
+    V64 x[NT];
+    {
+      V64 srall[NT], sm, um;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) load_v64(srall[t], Sr[t] + (size_t)c * 64, kq);
+      load_v64(sm, Sm + (size_t)c * 64, kq);
+      load_v64(um, Um + (size_t)c * 64, kq);
+      static_for<0, NGRP>([&](auto gi) {
+        constexpr int T0 = decltype(gi)::value * NI, N = (NT - T0 < NI ? NT - T0 : NI);
+        V64 ur[N];
+        Frag3 sf[N][2];
+#pragma unroll
+        for (int u = 0; u < N; ++u) gate_init16(ur[u], um, cv, sgn[T0 + u], kq);
+        linear_t16p_multi<N, WPF>(ur, sf, Wh_l, lane, [&](auto ki) {
+          constexpr int ks = decltype(ki)::value;
+#pragma unroll
+          for (int u = 0; u < N; ++u) split_8<false>(sf[u][ks], srall[T0 + u].t[2 * ks], srall[T0 + u].t[2 * ks + 1]);
+        });
+#pragma unroll
+        for (int u = 0; u < N; ++u) {
+          const int wchunk = 2 * (T0 + u) + (l15 >> 3), we = l15 & 7;
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int pr = 0; pr < 2; ++pr) {
+              const unsigned h = sf[u][mt >> 1].h[2 * (mt & 1) + pr], m = sf[u][mt >> 1].m[2 * (mt & 1) + pr];
+              const int d0 = 16 * mt + 4 * kq + 2 * pr, d1 = d0 + 1;
+              const int o0 = d0 * RL + 8 * wsw(d0, wchunk) + we, o1 = d1 * RL + 8 * wsw(d1, wchunk) + we;
+              t16[o0] = (unsigned short)h; t16[o1] = (unsigned short)(h >> 16);
+              t16[PLH + o0] = (unsigned short)m; t16[PLH + o1] = (unsigned short)(m >> 16);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < N; ++u) gate16(x[T0 + u], srall[T0 + u], ur[u], sm);
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+      });
+    }
+    static_for<0, NGRP>([&](auto gi) {
+      constexpr int T0 = decltype(gi)::value * NI, N = (NT - T0 < NI ? NT - T0 : NI);
+      // x_g^T = S^T alpha^T of the group's tiles: one image fragment per (k-step, d tile), N alpha fragments per k-step
+      V64 xg[N];
+#pragma unroll
+      for (int u = 0; u < N; ++u)
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) xg[u].t[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < KSX; ++ks) {
+        Frag3 bfr[N];
+#pragma unroll
+        for (int u = 0; u < N; ++u) {
+          const int ar = 16 * (T0 + u) + l15;
+          const unsigned short* ap_ = alds + ar * 64 + 8 * ((4 * ks + kq) ^ (ar & 7));
+          bfr[u].h = *reinterpret_cast<const u32x4*>(ap_);
+          bfr[u].m = *reinterpret_cast<const u32x4*>(ap_ + APL);
+        }
+        const int lc = min(4 * ks + kq, CH - 1);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+          const int d = 16 * mt + l15;
+          const int o = d * CH + wsw(d, lc);
+          Frag3 a;
+          a.h = im4[o]; a.m = im4[PL4 + o];
+#ifdef NNJ_MM4
+#pragma unroll
+          for (int u = 0; u < N; ++u) xg[u].t[mt] = mfma16_f16(a.m, bfr[u].m, xg[u].t[mt]);
+#endif
+#pragma unroll
+          for (int u = 0; u < N; ++u) xg[u].t[mt] = mfma16_f16(a.m, bfr[u].h, xg[u].t[mt]);
+#pragma unroll
+          for (int u = 0; u < N; ++u) xg[u].t[mt] = mfma16_f16(a.h, bfr[u].m, xg[u].t[mt]);
+#pragma unroll
+          for (int u = 0; u < N; ++u) xg[u].t[mt] = mfma16_f16(a.h, bfr[u].h, xg[u].t[mt]);
+        }
+      }
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      {
+        V64 g[N];
+        Frag3 bx[N][2];
+#pragma unroll
+        for (int u = 0; u < N; ++u)
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt) g[u].t[mt] = *reinterpret_cast<const f32x4*>(cv + 64 + 16 * mt + 4 * kq);
+        linear_t16p_multi<N, WPF>(g, bx, Wg_l, lane, [&](auto ki) {
+          constexpr int ks = decltype(ki)::value;
+#pragma unroll
+          for (int u = 0; u < N; ++u) split_8<false>(bx[u][ks], xg[u].t[2 * ks], xg[u].t[2 * ks + 1]);
+        });
+#pragma unroll
+        for (int u = 0; u < N; ++u)
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float wg = sigmoid_l2(g[u].t[mt][e]);
+              x[T0 + u].t[mt][e] += wg * (xg[u].t[mt][e] - x[T0 + u].t[mt][e]);
+            }
+      }
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      {
+        V64 s1[N];
+        Frag3 bx[N][2];
+#pragma unroll
+        for (int u = 0; u < N; ++u)
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt) s1[u].t[mt] = *reinterpret_cast<const f32x4*>(cv + 128 + 16 * mt + 4 * kq);
+        linear_t16p_multi<N, WPF>(s1, bx, S0_l, lane, [&](auto ki) {
+          constexpr int ks = decltype(ki)::value;
+#pragma unroll
+          for (int u = 0; u < N; ++u) split_8<false>(bx[u][ks], x[T0 + u].t[2 * ks], x[T0 + u].t[2 * ks + 1]);
+        });
+#pragma unroll
+        for (int u = 0; u < N; ++u) {
+          f32x2v s2 = {0.f, 0.f};
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt) {
+            const f32x4 w4 = *reinterpret_cast<const f32x4*>(cv + 192 + 16 * mt + 4 * kq);
+            gelu_dot4(s2, s1[u].t[mt], w4);
+          }
+          float s = s2[0] + s2[1];
+          s += __shfl_xor(s, 16);
+          s += __shfl_xor(s, 32);
+          score[T0 + u] += (s + w.s2b) * mc;
+        }
+      }
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+    });
+  }
+  __syncthreads();
+  float* red = smem + 3 * IMG64;
+  red[wave * 64 + lane] = 0.f;
+  __syncthreads();
+  if (kq == 0) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) red[wave * 64 + rr[t]] = score[t];
+  }
+  __syncthreads();
+  if (tid < 64) {
+    float v = 0.f;
+#pragma unroll
+    for (int s_ = 0; s_ < NW; ++s_) v += red[s_ * 64 + tid];
+    score_part[((size_t)b * gridDim.x + sc) * 64 + tid] = v;
+  }
+}

@@ -383,7 +383,10 @@ __global__ __launch_bounds__(64 * NW) void k_step_alpha(RowSet rs, ScorerW w, St
 // while it finishes the merged row (measured: waiting, not issue, bounds that kernel: VALU 0.15, matrix pipe 0.29 of
 // the cycles).  NW waves per workgroup at <= 512 / ceil(NW / 4) registers; the other waves of the SIMD cover a wave's
 // dependent chains.
-template <int NT, int NW>
+// IL: step 3 over the NT tiles STAGE BY STAGE (linear_t16p_multi: every weight / image fragment read once per site, NT
+// independent accumulator chains; see k_inc_score_wi) and the image rows written from the pieces the U_r product uses
+// (no second split).  Bit-identical results.
+template <int NT, int NW, bool IL = false>
 __global__ __launch_bounds__(64 * NW) void k_step_alpha_w(RowSet rs, ScorerW w, StepIO io, int n, int C, int cs) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int IMG = 16 * NT * 64 * NPL / 2;              // floats of a site image = of the products of its rows
@@ -553,6 +556,93 @@ __global__ __launch_bounds__(64 * NW) void k_step_alpha_w(RowSet rs, ScorerW w, 
     // pieces again (split twice: kept, they and the x of every tile would not fit the registers), U_r = W_h S_r, gate,
     // x' = A^T x, the products with the image; and x'_cand[c] . S_r[c]
     if (has_cand) v_xc[lane] = xc_l;
+    if constexpr (IL) {
+      V64 x[NT];
+      {
+        V64 ur[NT];
+        Frag3 sf[NT][2];
+        {
+          V64 um;
+          load_v64(um, v_um, kq);
+#pragma unroll
+          for (int t = 0; t < NT; ++t) gate_init16(ur[t], um, cv, sgn[t], kq);
+        }
+        lds_wait_all();
+        linear_t16p_multi<NT>(ur, sf, Wh_l, lane, [&](auto ki) {
+          constexpr int ks = decltype(ki)::value;
+#pragma unroll
+          for (int t = 0; t < NT; ++t) split_8(sf[t][ks], sr[t].t[2 * ks], sr[t].t[2 * ks + 1]);
+        });
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          const int q = 16 * t + l15;
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks) {
+            const int o = q * 8 + wswz6<8>(q, 4 * ks + kq);
+            im4[o] = sf[t][ks].h; im4[PL + o] = sf[t][ks].m;
+          }
+        }
+        V64 sm;
+        load_v64(sm, v_sm, kq);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) gate16(x[t], sr[t], ur[t], sm);
+      }
+      if (has_cand) {
+        V64 xcv;
+        load_v64(xcv, v_xc, kq);
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) cacc[t] += xcv.t[mt][e] * sr[t].t[mt][e];
+      }
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      V64 xp[NT];
+      {
+        Frag3 bx[NT][2];
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt) xp[t].t[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        lds_wait_all();
+        linear_t16p_multi<NT>(xp, bx, At_l, lane, [&](auto ki) {
+          constexpr int ks = decltype(ki)::value;
+#pragma unroll
+          for (int t = 0; t < NT; ++t) split_8(bx[t][ks], x[t].t[2 * ks], x[t].t[2 * ks + 1]);
+        });
+      }
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      static_for<0, 2>([&](auto ki) {
+        constexpr int ks = decltype(ki)::value;
+        Frag3 bp[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) split_8(bp[t], xp[t].t[2 * ks], xp[t].t[2 * ks + 1]);
+#pragma unroll
+        for (int mt = 0; mt < NT; ++mt) {
+          const int row = 16 * mt + l15;
+          const int o = row * 8 + wswz6<8>(row, 4 * ks + kq);
+          Frag3 a;
+          a.h = im4[o]; a.m = im4[PL + o];
+#ifdef NNJ_MM4
+#pragma unroll
+          for (int t = 0; t < NT; ++t) acc[t][mt] = mfma16_f16(a.m, bp[t].m, acc[t][mt]);
+#endif
+#pragma unroll
+          for (int t = 0; t < NT; ++t) acc[t][mt] = mfma16_f16(a.m, bp[t].h, acc[t][mt]);
+#pragma unroll
+          for (int t = 0; t < NT; ++t) acc[t][mt] = mfma16_f16(a.h, bp[t].m, acc[t][mt]);
+#pragma unroll
+          for (int t = 0; t < NT; ++t) acc[t][mt] = mfma16_f16(a.h, bp[t].h, acc[t][mt]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      });
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      continue;
+    }
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       Frag3 sf[2];
