@@ -849,8 +849,8 @@ int launch_step2(nnj_handle* h, RowSet rs, const int* live_old, const int* ij, c
     // shared 16-pair tiles (nnj_scorer_g.hpp): G sites per tile group where the pairs of one site leave a tile part
     // empty.  NNJ_SCORE_G is a bit mask of the tiers that use it: 1 = up to 4 pairs (four sites per tile), 2 = 5..8 (two),
     // 4 = 17..24 (three tiles for two sites), 8 = the remaining tiers with one site per group (its transposed-read
-    // image alone, for comparisons)
-    static const int score_g = getenv("NNJ_SCORE_G") ? atoi(getenv("NNJ_SCORE_G")) : 22;
+    // image alone, for comparisons), 32 = 33..40 (five tiles for two sites, k_inc_score_s5).  Default 54 = 2 + 4 + 16 + 32.
+    static const int score_g = getenv("NNJ_SCORE_G") ? atoi(getenv("NNJ_SCORE_G")) : 54;
 #define NNJ_SG(NT, G, IR, NW, ...)                                                                              \
   {                                                                                                            \
     const size_t lds = (size_t)inc_score_g_lds(NT, G, IR, NW) * sizeof(float);                                 \
@@ -865,6 +865,13 @@ int launch_step2(nnj_handle* h, RowSet rs, const int* live_old, const int* ij, c
     else if (has_ctx && np <= 16 && (score_g & 8)) NNJ_SG(1, 1, 16, 12)
     else if (np > 16 && np <= 32 && (score_g & 8)) NNJ_SG(2, 1, 32, 8)
     else if (np > 32 && np <= 48 && (score_g & 8)) NNJ_SG(3, 1, 48, 8)
+    else if (np > 32 && np <= 40 && (score_g & 32)) {
+      // 33..40 pairs: five tiles per two sites through one image buffer in turn (k_inc_score_s5)
+      const size_t lds = (size_t)inc_score_g_lds(3, 1, 48, 8) * sizeof(float);
+      if (int rc = set_lds(h, (k_inc_score_s5<8>), lds)) return rc;
+      hipLaunchKernelGGL((k_inc_score_s5<8>), grid, dim3(512), lds, st, rs, sw, ij, base + w.alpha, mask,
+                         base + w.score_part, n, C, g.cs);
+    }
     else
 #undef NNJ_SG
     if (np <= 16) {

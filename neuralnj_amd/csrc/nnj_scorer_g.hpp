@@ -254,6 +254,351 @@ __global__ __launch_bounds__(64 * NW) void k_inc_score_g(RowSet rs, ScorerW w, c
   }
 }
 
+// ------------------------------------------------------------------ k_inc_score_s5: 33..40 pairs, FIVE tiles per TWO sites
+// k_inc_score_w<3> gives each site three tiles, the third at most half full.  Here a wave owns two consecutive sites A, B
+// and five tiles: A0 A1 (pairs 0..31 of A), S (columns 0..7 = pairs 32..39 of A, columns 8..15 = pairs 32..39 of B),
+// B0 B1.  Two 40-row images at once would take 160 KB for eight waves; instead the images of A and B share ONE 48-row
+// buffer IN TURN: rows 0..31 hold the site being worked on, rows 32..39 the tail of A, rows 40..47 the tail of B (both
+// written with tile S).  Order per site pair: gate phase of A0 A1 S -> chains of A0 A1 and the A half of x_g(S) ->
+// gate phase of B0 B1 (rows 0..31 overwritten) -> the B half of x_g(S), chain of S -> chains of B0 B1.  For site B the
+// k-slots 8..15 of k-step 1 (buffer rows 40..47) carry alpha[32..39]: its alpha fragments of that k-step are read one
+// chunk down and the lanes of slots 0..7 (A's tail) take the zero row.  The tile pairs (A0 A1), (B0 B1) run stage by
+// stage (linear_t16p_multi, see k_inc_score_wi), the image is the transposed-read one of k_inc_score_g.
+// Requires 33 <= n - 1 <= 40.  part[b][sc][pair p].
+template <int N, int KSX, int PLB, int PF>
+__device__ __forceinline__ void xg_from_image_multi(V64 (&xg)[N], unsigned base, const unsigned (&ro)[2],
+                                                    const Frag3 (&bfr)[N][KSX]) {
+  constexpr int NS = 4 * KSX;
+  u32x2 ah[PF][2], am[PF][2];
+  auto issue = [&](auto si) {
+    constexpr int s = decltype(si)::value;
+    if constexpr (s < NS) {
+      constexpr int ks = s / 4, mt = s % 4;
+      const unsigned a0 = base + (ro[0] ^ (32u * mt)), a1 = base + (ro[1] ^ (32u * mt));
+      lds_read_tr16<ks * 4096>(ah[s % PF][0], a0);
+      lds_read_tr16<ks * 4096>(ah[s % PF][1], a1);
+      lds_read_tr16<ks * 4096 + PLB>(am[s % PF][0], a0);
+      lds_read_tr16<ks * 4096 + PLB>(am[s % PF][1], a1);
+    }
+  };
+  static_for<0, PF>([&](auto si) { issue(si); });
+  static_for<0, NS>([&](auto si) {
+    constexpr int s = decltype(si)::value;
+    constexpr int ks = s / 4, mt = s % 4;
+    constexpr int ahead = (s + PF - 1 < NS - 1 ? s + PF - 1 : NS - 1) - s;
+    lds_wait_le_nb<4 * ahead>();
+    Frag3 a;
+    a.h = (u32x4){ah[s % PF][0][0], ah[s % PF][0][1], ah[s % PF][1][0], ah[s % PF][1][1]};
+    a.m = (u32x4){am[s % PF][0][0], am[s % PF][0][1], am[s % PF][1][0], am[s % PF][1][1]};
+    pin_frag(a);
+#ifdef NNJ_MM4
+#pragma unroll
+    for (int u = 0; u < N; ++u) xg[u].t[mt] = mfma16_f16(a.m, bfr[u][ks].m, xg[u].t[mt]);
+#endif
+#pragma unroll
+    for (int u = 0; u < N; ++u) xg[u].t[mt] = mfma16_f16(a.m, bfr[u][ks].h, xg[u].t[mt]);
+#pragma unroll
+    for (int u = 0; u < N; ++u) xg[u].t[mt] = mfma16_f16(a.h, bfr[u][ks].m, xg[u].t[mt]);
+#pragma unroll
+    for (int u = 0; u < N; ++u) xg[u].t[mt] = mfma16_f16(a.h, bfr[u][ks].h, xg[u].t[mt]);
+    issue(std::integral_constant<int, s + PF>{});
+  });
+}
+
+template <int NW, int PF = 2>
+__global__ __launch_bounds__(64 * NW) void k_inc_score_s5(RowSet rs, ScorerW w, const int* __restrict__ ij_prev,
+                                                         const float* __restrict__ alpha,
+                                                         const uint8_t* __restrict__ mask,
+                                                         float* __restrict__ score_part, int n, int C, int cs) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int WPF = 2;
+  constexpr int IR = 48, KSX = 2;
+  constexpr int PLB = IR * 128;                            // bytes of an image plane
+  constexpr int SITEB = 2 * PLB;                           // bytes of a wave's buffer
+  constexpr int IMGF = SITEB / 4;
+  constexpr int SLACK = (32 * KSX - IR) * 32 + 32 + 64;    // as k_inc_score_g: zeroed rows behind the last buffer + the dump line
+  constexpr int APR = 48, APN = APR + 1, APL = APN * 64;   // alpha rows in LDS (+ a zero row at APR)
+  float* Wg_l = smem;
+  float* S0_l = smem + IMG64;
+  float* Wh_l = smem + 2 * IMG64;
+  const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, kq = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  float* imgs = smem + 3 * IMG64;
+  float* cv = imgs + NW * IMGF + SLACK;
+  unsigned short* alds = reinterpret_cast<unsigned short*>(cv + SCORER_CONSTS);
+  const int sc = blockIdx.x, b = blockIdx.y;
+  const int c0 = sc * cs, c1 = min(C, c0 + cs);
+  const int P = n - 1;
+  stage_image_t16(Wg_l, w.imgWg, tid, 64 * NW);
+  stage_image_t16(S0_l, w.imgS0, tid, 64 * NW);
+  stage_image_t16(Wh_l, w.imgWh, tid, 64 * NW);
+  stage_scorer_consts(cv, w, tid);
+  for (int i = tid; i < NW * IMGF + SLACK; i += 64 * NW) imgs[i] = 0.f;      // tail rows no pair writes must be finite
+  {
+    const long apl = (long)gridDim.y * 4096;
+    const unsigned short* ag = reinterpret_cast<const unsigned short*>(alpha) + (size_t)b * 4096;
+    for (int i = tid; i < 2 * APN * 8; i += 64 * NW) {
+      const int pl = i / (APN * 8), rc = i % (APN * 8), r = rc >> 3, ch = rc & 7;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (r < APR) v = *reinterpret_cast<const u32x4*>(ag + pl * apl + r * 64 + 8 * ch);
+      *reinterpret_cast<u32x4*>(alds + pl * APL + r * 64 + 8 * (ch ^ (r & 7))) = v;
+    }
+  }
+  __syncthreads();
+  const size_t bo = (size_t)b * rs.bstride;
+  const int m = min(max(ij_prev[2 * b], 0), n - 1);
+  const float* Sm = rs.S + bo + (size_t)slot_of(rs, b, m) * C * 64;
+  const float* Um = rs.U + bo + (size_t)slot_of(rs, b, m) * C * 64;
+  const unsigned img0 = lds_addr(imgs) + (unsigned)wave * (unsigned)SITEB;
+  char* imw = reinterpret_cast<char*>(imgs) + wave * SITEB;
+  // full tiles t = 0, 1: pair 16 t + l15 (of site A or B); tile S: pair 32 + (l15 & 7) of site l15 >> 3
+  const float* Sr[3];
+  float sgn[3];
+  unsigned wo[3];
+  const int siteS = l15 >> 3, pS = 32 + (l15 & 7);
+  const bool validS = pS < P;
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+    const int p = t < 2 ? 16 * t + l15 : (validS ? pS : 0);
+    const int r = q_to_r(p, m);
+    sgn[t] = r < m ? 1.0f : -1.0f;
+    Sr[t] = rs.S + bo + (size_t)slot_of(rs, b, r) * C * 64;
+    const int R = t < 2 ? p : pS + 8 * siteS;                               // buffer row
+    wo[t] = (unsigned)(R * 128) + 8u * (unsigned)(kq ^ img_bp(R & 15));
+  }
+  const unsigned dump = (unsigned)((NW - wave) * SITEB) + (unsigned)((32 * KSX - IR) * 128 + 128);   // (from imw)
+  const unsigned woS = validS ? wo[2] : dump + 8u * (unsigned)kq;
+  const unsigned wmS = validS ? (unsigned)PLB : 128u;
+  unsigned ro[2];
+#pragma unroll
+  for (int sec = 0; sec < 2; ++sec) {
+    const int row = 8 * kq + 4 * sec + (l15 >> 2);
+    ro[sec] = (unsigned)(row * 128) + 8u * (unsigned)((l15 & 3) ^ img_bp(row & 15));
+  }
+  float score[3] = {0.f, 0.f, 0.f};
+  // gate phase of the two full tiles of site c: x, and rows 0..31 of the buffer
+  auto gate_pair = [&](V64 (&x)[2], int c) {
+    V64 sr[2], sm, um, ur[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) load_v64(sr[t], Sr[t] + (size_t)c * 64, kq);
+    load_v64(sm, Sm + (size_t)c * 64, kq);
+    load_v64(um, Um + (size_t)c * 64, kq);
+    Frag3 sf[2][2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) gate_init16(ur[t], um, cv, sgn[t], kq);
+    linear_t16p_multi<2, WPF>(ur, sf, Wh_l, lane, [&](auto ki) {
+      constexpr int ks = decltype(ki)::value;
+#pragma unroll
+      for (int t = 0; t < 2; ++t) split_8<false>(sf[t][ks], sr[t].t[2 * ks], sr[t].t[2 * ks + 1]);
+    });
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const unsigned o = wo[t] ^ (32u * (2 * ks + u));
+          *reinterpret_cast<u32x2*>(imw + o) = (u32x2){sf[t][ks].h[2 * u], sf[t][ks].h[2 * u + 1]};
+          *reinterpret_cast<u32x2*>(imw + o + PLB) = (u32x2){sf[t][ks].m[2 * u], sf[t][ks].m[2 * u + 1]};
+        }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) gate16(x[t], sr[t], ur[t], sm);
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  // chains of the two full tiles against the buffer as it stands; SHIFT: the site is B (tail rows at 40..47)
+  auto chain_pair = [&](V64 (&x)[2], float mcs, auto shift_c) {
+    constexpr bool SHIFT = decltype(shift_c)::value;
+    V64 xg[2];
+    {
+      Frag3 bfr[2][KSX];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) xg[t].t[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KSX; ++ks) {
+          int ar = 16 * t + l15, ch = 4 * ks + kq;
+          if (SHIFT && ks == 1) { if (kq == 0) ar = APR; else ch -= 1; }
+          const unsigned short* ap_ = alds + ar * 64 + 8 * (ch ^ (ar & 7));
+          bfr[t][ks].h = *reinterpret_cast<const u32x4*>(ap_);
+          bfr[t][ks].m = *reinterpret_cast<const u32x4*>(ap_ + APL);
+        }
+      }
+      xg_from_image_multi<2, KSX, PLB, PF>(xg, img0, ro, bfr);
+    }
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    {
+      V64 g[2];
+      Frag3 bx[2][2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) g[t].t[mt] = *reinterpret_cast<const f32x4*>(cv + 64 + 16 * mt + 4 * kq);
+      linear_t16p_multi<2, WPF>(g, bx, Wg_l, lane, [&](auto ki) {
+        constexpr int ks = decltype(ki)::value;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) split_8<false>(bx[t][ks], xg[t].t[2 * ks], xg[t].t[2 * ks + 1]);
+      });
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float wg = sigmoid_l2(g[t].t[mt][e]);
+            x[t].t[mt][e] += wg * (xg[t].t[mt][e] - x[t].t[mt][e]);
+          }
+    }
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    {
+      V64 s1[2];
+      Frag3 bx[2][2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) s1[t].t[mt] = *reinterpret_cast<const f32x4*>(cv + 128 + 16 * mt + 4 * kq);
+      linear_t16p_multi<2, WPF>(s1, bx, S0_l, lane, [&](auto ki) {
+        constexpr int ks = decltype(ki)::value;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) split_8<false>(bx[t][ks], x[t].t[2 * ks], x[t].t[2 * ks + 1]);
+      });
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        f32x2v s2 = {0.f, 0.f};
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+          const f32x4 w4 = *reinterpret_cast<const f32x4*>(cv + 192 + 16 * mt + 4 * kq);
+          gelu_dot4(s2, s1[t].t[mt], w4);
+        }
+        float s = s2[0] + s2[1];
+        s += __shfl_xor(s, 16);
+        s += __shfl_xor(s, 32);
+        score[t] += (s + w.s2b) * mcs;
+      }
+    }
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  // half of x_g(S): the columns of site `sb` against the buffer as it stands
+  auto xg_half = [&](V64& xg, auto site_c) {
+    constexpr int sb = decltype(site_c)::value;
+    Frag3 bfr[KSX];
+#pragma unroll
+    for (int ks = 0; ks < KSX; ++ks) {
+      int ar = (validS && siteS == sb) ? pS : APR, ch = 4 * ks + kq;
+      if (sb == 1 && ks == 1) { if (kq == 0) ar = APR; else ch -= 1; }
+      const unsigned short* ap_ = alds + ar * 64 + 8 * (ch ^ (ar & 7));
+      bfr[ks].h = *reinterpret_cast<const u32x4*>(ap_);
+      bfr[ks].m = *reinterpret_cast<const u32x4*>(ap_ + APL);
+    }
+    xg_from_image<KSX, PLB, PF>(xg.t, img0, ro, bfr);
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  for (int cg = c0 + 2 * wave; cg < c1; cg += 2 * NW) {
+    asm volatile("" ::: "memory");
+    const int cA = cg, cB = min(cg + 1, c1 - 1);
+    const bool hasB = cg + 1 < c1;
+    const float mcA = mask[(size_t)b * C + cA] ? 0.f : 1.f;                  // seq_mask (model.py:96)
+    const float mcB = (!hasB || mask[(size_t)b * C + cB]) ? 0.f : 1.f;
+    const float mcS = !validS ? 0.f : (siteS == 0 ? mcA : mcB);
+    V64 xgS;
+    const int cS = siteS == 0 ? cA : cB;
+    {
+      V64 x[2];
+      gate_pair(x, cA);
+      {                                                    // the tails of both sites' images (tile S's rows); its gate phase comes later
+        V64 sr;
+        load_v64(sr, Sr[2] + (size_t)cS * 64, kq);
+        Frag3 sf[2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) split_8<false>(sf[ks], sr.t[2 * ks], sr.t[2 * ks + 1]);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            const unsigned o = woS ^ (32u * (2 * ks + u));
+            *reinterpret_cast<u32x2*>(imw + o) = (u32x2){sf[ks].h[2 * u], sf[ks].h[2 * u + 1]};
+            *reinterpret_cast<u32x2*>(imw + o + wmS) = (u32x2){sf[ks].m[2 * u], sf[ks].m[2 * u + 1]};
+          }
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      chain_pair(x, mcA, std::false_type{});
+    }
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) xgS.t[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    xg_half(xgS, std::integral_constant<int, 0>{});
+    {
+      V64 x[2];
+      gate_pair(x, cB);                                    // rows 0..31 now hold site B
+      xg_half(xgS, std::integral_constant<int, 1>{});
+      {                                                    // tile S: gate phase (rows re-read: kept from above they would cost 16 registers
+        V64 xS;                                            // across two gate phases and a chain), then its chain
+        {
+          V64 sr, sm, um, ur;
+          load_v64(sr, Sr[2] + (size_t)cS * 64, kq);
+          load_v64(sm, Sm + (size_t)cS * 64, kq);
+          load_v64(um, Um + (size_t)cS * 64, kq);
+          Frag3 sf[2];
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks) split_8<false>(sf[ks], sr.t[2 * ks], sr.t[2 * ks + 1]);
+          gate_init16(ur, um, cv, sgn[2], kq);
+          linear_t16p_core<4, WPF>(ur.t, sf, Wh_l, lane, [] {});
+          gate16(xS, sr, ur, sm);
+        }
+        V64 gg;
+        linear_t16p<4, false, true, WPF, false>(gg.t, xgS, Wg_l, cv + 64, lane);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float wg = sigmoid_l2(gg.t[mt][e]);
+            xS.t[mt][e] += wg * (xgS.t[mt][e] - xS.t[mt][e]);
+          }
+        V64 s1;
+        linear_t16p<4, false, true, WPF, false>(s1.t, xS, S0_l, cv + 128, lane);
+        f32x2v s2 = {0.f, 0.f};
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+          const f32x4 w4 = *reinterpret_cast<const f32x4*>(cv + 192 + 16 * mt + 4 * kq);
+          gelu_dot4(s2, s1.t[mt], w4);
+        }
+        float s = s2[0] + s2[1];
+        s += __shfl_xor(s, 16);
+        s += __shfl_xor(s, 32);
+        score[2] += (s + w.s2b) * mcS;
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      chain_pair(x, mcB, std::true_type{});
+    }
+  }
+  // one partial set per WORKGROUP: per wave tile S's two columns of a pair are added A then B, then the waves in order
+  __syncthreads();
+  float* red = smem + 3 * IMG64;                           // [NW][64] (the buffers are dead)
+  red[wave * 64 + lane] = 0.f;
+  __syncthreads();
+  if (kq == 0) {
+    red[wave * 64 + l15] = score[0];
+    red[wave * 64 + 16 + l15] = score[1];
+  }
+  for (int gi = 0; gi < 2; ++gi) {
+    if (kq == 0 && validS && siteS == gi) red[wave * 64 + pS] += score[2];
+    asm volatile("" ::: "memory");
+  }
+  __syncthreads();
+  if (tid < 64) {
+    float v = 0.f;
+#pragma unroll
+    for (int s_ = 0; s_ < NW; ++s_) v += red[s_ * 64 + tid];
+    score_part[((size_t)b * gridDim.x + sc) * 64 + tid] = v;
+  }
+}
+
 // floats of dynamic LDS k_inc_score_g<NT, G, IR, NW> needs
 constexpr int inc_score_g_lds(int NT, int G, int IR, int NW) {
   return 3 * IMG64 + NW * G * IR * 64 + ((32 * ((IR + 31) / 32) - IR) * 32 + 32 + 64) + SCORER_CONSTS + 2 * (16 * NT + 1) * 32;
