@@ -1268,3 +1268,40 @@ def test_search_mode_at_config5_200x4096(ctx_cache):
     # Every trajectory that leaves the twin's is certified at its first divergent step; over 199 sampled steps per
     # trajectory a CDF-boundary case somewhere is the rule, so no share of fully identical trajectories is asked for.
     _certify_sampled(ref, got["merges"].cpu().numpy(), got["logits"].cpu().numpy(), uw, 1.0, T, rtol=2 * RTOL)
+
+
+def test_switchable_kernels_agree(tmp_path):
+    """Every kernel family that is kept behind an NNJ_* switch (the A/B arms of DESIGN.md sections 5g and 9) computes the
+    SAME rollout as the default dispatch: one child process per setting (the library reads its switches once), a traced
+    Argmax rollout of three seeded 50 x 72 alignments (one padded), tables within 2e-5 of the default's scale and equal
+    merge lists.  Guards the arms that no other test reaches against bit rot."""
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    variants = {
+        "default": {},
+        "round3_kernels": {"NNJ_SCORE_G": "0", "NNJ_ALPHA_G": "0", "NNJ_SCORE_IL": "0", "NNJ_ALPHA_IL": "0"},
+        "shared_tiles_everywhere": {"NNJ_SCORE_G": "15", "NNJ_ALPHA_G": "15"},
+        "stage_by_stage_three_tiles": {"NNJ_SCORE_G": "22", "NNJ_SCORE_IL": "3"},
+        "site_sharing_step": {"NNJ_STEP_W": "0"},
+        "row_attention_arms": {"NNJ_ROW_FUSED": "1", "NNJ_TOK_SK": "0"},
+        "register_staging": {"NNJ_ROWS_RS": "1", "NNJ_PV_RS": "1"},
+    }
+    res = {}
+    for name, env in variants.items():
+        out = tmp_path / (name + ".npz")
+        e = dict(os.environ)
+        for k in ("NNJ_SCORE_G", "NNJ_ALPHA_G", "NNJ_SCORE_IL", "NNJ_ALPHA_IL", "NNJ_STEP_W", "NNJ_ROW_FUSED", "NNJ_TOK_SK",
+                  "NNJ_ROWS_RS", "NNJ_PV_RS"):
+            e.pop(k, None)
+        e.update(env)
+        p = subprocess.run([sys.executable, os.path.join(here, "variant_run.py"), str(out)], env=e, capture_output=True,
+                           text=True, timeout=300)
+        assert p.returncode == 0, (name, p.stderr[-2000:])
+        res[name] = np.load(out)
+    ref = res["default"]
+    scale = max(float(np.abs(ref["logits"]).max()), 1.0)
+    for name, z in res.items():
+        assert np.array_equal(z["merges"], ref["merges"]), name
+        err = float(np.abs(z["logits"] - ref["logits"]).max()) / scale
+        assert err <= 2e-5, (name, err)
