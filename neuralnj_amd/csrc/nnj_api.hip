@@ -228,7 +228,10 @@ PairGeom pair_geom(int mode, int n, int B, int C) {
     g.npairs = n; g.tpw = 1; g.pg = 1; g.ppad = 64;
     static const int wgs = getenv("NNJ_INCR_WGS") ? atoi(getenv("NNJ_INCR_WGS")) : 1024;
     int blocks = (wgs + B - 1) / B;            // (measured flat from 512 to 3072 workgroups per launch)
-    const int max_blocks = (C + 7) / 8;       // small batches: down to 8 sites per workgroup (1-2 per wave)
+    // small batches: down to 4 sites per workgroup -- one alignment of 1024 sites then runs 256 workgroups with four busy
+    // waves each, one per SIMD of every CU, instead of 128 with eight (B = 1: 3.53 -> 3.48 ms per tree; 2 sites: 4.6)
+    static const int mincs = getenv("NNJ_INCR_MINCS") ? std::max(1, atoi(getenv("NNJ_INCR_MINCS"))) : 4;
+    const int max_blocks = (C + mincs - 1) / mincs;
     if (blocks > max_blocks) blocks = max_blocks;
     if (blocks < 1) blocks = 1;
     g.cs = (C + blocks - 1) / blocks;
@@ -353,7 +356,7 @@ int scorer_mask(nnj_handle* h, const uint8_t* mask, float* base, const LoopWs& w
 struct EncWs { size_t ctx, q6, k6, v6, s, m, cls, end; };
 EncWs enc_ws(int B, int T, int C) {
   const EncDims d = enc_dims(B, T, C);
-  const Ra6 g = ra6_geom(T, C, d.Epad);
+  const Ra6 g = ra6_geom(T, C, d.Epad, B);
   const size_t nbh = (size_t)B * NNJ_NHEAD;
   EncWs w;
   size_t o = 0;
@@ -393,7 +396,7 @@ int launch_encoder(nnj_handle* h, const uint8_t* codes, const float* onehot, con
                    float* scratch, int B, int T, int C, hipStream_t st) {
   const EncDims d = enc_dims(B, T, C);
   const EncWs ew_ = enc_ws(B, T, C);
-  const Ra6 g6 = ra6_geom(T, C, d.Epad);
+  const Ra6 g6 = ra6_geom(T, C, d.Epad, B);
   float* ctx = scratch + ew_.ctx;
   uint8_t* Q6 = reinterpret_cast<uint8_t*>(scratch + ew_.q6);
   uint8_t* K6 = reinterpret_cast<uint8_t*>(scratch + ew_.k6);

@@ -45,7 +45,11 @@ struct Ra6 {
   size_t s_bh;     // floats of S per (b, h)
   size_t m_bh;     // floats of M per (b, h)
 };
-inline Ra6 ra6_geom(int T, int C, int Epad) {
+// B: the batch the geometry is for.  A small batch leaves k_row_pv's grid (B x 8 heads x C / 128 query blocks) far below the
+// chip's 256 CUs -- one alignment of 1024 columns: 64 workgroups walking all keys with 13 accumulator tiles each -- so its
+// head dimension is cut into more e-chunks than the registers ask for (every chunk recomputes the probabilities and owns
+// its slice of the context rows: results are bit-identical for every cut).
+inline Ra6 ra6_geom(int T, int C, int Epad, int B) {
   Ra6 g;
   g.C = C; g.T = T; g.Epad = Epad;
   g.KS = (8 * T + 15) / 16;
@@ -53,6 +57,11 @@ inline Ra6 ra6_geom(int T, int C, int Epad) {
   static const int buckets[] = {1, 2, 4, 6, 8, 10, 13, 16};
   const int need = (16 * g.KS + 31) / 32;
   g.nech = (need + 15) / 16;
+  static const bool small_cut = !(getenv("NNJ_PV_CUT") && atoi(getenv("NNJ_PV_CUT")) == 0);
+  if (small_cut) {
+    const long wgs = (long)B * 8 * (g.Cp / 128);
+    while (g.nech < 4 && wgs * g.nech < 256 && need >= 4 * g.nech) g.nech *= 2;
+  }
   const int per = (need + g.nech - 1) / g.nech;
   g.ETc = 16;
   for (int k : buckets) if (per <= k) { g.ETc = k; break; }
