@@ -816,9 +816,10 @@ int launch_step2(nnj_handle* h, RowSet rs, const int* live_old, const int* ij, c
     if (int rc = set_lds(h, (k_step_alpha_g<NT, G, IR, NW>), lds)) return rc;                                  \
     hipLaunchKernelGGL((k_step_alpha_g<NT, G, IR, NW>), grid, dim3(64 * NW), lds, st, rs, sw, io, n, C, g.cs); \
   }
-    if (n > 2 && np <= 4 && (alpha_g & 1)) NNJ_AG(1, 4, 8, 8)
-    else if (n > 2 && np > 4 && np <= 8 && (alpha_g & 2)) NNJ_AG(1, 2, 8, 8)
-    else if (np > 16 && np <= 24 && (alpha_g & 4)) NNJ_AG(3, 2, 24, 8)
+    const bool grp2 = g.cs >= 16, grp4 = g.cs >= 32;      // (see the score kernels below)
+    if (n > 2 && np <= 4 && (alpha_g & 1) && grp4) NNJ_AG(1, 4, 8, 8)
+    else if (n > 2 && np > 4 && np <= 8 && (alpha_g & 2) && grp2) NNJ_AG(1, 2, 8, 8)
+    else if (np > 16 && np <= 24 && (alpha_g & 4) && grp2) NNJ_AG(3, 2, 24, 8)
     else if (n > 2 && np <= 16 && (alpha_g & 8)) NNJ_AG(1, 1, 16, 8)
     else if (np > 16 && np <= 32 && (alpha_g & 8)) NNJ_AG(2, 1, 32, 8)
     else if (np > 32 && np <= 48 && (alpha_g & 8)) NNJ_AG(3, 1, 48, 8)
@@ -861,14 +862,18 @@ int launch_step2(nnj_handle* h, RowSet rs, const int* live_old, const int* ij, c
     hipLaunchKernelGGL((k_inc_score_g<NT, G, IR, NW, ##__VA_ARGS__>), grid, dim3(64 * NW), lds, st, rs, sw, ij, \
                        base + w.alpha, mask, base + w.score_part, n, C, g.cs);                                 \
   }
-    if (has_ctx && np <= 4 && (score_g & 16)) NNJ_SG(1, 4, 8, 8)
-    else if (has_ctx && np <= 4 && (score_g & 1)) NNJ_SG(1, 4, 8, 12, 1)
-    else if (has_ctx && np <= 8 && np > 4 && (score_g & 2)) NNJ_SG(1, 2, 8, 12)
-    else if (np > 16 && np <= 24 && (score_g & 4)) NNJ_SG(3, 2, 24, 8)
+    // (a wave of these kernels walks the G sites of a group one after the other: where a workgroup has fewer than G sites
+    // per wave -- one alignment per rollout: 4 sites per workgroup -- the one-site-per-wave kernels are the shorter path:
+    // B = 1 3.40 -> 3.34 ms per tree)
+    const bool grp2 = g.cs >= 16, grp4 = g.cs >= 32;
+    if (has_ctx && np <= 4 && (score_g & 16) && grp4) NNJ_SG(1, 4, 8, 8)
+    else if (has_ctx && np <= 4 && (score_g & 1) && grp4) NNJ_SG(1, 4, 8, 12, 1)
+    else if (has_ctx && np <= 8 && np > 4 && (score_g & 2) && grp2) NNJ_SG(1, 2, 8, 12)
+    else if (np > 16 && np <= 24 && (score_g & 4) && grp2) NNJ_SG(3, 2, 24, 8)
     else if (has_ctx && np <= 16 && (score_g & 8)) NNJ_SG(1, 1, 16, 12)
     else if (np > 16 && np <= 32 && (score_g & 8)) NNJ_SG(2, 1, 32, 8)
     else if (np > 32 && np <= 48 && (score_g & 8)) NNJ_SG(3, 1, 48, 8)
-    else if (np > 32 && np <= 40 && (score_g & 32)) {
+    else if (np > 32 && np <= 40 && (score_g & 32) && g.cs >= 16) {   // (a wave with fewer than two sites: one site per wave is the shorter path)
       // 33..40 pairs: five tiles per two sites through one image buffer in turn (k_inc_score_s5)
       const size_t lds = (size_t)inc_score_g_lds(3, 1, 48, 8) * sizeof(float);
       if (int rc = set_lds(h, (k_inc_score_s5<8>), lds)) return rc;

@@ -986,29 +986,55 @@ __global__ __launch_bounds__(256) void k_assemble_argmax(const float* __restrict
   // everything the two-pass tail needs that does NOT depend on the pick is fetched here, behind the table pass -- the
   // carried candidate's pair, its logits' partial sums (used only if the pick turns out to be that pair: same sums, same
   // order), the per-row bias of every position.
+  // Sums of MANY partial sets (one alignment per rollout: 256 workgroups of the step kernels, 64 values each): thread
+  // (phase tid >> 4, column group tid & 15) adds every 16th set, four columns at a time -- 16 independent 16-byte loads in
+  // flight per thread and sum, ONE round trip where four threads per column took two to four -- and the 16 phase sums of a
+  // column are added in phase order (fixed order: reproducible).  psum[which][phase][column].
+  __shared__ float psum[2][16][64];
+  auto phase_sums = [&](const float* part, int nset, int which) {
+    const int cg = tid & 15, ph = tid >> 4;
+    f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 16
+    for (int k = ph; k < nset; k += 16) a += *reinterpret_cast<const f32x4*>(part + (size_t)k * 64 + 4 * cg);
+    *reinterpret_cast<f32x4*>(&psum[which][ph][4 * cg]) = a;
+  };
+  auto phase_total = [&](int which, int col) {
+    float v = psum[which][0][col];
+#pragma unroll
+    for (int ph = 1; ph < 16; ++ph) v += psum[which][ph][col];
+    return v;
+  };
   int cc0 = -2, cc1 = -2;
   float a_cand = 0.f, beta_r = 0.f;
+  const bool cand_phases = so.am && so.acand_part && so.cand_cur && so.nblk >= 32;
   if (so.am) {
     if (so.acand_part && so.cand_cur) {
       cc0 = so.cand_cur[2 * b]; cc1 = so.cand_cur[2 * b + 1];
-      const int r = tid & 63, part = tid >> 6;
-      if (r < n) {
-        const int col = (mode == PAIRS_INCR && r == ip) ? 63 : r - ((mode == PAIRS_INCR && r > ip) ? 1 : 0);
+      if (cand_phases) phase_sums(so.acand_part + (size_t)b * so.nblk * 64, so.nblk, 1);
+      else {
+        const int r = tid & 63, part = tid >> 6;
+        if (r < n) {
+          const int col = (mode == PAIRS_INCR && r == ip) ? 63 : r - ((mode == PAIRS_INCR && r > ip) ? 1 : 0);
 #pragma unroll 16
-        for (int k = part; k < so.nblk; k += 4) a_cand += so.acand_part[((size_t)b * so.nblk + k) * 64 + col];
+          for (int k = part; k < so.nblk; k += 4) a_cand += so.acand_part[((size_t)b * so.nblk + k) * 64 + col];
+        }
       }
     }
     if (tid < 64 && tid < n) beta_r = so.beta_slot[(size_t)b * so.nslot + live_cur[(size_t)b * live_stride + tid]];
   }
   if (mode == PAIRS_INCR) {
-    if (qn && nsc > 8) {
-      // many partials (small batch: many workgroups per alignment) and at most 64 new scores: four threads per score,
-      // every 4th partial each, the four sums added in order
+    if (qn && nsc >= 32 && ppad == 64) {
+      phase_sums(score_part + (size_t)b * nsc * 64, nsc, 0);
+      __syncthreads();
+      if (tid < n) newsc[tid] = phase_total(0, tid - (tid > ip ? 1 : 0));
+    } else if (qn && nsc > 8) {
+      // several partials and at most 64 new scores: four threads per score, every 4th partial each, the four sums added
+      // in order
       const int r = tid & 63, part = tid >> 6;
       float s = 0.f;
       if (r < n) {
         const int src = r - (r > ip ? 1 : 0);
-#pragma unroll 32        // every partial of the thread in flight at once (B = 1: 128 partials, 32 per thread), added in order
+#pragma unroll 32
         for (int sc = part; sc < nsc; sc += 4) s += score_part[((size_t)b * nsc + sc) * ppad + src];
       }
       pval[PCACHE - 256 + tid] = s;
@@ -1164,7 +1190,7 @@ __global__ __launch_bounds__(256) void k_assemble_argmax(const float* __restrict
     pval[PCACHE - 256 + tid] = a;
     __syncthreads();
   }
-  if (src == 2) {
+  if (src == 2 && !cand_phases) {
     // the candidate's logits: the partials of the k_step_alpha workgroups, four threads per row (every 4th block
     // each; summed at the top of the kernel), the four sums added in order by wave 0 below
     pval[PCACHE - 256 + tid] = a_cand;                      // (entries the table never reaches: np <= 2080 when src == 2)
@@ -1177,6 +1203,8 @@ __global__ __launch_bounds__(256) void k_assemble_argmax(const float* __restrict
     if (in) {
       float a;
       if (src == 1) a = so.lam[((size_t)b * 64 + qs) * 64 + (r - (r > ip ? 1 : 0))];
+      else if (src == 2 && cand_phases)                      // (psum[1] is complete: several workgroup barriers since)
+        a = phase_total(1, (mode == PAIRS_INCR && r == ip) ? 63 : r - ((mode == PAIRS_INCR && r > ip) ? 1 : 0));
       else a = ((pval[PCACHE - 256 + r] + pval[PCACHE - 192 + r]) + pval[PCACHE - 128 + r]) + pval[PCACHE - 64 + r];   // src 2, 3
       v = (a + beta_r) * so.inv_scale;
     }
