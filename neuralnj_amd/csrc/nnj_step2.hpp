@@ -748,7 +748,6 @@ __global__ __launch_bounds__(256) void k_step_softmax(RowSet rs, ScorerW w, cons
                                                       int n, int C) {
   // SPLIT (small batches: k_step_alpha ran many workgroups per alignment, i.e. many partials): one pair per
   // workgroup, its four waves sum every 4th partial each and the four sums are added in wave order; grid (64, B)
-  __shared__ float part4[4][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int q = SPLIT ? blockIdx.x : blockIdx.x * 4 + wave, b = blockIdx.y;
   const int m = min(max(ij_prev[2 * b], 0), n - 1);
@@ -763,12 +762,22 @@ __global__ __launch_bounds__(256) void k_step_softmax(RowSet rs, ScorerW w, cons
   }
   float a = 0.f;
   if (SPLIT) {
-#pragma unroll 32        // (B = 1: 128 partials, 32 per wave: all in flight, added in order)
-    for (int sc = wave; sc < nblk; sc += 4) a += alpha_part[(((size_t)b * nblk + sc) * 64 + q) * 64 + lane];
-    part4[wave][lane] = a;
+    // thread (phase tid >> 4, column group tid & 15) adds every 16th partial set, four columns at a time: 16 independent
+    // 16-byte loads in flight (one round trip for 256 sets), the 16 phase sums of a column added in phase order
+    __shared__ float psum[16][64];
+    {
+      const int cg = threadIdx.x & 15, ph = threadIdx.x >> 4;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 16
+      for (int sc = ph; sc < nblk; sc += 16)
+        v += *reinterpret_cast<const f32x4*>(alpha_part + (((size_t)b * nblk + sc) * 64 + q) * 64 + 4 * cg);
+      *reinterpret_cast<f32x4*>(&psum[ph][4 * cg]) = v;
+    }
     __syncthreads();
     if (wave != 0) return;
-    a = ((part4[0][lane] + part4[1][lane]) + part4[2][lane]) + part4[3][lane];
+    a = psum[0][lane];
+#pragma unroll
+    for (int ph = 1; ph < 16; ++ph) a += psum[ph][lane];
   } else {
 #pragma unroll 8          // independent loads in flight; the additions stay in order
     for (int sc = 0; sc < nblk; ++sc) a += alpha_part[(((size_t)b * nblk + sc) * 64 + q) * 64 + lane];
