@@ -510,11 +510,25 @@ int launch_encoder(nnj_handle* h, const uint8_t* codes, const float* onehot, con
                          (const float*)Mbuf, ctx, g6, nbh);                                              \
     }                                                                                                    \
   } break;
+#define NNJ_PV2_CASE(N)                                                                                  \
+  case N: {                                                                                              \
+    const size_t lds = 4 * ((2 * N * NPL * 1024 + 8191) / 8192 * 8192);                                   \
+    if (int rc = set_lds(h, k_row_pv2<N>, lds)) return rc;                                               \
+    hipLaunchKernelGGL(k_row_pv2<N>, dim3(grid), dim3(512), lds, st, (const uint8_t*)V6, (const float*)Sbuf, \
+                       (const float*)Mbuf, ctx, g6, nbh);                                                \
+  } break;
+      if (g6.halves) {
+        switch (g6.ETc / 2) {
+          NNJ_PV2_CASE(5) NNJ_PV2_CASE(6) NNJ_PV2_CASE(7) NNJ_PV2_CASE(8)
+          default: return fail(h, NNJ_ERR_UNSUPPORTED, "row attention: no two-half instantiation for %d head tiles", g6.ETc);
+        }
+      } else
       switch (g6.ETc) {
-        NNJ_PV_CASE(1) NNJ_PV_CASE(2) NNJ_PV_CASE(4) NNJ_PV_CASE(6) NNJ_PV_CASE(8) NNJ_PV_CASE(10) NNJ_PV_CASE(13)
+        NNJ_PV_CASE(1) NNJ_PV_CASE(2) NNJ_PV_CASE(4) NNJ_PV_CASE(6) NNJ_PV_CASE(7) NNJ_PV_CASE(8) NNJ_PV_CASE(10) NNJ_PV_CASE(13)
         NNJ_PV_CASE(16)
         default: return fail(h, NNJ_ERR_UNSUPPORTED, "row attention: no instantiation for %d head tiles", g6.ETc);
       }
+#undef NNJ_PV2_CASE
 #undef NNJ_PV_CASE
     }
     }

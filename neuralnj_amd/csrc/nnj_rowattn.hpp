@@ -36,6 +36,7 @@ struct Ra6 {
   int ET;          // 32-row tiles of the head dimension in V6 (= nech * ETc)
   int ETc;         // ... per e-chunk of k_row_pv (bucketed, <= 16: its context accumulators)
   int nech;        // e-chunks: k_row_pv workgroups per query block (1 up to 64 rows; 100 rows: 2 x 13 tiles; 200: 4 x 13)
+  int halves;      // 1 = k_row_pv2: eight waves per workgroup, two halves of ETc / 2 tiles
   int nrb;         // Cp / 256
   int nt32;        // Cp / 32
   int nk16;        // Cp / 16
@@ -54,7 +55,7 @@ inline Ra6 ra6_geom(int T, int C, int Epad, int B) {
   g.C = C; g.T = T; g.Epad = Epad;
   g.KS = (8 * T + 15) / 16;
   g.Cp = (C + 255) / 256 * 256;
-  static const int buckets[] = {1, 2, 4, 6, 8, 10, 13, 16};
+  static const int buckets[] = {1, 2, 4, 6, 7, 8, 10, 13, 16};
   const int need = (16 * g.KS + 31) / 32;
   g.nech = (need + 15) / 16;
   static const bool small_cut = !(getenv("NNJ_PV_CUT") && atoi(getenv("NNJ_PV_CUT")) == 0);
@@ -62,9 +63,20 @@ inline Ra6 ra6_geom(int T, int C, int Epad, int B) {
     const long wgs = (long)B * 8 * (g.Cp / 128);
     while (g.nech < 4 && wgs * g.nech < 256 && need >= 4 * g.nech) g.nech *= 2;
   }
+  // 33..64 rows (9..16 head tiles): TWO e-chunks at every batch -- two workgroups of <= 8 accumulator tiles per CU, i.e. two
+  // waves per SIMD, instead of one of 13 (50 rows: 7 + 7 tiles; twice the V6 DMA and the exponentials, 8 % padding, and
+  // still 35.5 -> 34.1 ms per rollout: one wave's DMA issue and barrier waits sit under the other workgroup's MFMAs).
+  // NNJ_PV_NECH=1: one chunk as before.
+  static const int min_nech = getenv("NNJ_PV_NECH") ? atoi(getenv("NNJ_PV_NECH")) : 2;
+  if (g.nech < min_nech && need >= 9 && need <= 16) g.nech = min_nech;
   const int per = (need + g.nech - 1) / g.nech;
   g.ETc = 16;
   for (int k : buckets) if (per <= k) { g.ETc = k; break; }
+  // NNJ_PV_HALVES=1 (with NNJ_PV_NECH=1): the two halves inside ONE workgroup of eight waves (k_row_pv2; one V6 DMA for
+  // both) -- measured SLOWER than one chunk (38.5 vs 35.8 ms per rollout: the eight-wave barrier couples the halves)
+  static const bool pv_halves = getenv("NNJ_PV_HALVES") && atoi(getenv("NNJ_PV_HALVES")) != 0;
+  g.halves = 0;
+  if (pv_halves && g.nech == 1 && need >= 9 && need <= 16) { g.halves = 1; g.ETc = 2 * ((need + 1) / 2); }
   g.ET = g.nech * g.ETc;
   g.nrb = g.Cp / 256; g.nt32 = g.Cp / 32; g.nk16 = g.Cp / 16;
   g.qk_bh = (size_t)g.KS * g.nrb * NPL * 8192;
@@ -643,6 +655,132 @@ __global__ __launch_bounds__(256) void k_row_pv(const uint8_t* __restrict__ V6, 
 #pragma unroll
       for (int gq = 0; gq < 4; ++gq) {
         const int e = 32 * (ech * ET + t) + 8 * gq + 4 * HH;
+        if (e < E)
+          *reinterpret_cast<f32x4*>(dst + e) = (f32x4){acc[t][4 * gq] * inv, acc[t][4 * gq + 1] * inv,
+                                                       acc[t][4 * gq + 2] * inv, acc[t][4 * gq + 3] * inv};
+      }
+  }
+}
+
+// ------------------------------------------------------------------ k_row_pv2 (round 4, late)
+// k_row_pv with EIGHT waves per workgroup: waves w and w + 4 share the 32 queries of query tile w and own one HALF of the
+// head dimension each (ET accumulator tiles: 7 + 7 for the 13 tiles of 50 rows) -- 112 accumulators per wave instead of
+// 208, two waves per SIMD, so one wave's LDS-DMA issue and barrier waits sit under the other's MFMAs.  The V6 tile of a
+// k-step (2 ET tiles, both planes) is fetched ONCE per workgroup as before; both waves of a query tile compute its
+// probabilities (the exponentials are cheap next to ET x 3 MFMAs per 16 keys).  Same products in the same order per
+// output element: bit-identical to k_row_pv.  (Two e-chunk WORKGROUPS per query block, NNJ_PV_NECH=2, measured 35.5 ->
+// 34.1 ms per rollout with twice the DMA traffic.)
+template <int ET>
+__global__ __launch_bounds__(512) void k_row_pv2(const uint8_t* __restrict__ V6, const float* __restrict__ S,
+                                                 const float* __restrict__ M, float* __restrict__ ctx, Ra6 g,
+                                                 int nbh) {
+  constexpr int ETL = 2 * ET;                                         // tiles of the V6 tile in LDS
+  constexpr unsigned TILE = ETL * NPL * 1024u;
+  constexpr unsigned STG = (TILE + 8191u) / 8192u * 8192u;            // stage size: whole KiB per wave (8 waves)
+  constexpr int NIW = STG / 8192;                                     // DMA instructions per wave and tile
+  constexpr int NST = 4;
+  static_assert(4 * STG <= 163840, "four-stage ring");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, HH = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wq = wave & 3, eh = wave >> 2;
+  const int nqb = g.Cp / 128;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int bh = (slot / nqb) * 8 + xcd;
+  if (bh >= nbh) return;
+  const int qb = slot % nqb, qt = qb * 4 + wq;
+  const int nk16 = g.nk16;
+  const size_t tile_g = (size_t)g.ET * NPL * 1024u;
+  const size_t plane_g = (size_t)g.ET * 1024u;
+  const uint8_t* Vt = V6 + (size_t)bh * g.v_bh;
+  auto issue_piece = [&](auto pi, int k, int stage) {
+    constexpr int i = decltype(pi)::value;
+    const int kk = k < nk16 ? k : nk16 - 1;
+    const unsigned I = (unsigned)(wave * NIW + i);
+    const size_t so = I * 1024u < TILE ? (size_t)(I / ETL) * plane_g + (size_t)(I % ETL) * 1024u : 0u;
+    lds_dma16(reinterpret_cast<const float*>(Vt + (size_t)kk * tile_g + so + lane * 16),
+              reinterpret_cast<float*>(reinterpret_cast<uint8_t*>(smem) + stage * STG + I * 1024u));
+  };
+  auto issue = [&](int k, int stage) {
+    static_for<0, NIW>([&](auto pi) { issue_piece(pi, k, stage); });
+  };
+  const float* Sq = S + (size_t)bh * g.s_bh + (size_t)qt * g.nt32 * 1024 + lane * 4;
+  const float* Mq = M + (size_t)bh * g.m_bh + (size_t)qt * g.nt32 * 32 + l31;
+  float m = -INFINITY;
+  for (int kt = 0; kt < g.nt32; ++kt) m = fmaxf(m, Mq[(size_t)kt * 32]);
+  auto loadS = [&](f32x16& s, int kt) {
+    const float* p = Sq + (size_t)kt * 1024;
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(p + 256 * gq);
+      s[4 * gq] = v[0]; s[4 * gq + 1] = v[1]; s[4 * gq + 2] = v[2]; s[4 * gq + 3] = v[3];
+    }
+  };
+  f32x16 acc[ET];
+#pragma unroll
+  for (int t = 0; t < ET; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  float lsum = 0.f;
+  f32x16 s_cur, s_nxt;
+  issue(0, 0);
+  loadS(s_cur, 0);
+  issue(1, 1);
+  s_nxt = s_cur;
+  const unsigned aA = lds_addr(smem) + (unsigned)l31 * 32u + 16u * (unsigned)(HH ^ ((l31 >> 3) & 1)) + (unsigned)(eh * ET) * 1024u;
+  Frag3 bfr[2];
+  auto kstep = [&](int k, auto par) {
+    constexpr int P = decltype(par)::value;    // k & 1
+    // four-stage ring, one barrier per two k-steps (see k_row_pv)
+    if constexpr (P == 0) {
+      wait_vmem_le<0>();
+      barrier_nofence();
+      if ((k >> 1) + 1 < g.nt32) loadS(s_nxt, (k >> 1) + 1);
+    }
+    const int st2 = (k + 2) % NST;
+    if constexpr (P == 0) {
+      f32x16 p;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { p[r] = __builtin_amdgcn_exp2f(s_cur[r] - m); lsum += p[r]; }
+      split8<0>(bfr[0], p);
+      split8<8>(bfr[1], p);
+    }
+    const Frag3& bf = bfr[P];
+    const unsigned so = aA + (unsigned)(k % NST) * STG;
+    Frag3 a[3];
+    auto rd = [&](auto ti) {
+      constexpr int t = decltype(ti)::value;
+      lds_read_frag<t * 1024>(a[t % 3].h, so);
+      lds_read_frag<t * 1024 + ETL * 1024>(a[t % 3].m, so);
+    };
+    rd(std::integral_constant<int, 0>{});
+    if constexpr (ET > 1) rd(std::integral_constant<int, 1>{});
+    static_for<0, ET>([&](auto ti) {
+      constexpr int t = decltype(ti)::value;
+      if constexpr (t + 1 < ET) lds_wait_le<NPL>(); else lds_wait_all();
+      pin_frag(a[t % 3]);
+      if constexpr (t + 2 < ET) rd(std::integral_constant<int, t + 2>{});
+      acc[t] = mfma_b6(a[t % 3], bf, acc[t]);
+      if constexpr (t < NIW) issue_piece(std::integral_constant<int, t>{}, k + 2, st2);
+    });
+    if constexpr (P == 1) s_cur = s_nxt;
+  };
+  for (int k = 0; k < nk16; k += 2) {          // nk16 is even (Cp is a multiple of 256)
+    kstep(k, std::integral_constant<int, 0>{});
+    kstep(k + 1, std::integral_constant<int, 1>{});
+  }
+  wait_vmem_le<0>();
+  lsum += __shfl_xor(lsum, 32);
+  const float inv = nnj_rcp(lsum);
+  const int q = qt * 32 + l31;
+  if (q < g.C) {
+    float* dst = ctx + ((size_t)bh * g.C + q) * g.Epad;
+    const int E = 8 * g.T;
+#pragma unroll
+    for (int t = 0; t < ET; ++t)
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        const int e = 32 * (eh * ET + t) + 8 * gq + 4 * HH;
         if (e < E)
           *reinterpret_cast<f32x4*>(dst + e) = (f32x4){acc[t][4 * gq] * inv, acc[t][4 * gq + 1] * inv,
                                                        acc[t][4 * gq + 2] * inv, acc[t][4 * gq + 3] * inv};

@@ -1284,15 +1284,17 @@ def test_switchable_kernels_agree(tmp_path):
         "shared_tiles_everywhere": {"NNJ_SCORE_G": "15", "NNJ_ALPHA_G": "15"},
         "stage_by_stage_three_tiles": {"NNJ_SCORE_G": "22", "NNJ_SCORE_IL": "3"},
         "site_sharing_step": {"NNJ_STEP_W": "0"},
-        "row_attention_arms": {"NNJ_ROW_FUSED": "1", "NNJ_TOK_SK": "0"},
+        "row_attention_arms": {"NNJ_ROW_FUSED": "1", "NNJ_PV_NECH": "1", "NNJ_PV_CUT": "0", "NNJ_TOK_SK": "0"},
         "register_staging": {"NNJ_ROWS_RS": "1", "NNJ_PV_RS": "1"},
+        "row_pv_one_chunk": {"NNJ_PV_NECH": "1", "NNJ_PV_CUT": "0"},
+        "row_pv_two_halves_in_a_workgroup": {"NNJ_PV_NECH": "1", "NNJ_PV_CUT": "0", "NNJ_PV_HALVES": "1"},
     }
     res = {}
     for name, env in variants.items():
         out = tmp_path / (name + ".npz")
         e = dict(os.environ)
         for k in ("NNJ_SCORE_G", "NNJ_ALPHA_G", "NNJ_SCORE_IL", "NNJ_ALPHA_IL", "NNJ_STEP_W", "NNJ_ROW_FUSED", "NNJ_TOK_SK",
-                  "NNJ_ROWS_RS", "NNJ_PV_RS"):
+                  "NNJ_ROWS_RS", "NNJ_PV_RS", "NNJ_PV_NECH", "NNJ_PV_HALVES", "NNJ_PV_CUT"):
             e.pop(k, None)
         e.update(env)
         p = subprocess.run([sys.executable, os.path.join(here, "variant_run.py"), str(out)], env=e, capture_output=True,
