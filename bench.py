@@ -1,8 +1,11 @@
 #!/usr/bin/env python3
 """Throughput benchmark of the Argmax hot path (encoder + neural NJ loop) on MI355X.
 
-  python bench.py --gpus N --steps K --warmup W        (N=1)
-  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+  python bench.py --gpus N --steps K --warmup W
+      N = 1: runs here.  N > 1 from a bare shell (WORLD_SIZE unset): starts the N ranks itself -- a CHILD
+      `python -m torch.distributed.run --nproc-per-node N bench.py ...`, launched before this process touches the GPU --
+      and relays rank 0's line and the exit code; more ranks than GPUs, or a line whose n_gpus is not N, is an error.
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   (the driver's form)
 
 A step = one device-resident Argmax rollout (nnj_rollout_argmax) of one batch of
 synthetic 50-taxa x 1024-site MSAs per GPU, site codes already in HBM, merge lists
@@ -20,11 +23,73 @@ import os
 import sys
 import time
 
-import numpy as np
-import torch
-
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
+
+
+def _visible_gpus():
+    """Device count, asked in a CHILD process so that this one never initialises the GPU."""
+    import subprocess
+    r = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"],
+                       capture_output=True, text=True, timeout=600)
+    try:
+        return int(r.stdout.strip().splitlines()[-1])
+    except (ValueError, IndexError):
+        raise SystemExit(f"bench.py: could not count the GPUs of this node: {r.stderr[-500:]}")
+
+
+def _self_launch():
+    """`python bench.py --gpus N` from a bare shell (no launcher, WORLD_SIZE unset), N > 1: this process -- which has
+    made NO GPU call and imported nothing that makes one -- starts `python -m torch.distributed.run --nproc-per-node N
+    bench.py ...` as a CHILD (subprocess, never exec), relays rank 0's JSON line and the exit code.  Asking for more
+    ranks than the node has GPUs is an error, never a silent one-GPU run (NNJ_BENCH_SHARE_GPU=1, the one-GPU
+    rehearsal, puts every rank on cuda:0 and is exempt)."""
+    n, argv = 1, sys.argv[1:]
+    for i, a in enumerate(argv):
+        if a == "--gpus" and i + 1 < len(argv):
+            n = int(argv[i + 1])
+        elif a.startswith("--gpus="):
+            n = int(a.split("=", 1)[1])
+    if n < 1:
+        raise SystemExit(f"bench.py: --gpus {n}")
+    if "WORLD_SIZE" in os.environ or n == 1:
+        return
+    import socket
+    import subprocess
+    if os.environ.get("NNJ_BENCH_SHARE_GPU") != "1":
+        have = _visible_gpus()
+        if n > have:
+            raise SystemExit(f"bench.py: --gpus {n} but this node shows {have} GPU(s): refusing to measure fewer GPUs than asked")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [x for x in r.stdout.splitlines() if x.startswith("{")]
+    for x in r.stdout.splitlines():
+        if not x.startswith("{"):
+            print(x, file=sys.stderr)
+    if r.returncode != 0:
+        for x in lines:
+            print(x, flush=True)
+        raise SystemExit(r.returncode)
+    if not lines:
+        raise SystemExit("bench.py: the launched ranks printed no result line")
+    got = json.loads(lines[-1]).get("n_gpus")
+    if got != n:
+        raise SystemExit(f"bench.py: asked for --gpus {n}, the run reports n_gpus = {got}")
+    print(lines[-1], flush=True)
+    raise SystemExit(0)
+
+
+if __name__ == "__main__":
+    _self_launch()
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
 
 from neuralnj_amd import synth, utils, weights  # noqa: E402
 from neuralnj_amd._lib import Nnj  # noqa: E402
@@ -388,25 +453,39 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        # (a bare `python bench.py --gpus N` never gets here: _self_launch() started N ranks under torch.distributed.run)
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: the line would not describe the run asked for")
     # Rehearsal knobs (one-GPU box): NNJ_BENCH_SHARE_GPU=1 puts every rank on cuda:0 and
     # NNJ_BENCH_BACKEND=gloo runs the (tiny) collectives on CPU tensors.  The real multi-GPU run uses
     # one GPU per rank and RCCL ("nccl").
     share = os.environ.get("NNJ_BENCH_SHARE_GPU") == "1"
     backend = os.environ.get("NNJ_BENCH_BACKEND", "nccl")
     dev_index = 0 if share else local_rank
+    if dev_index >= torch.cuda.device_count():
+        raise SystemExit(f"bench.py: rank {rank} (local rank {local_rank}) has no GPU of its own: "
+                         f"{torch.cuda.device_count()} visible")
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     cdev = dev if backend == "nccl" else torch.device("cpu")     # where collective buffers live
     dist = None
-    if world > 1:
+    # NNJ_BENCH_FORCE_DIST=1: run the collectives at world = 1 too (the RCCL branch on a one-GPU box: process group on
+    # the device, weight broadcast, all_gather, all_reduce MIN / MAX and the barriers all execute on GPU tensors)
+    force_dist = os.environ.get("NNJ_BENCH_FORCE_DIST") == "1"
+    if world > 1 or force_dist:
         import torch.distributed as dist_mod
         dist = dist_mod
+        if "MASTER_ADDR" not in os.environ or "MASTER_PORT" not in os.environ:
+            import socket
+            s_ = socket.socket()
+            s_.bind(("127.0.0.1", 0))
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", str(s_.getsockname()[1]))
+            s_.close()
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     cfgs = utils.shipped_config()
     packed = weights.pack(cfgs, weights.seeded_state(cfgs, 0, "sharp"))
@@ -475,7 +554,8 @@ def main():
         infos = [torch.empty_like(info) for _ in range(world)]
         dist.all_gather(infos, info)
         per_rank = {"trees_per_sec": [float(x[0]) for x in infos], "device_ordinal": [int(x[1]) for x in infos],
-                    "distinct_devices": len({int(x[1]) for x in infos})}
+                    "distinct_devices": len({int(x[1]) for x in infos}), "backend": backend,
+                    "collectives_on": "device tensors over RCCL" if backend == "nccl" else "host tensors (rehearsal)"}
     # ---- every rank verifies >= 8 of ITS trees against the oracle, outside the timed region; pass flags are reduced
     verified = None
     if not args.no_verify:
@@ -654,6 +734,12 @@ def main():
             hard = hard or not verified.get("all_ranks_ok", True)
         if hard:
             sys.exit(3)
+    # one GPU per rank: an RCCL run whose ranks did not sit on `world` distinct devices is not the
+    # run that was asked for (the shared-GPU rehearsal says so in its environment and is exempt)
+    if per_rank is not None and backend == "nccl" and not share and per_rank["distinct_devices"] != world:
+        print(f"bench.py: {world} ranks ran on {per_rank['distinct_devices']} distinct device(s): {per_rank['device_ordinal']}",
+              file=sys.stderr)
+        sys.exit(4)
 
 
 if __name__ == "__main__":

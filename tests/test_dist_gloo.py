@@ -115,6 +115,18 @@ def test_bench_two_ranks_on_the_device_match_single_rank_runs(tmp_path):
                        cwd=repo, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads([x for x in r.stdout.splitlines() if x.startswith("{")][-1])
+    # the same from a BARE shell -- no launcher, WORLD_SIZE unset: bench.py starts the two ranks itself
+    # (as a child process, before anything touches the GPU) and relays rank 0's line; n_gpus must be what was asked for
+    bare_env = {k: v for k, v in env.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    two_b = tmp_path / "two_bare.npy"
+    rb = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--dump-merges", str(two_b)] + shape,
+                        cwd=repo, env=bare_env, capture_output=True, text=True, timeout=900)
+    assert rb.returncode == 0, rb.stderr[-2000:]
+    out_lines = [x for x in rb.stdout.splitlines() if x.strip()]
+    assert len(out_lines) == 1, out_lines                              # ONE JSON line on stdout
+    bare = json.loads(out_lines[0])
+    assert bare["n_gpus"] == 2 and len(bare["per_rank"]["trees_per_sec"]) == 2
+    assert np.array_equal(np.load(two_b), np.load(two))
     assert line["n_gpus"] == 2 and line["scaling"] == "weak"
     assert len(line["per_rank"]["trees_per_sec"]) == 2 and min(line["per_rank"]["trees_per_sec"]) > 0
     assert line["value"] <= sum(line["per_rank"]["trees_per_sec"]) * 1.0001      # whole-job rate over the SLOWEST rank's time
@@ -129,3 +141,56 @@ def test_bench_two_ranks_on_the_device_match_single_rank_runs(tmp_path):
                             cwd=repo, env=dict(os.environ), capture_output=True, text=True, timeout=900)
         assert r1.returncode == 0, r1.stderr[-2000:]
         assert np.array_equal(np.load(one)[0], got[rank]), f"rank {rank}'s gathered merge lists differ from its single-rank run"
+
+
+def _run_bench(args, env_extra=None, drop=()):
+    import subprocess
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK") + tuple(drop)}
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, os.path.join(repo, "bench.py")] + args, cwd=repo, env=env, capture_output=True,
+                          text=True, timeout=900)
+
+
+def test_bench_refuses_more_gpus_than_the_node_has():
+    """`python bench.py --gpus N` from a bare shell must never print an n_gpus: 1 line.  Here (any
+    box): asking for more GPUs than the node shows is an error before anything is launched or measured."""
+    r = _run_bench(["--gpus", "64", "--steps", "1", "--warmup", "0"])
+    assert r.returncode != 0
+    assert "--gpus 64" in r.stderr and "refusing" in r.stderr
+    assert not [x for x in r.stdout.splitlines() if x.startswith("{")]
+
+
+def test_bench_refuses_a_world_size_that_is_not_gpus():
+    """A launcher whose WORLD_SIZE disagrees with --gpus (either way, including WORLD_SIZE=1) is refused before any
+    GPU call: the printed line would describe another run than the one asked for."""
+    for world, gpus in (("1", "2"), ("2", "1"), ("2", "4")):
+        r = _run_bench(["--gpus", gpus, "--steps", "1", "--warmup", "0"],
+                       env_extra={"WORLD_SIZE": world, "RANK": "0", "LOCAL_RANK": "0"})
+        assert r.returncode != 0
+        assert f"--gpus {gpus} but WORLD_SIZE={world}" in r.stderr, r.stderr[-500:]
+
+
+@pytest.mark.gpu
+def test_bench_rccl_branch_runs_at_world_one(tmp_path):
+    """the `"nccl"` (= RCCL) branch of bench.py executed on the one-GPU box.  NNJ_BENCH_FORCE_DIST=1
+    makes a world-1 run go through init_process_group("nccl", device_id=...), the weight broadcast, both all_gathers, the
+    all_reduce(MAX / MIN) of the timing and the verification flags, and the barriers -- all on DEVICE tensors; the line
+    must say so and the merge lists must equal those of the plain run."""
+    import json
+    shape = ["--batch", "16", "--taxa", "20", "--sites", "256", "--steps", "1", "--warmup", "1", "--no-cpu-baseline",
+             "--no-compat", "--no-single-msa"]
+    a, b = tmp_path / "rccl.npy", tmp_path / "plain.npy"
+    r = _run_bench(["--gpus", "1", "--dump-merges", str(a)] + shape,
+                   env_extra={"NNJ_BENCH_FORCE_DIST": "1", "NNJ_BENCH_BACKEND": "nccl", "HSA_ENABLE_IPC_MODE_LEGACY": "0"},
+                   drop=("NNJ_BENCH_SHARE_GPU",))
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([x for x in r.stdout.splitlines() if x.startswith("{")][-1])
+    assert line["n_gpus"] == 1
+    pr = line["per_rank"]
+    assert pr["backend"] == "nccl" and pr["distinct_devices"] == 1 and pr["device_ordinal"] == [0]
+    v = line["verified"]
+    assert v["ok"] and v["all_ranks_ok"] and v["all_ranks_rf_gate_ok"] and v["ranks_verified"] == 1
+    r2 = _run_bench(["--gpus", "1", "--no-verify", "--no-profile", "--dump-merges", str(b)] + shape)
+    assert r2.returncode == 0, r2.stderr[-2000:]
+    assert np.array_equal(np.load(a), np.load(b))
