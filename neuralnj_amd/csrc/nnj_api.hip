@@ -14,6 +14,7 @@
 
 #include "../../include/nnj.h"
 #include "nnj_encoder.hpp"
+#include "nnj_encoder64.hpp"
 #include "nnj_rowfused.hpp"
 #include "nnj_scorer.hpp"
 #include "nnj_scorer16.hpp"
@@ -48,6 +49,12 @@ struct nnj_handle {
   bool have_w = false;
   float* d_w = nullptr;          // packed weights followed by derived tensors
   float* d_wimg = nullptr;       // the scorer's four 64 x 64 operands as ready LDS images (k_build_scorer_images)
+  // the fp64 encoder of alignments of more than 64 rows (nnj_encoder64.hpp): every packed tensor as doubles at its
+  // packed offset, the embed tables unrounded, then per layer the stacked q|k|v matrices of both attentions
+  double* d_w64 = nullptr;
+  struct Qkv64 { size_t Wrow, brow, Wcol, bcol; };
+  std::vector<Qkv64> lo64;
+  int enc64 = 1;                 // NNJ_ENC64=0: the f16x3 encoder above 64 rows too (A/B of the parity tables only)
   size_t n_packed = 0;
   std::vector<LayerOff> lo;
   size_t oE0, oe0, oE2, oe2, oWh, obh, oWg, obg, oWgq, obgq, oWgk, obgk, oS0, os0, os2w, os2b;
@@ -372,9 +379,28 @@ EncWs enc_ws(int B, int T, int C) {
   return w;
 }
 
+// scratch of the fp64 encoder (more than 64 rows), in DOUBLES, for ONE alignment (the host loops over the batch):
+// x | y = LayerNorm(x) | big = { Q, K, V planes [8][R*8][Cp] + ctx  |  column q|k|v [token][192] + ctx  |  FFN hidden [token][256] } | S [8][C][Cp]
+struct Enc64Ws { size_t x, y, big, ctx, s, end; long Cp, plane; };
+Enc64Ws enc64_ws(int T, int C) {
+  Enc64Ws w;
+  w.Cp = (C + 1) / 2 * 2;
+  w.plane = (long)T * 8 * w.Cp;
+  const size_t tok64 = (size_t)T * C * 64;
+  const size_t planes = 3 * 8 * (size_t)w.plane;
+  size_t o = 0;
+  auto take = [&](size_t n) { size_t r = o; o += align_up(n, 32); return r; };
+  w.x = take(tok64);
+  w.y = take(tok64);
+  w.big = take(std::max(planes, 3 * tok64) + 32 + tok64);
+  w.ctx = w.big + align_up(std::max(planes, 3 * tok64), 32);           // the context of either attention, behind its operands
+  w.s = take((size_t)8 * C * w.Cp);
+  w.end = o;
+  return w;
+}
 size_t ws_floats_one(int B, int T, int C) {
   const size_t state = align_up((size_t)B * T * C * 64, 64);
-  const size_t enc = enc_ws(B, T, C).end;
+  const size_t enc = std::max(enc_ws(B, T, C).end, T > 64 ? 2 * enc64_ws(T, C).end : (size_t)0);
   const size_t loop = loop_ws(B, T, C).end;
   return state + std::max(enc, loop) + 256;
 }
@@ -569,8 +595,111 @@ int launch_encoder(nnj_handle* h, const uint8_t* codes, const float* onehot, con
   return NNJ_OK;
 }
 
+// ---- more than 64 rows: the encoder in fp64 (nnj_encoder64.hpp), one alignment at a time
+template <int BM, int BN, bool TA, bool TB, typename EPI>
+int gemm64(nnj_handle* h, const Gemm64& g, const EPI& epi, int batches, hipStream_t st) {
+  const size_t lds = gemm64_lds<BM, BN, TA, TB>();
+  if (int rc = set_lds(h, (k64_gemm<BM, BN, TA, TB, EPI>), lds)) return rc;
+  const long gx = (g.N + BN - 1) / BN, gy = (g.M + BM - 1) / BM;
+  if (gy > 65535 || batches > 65535) return fail(h, NNJ_ERR_UNSUPPORTED, "fp64 encoder: %d x %d exceeds the launch grid", g.M, g.N);
+  hipLaunchKernelGGL((k64_gemm<BM, BN, TA, TB, EPI>), dim3((unsigned)gx, (unsigned)gy, (unsigned)batches), dim3(256), lds, st, g, epi);
+  return NNJ_OK;
+}
+int run_encoder64(nnj_handle* h, const uint8_t* codes, const float* onehot, const uint8_t* mask, float* x_out,
+                  float* scratch, int B, int T, int C, hipStream_t st) {
+  const Enc64Ws ew = enc64_ws(T, C);
+  double* base = reinterpret_cast<double*>(scratch);
+  double *x = base + ew.x, *y = base + ew.y, *big = base + ew.big, *ctx = base + ew.ctx, *S = base + ew.s;
+  const double* w = h->d_w64;
+  const int K = h->cfg.patch_size, dt = h->cfg.embed_dim, nl = h->cfg.num_layers;
+  const long ntok = (long)T * C, L = (long)C * K;
+  const int RD = T * 8;
+  const unsigned ln_grid = (unsigned)((ntok * 16 + 255) / 256);
+  // reference no-grad chunking: one masked_fill(-10000) per row chunk, summed (axial_attention.py:35-64)
+  int nchunks = 1;
+  if ((long)T * C > 1024) { int max_rows = 1024 / C; if (max_rows < 1) max_rows = 1; nchunks = (T + max_rows - 1) / max_rows; }
+  const double fill = -10000.0 * nchunks;
+  const double row_scale = 1.0 / (sqrt((double)NNJ_DH) * sqrt((double)T)), col_scale = 1.0 / sqrt((double)NNJ_DH);
+  const size_t lds_col = (size_t)T * 64 * sizeof(double);
+  if (int rc = set_lds(h, k64_col_attention, lds_col)) return rc;
+  for (int b = 0; b < B; ++b) {
+    const uint8_t* mb = mask ? mask + (size_t)b * C : nullptr;
+    {
+      Scope sc(h, st, PK_EMBED);
+      const Embed64W e{w + h->oE0, w + h->oe0, w + h->oE2, w + h->oe2, w + h->olut, w + h->optab};
+      hipLaunchKernelGGL(k64_embed, dim3((unsigned)((ntok + 3) / 4)), dim3(256), 0, st,
+                         codes ? codes + (size_t)b * T * L : nullptr, onehot ? onehot + (size_t)b * T * L * 4 : nullptr, e, x,
+                         T, C, K);
+    }
+    for (int l = 0; l < nl; ++l) {
+      const LayerOff& lo = h->lo[l];
+      const nnj_handle::Qkv64& q64 = h->lo64[l];
+      double *Qp = big, *Kp = big + 8 * ew.plane, *Vp = big + 16 * ew.plane;
+      {   // tied row attention: LN -> q,k,v planes
+        Scope sc(h, st, PK_ROW_QKV);
+        hipLaunchKernelGGL(k64_layernorm, dim3(ln_grid), dim3(256), 0, st, (const double*)x, y, w + lo.row[8], w + lo.row[9], ntok, dt);
+        const Gemm64 g{w + q64.Wrow, 64, 0, y, 64, 0, 192, (int)ntok, 64};
+        const EpiRowQkv epi{Qp, Kp, Vp, w + q64.brow, mb, C, ew.Cp, ew.plane, row_scale};
+        if (int rc = gemm64<64, 128, false, false>(h, g, epi, 1, st)) return rc;
+      }
+      {   // S = Q^T K per head, softmax over the keys
+        Scope sc(h, st, PK_ROW_S);
+        const Gemm64 g{Qp, ew.Cp, ew.plane, Kp, ew.Cp, ew.plane, C, C, RD};
+        const EpiLogits epi{S, ew.Cp, (long)C * ew.Cp, mb, fill};
+        if (int rc = gemm64<128, 128, true, true>(h, g, epi, 8, st)) return rc;
+        hipLaunchKernelGGL(k64_softmax_rows, dim3((unsigned)(8 * C)), dim3(256), 0, st, S, ew.Cp, C);
+      }
+      {   // ctx = P V
+        Scope sc(h, st, PK_ROW_PV);
+        const Gemm64 g{S, ew.Cp, (long)C * ew.Cp, Vp, ew.Cp, ew.plane, C, RD, C};
+        const EpiCtx epi{ctx, C};
+        if (int rc = gemm64<128, 128, false, false>(h, g, epi, 8, st)) return rc;
+      }
+      {
+        Scope sc(h, st, PK_TOK1);
+        {   // row out-projection + residual
+          const Gemm64 g{ctx, 64, 0, w + lo.row[6], 64, 0, (int)ntok, 64, 64};
+          const EpiResid epi{x, w + lo.row[7]};
+          if (int rc = gemm64<128, 64, false, false>(h, g, epi, 1, st)) return rc;
+        }
+        if (!(l == 0 && h->debug_stop == 1)) {
+          // column attention: LN -> q|k|v -> R x R attention per column and head -> out-projection + residual
+          hipLaunchKernelGGL(k64_layernorm, dim3(ln_grid), dim3(256), 0, st, (const double*)x, y, w + lo.col[8], w + lo.col[9], ntok, dt);
+          const Gemm64 g{y, 64, 0, w + q64.Wcol, 64, 0, (int)ntok, 192, 64};
+          const EpiColQkv epi{big, w + q64.bcol, col_scale};
+          if (int rc = gemm64<128, 64, false, false>(h, g, epi, 1, st)) return rc;
+          hipLaunchKernelGGL(k64_col_attention, dim3((unsigned)C, 2), dim3(256), lds_col, st, (const double*)big, ctx, mb, T, C);
+          const Gemm64 g2{ctx, 64, 0, w + lo.col[6], 64, 0, (int)ntok, 64, 64};
+          const EpiResid epi2{x, w + lo.col[7]};
+          if (int rc = gemm64<128, 64, false, false>(h, g2, epi2, 1, st)) return rc;
+        }
+      }
+      if (l == 0 && (h->debug_stop == 1 || h->debug_stop == 2)) break;
+      {
+        Scope sc(h, st, PK_FFN);
+        hipLaunchKernelGGL(k64_layernorm, dim3(ln_grid), dim3(256), 0, st, (const double*)x, y, w + lo.ln_w, w + lo.ln_b, ntok, dt);
+        const Gemm64 g{y, 64, 0, w + lo.W1, 64, 0, (int)ntok, 256, 64};
+        const EpiGelu epi{big, w + lo.b1};
+        if (int rc = gemm64<128, 128, false, false>(h, g, epi, 1, st)) return rc;
+        const Gemm64 g2{big, 256, 0, w + lo.W2, 256, 0, (int)ntok, 64, 256};
+        const EpiResid epi2{x, w + lo.b2};
+        if (int rc = gemm64<128, 64, false, false>(h, g2, epi2, 1, st)) return rc;
+      }
+    }
+    {
+      Scope sc(h, st, PK_MISC);
+      const long n = ntok * 64;
+      hipLaunchKernelGGL(k64_store_f32, dim3((unsigned)((n / 2 + 255) / 256)), dim3(256), 0, st, (const double*)x,
+                         x_out + (size_t)b * ntok * 64, n);
+    }
+  }
+  HIPCHK(h, hipGetLastError());
+  return NNJ_OK;
+}
+
 int run_encoder(nnj_handle* h, const uint8_t* codes, const uint8_t* mask, float* x, float* scratch, int B, int T,
                 int C, hipStream_t st, const float* onehot = nullptr) {
+  if (T > 64 && h->enc64) return run_encoder64(h, codes, onehot, mask, x, scratch, B, T, C, st);
   switch (enc_dims(B, T, C).NT) {
     case 1: return launch_encoder<1>(h, codes, onehot, mask, x, scratch, B, T, C, st);
     case 2: return launch_encoder<2>(h, codes, onehot, mask, x, scratch, B, T, C, st);
@@ -1186,6 +1315,7 @@ int nnj_create(const nnj_config* cfg, nnj_handle** out) {
   if (const char* e = getenv("NNJ_TWO_PASS")) h->two_pass = atoi(e);
   if (const char* e = getenv("NNJ_TWO_PASS_CAND")) h->two_pass_cand = atoi(e);
   if (const char* e = getenv("NNJ_STEP_W")) h->step_w = atoi(e);
+  if (const char* e = getenv("NNJ_ENC64")) h->enc64 = atoi(e);
   if (const char* e = getenv("NNJ_GRAPH")) h->use_graph = atoi(e);     // NNJ_GRAPH=0: small-batch rollouts are never replayed from a hipGraph
   h->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   if (hipSetDevice(cfg->device) != hipSuccess || hipMalloc(&h->d_flag, sizeof(int)) != hipSuccess ||
@@ -1202,6 +1332,7 @@ int nnj_destroy(nnj_handle* h) {
   hipSetDevice(h->cfg.device);
   if (h->d_w) hipFree(h->d_w);
   if (h->d_wimg) hipFree(h->d_wimg);
+  if (h->d_w64) hipFree(h->d_w64);
   if (h->d_flag) hipFree(h->d_flag);
   if (h->gexec) hipGraphExecDestroy(h->gexec);
   for (int k = 0; k < 4; ++k) {
@@ -1308,6 +1439,41 @@ int nnj_load_weights(nnj_handle* h, const float* p, size_t n) {
       host[h->olut + code * D + f] = (float)s;
     }
   }
+  // fp64 copy for the > 64-row encoder: the packed tensors converted exactly, the embed tables unrounded, stacked q|k|v
+  std::vector<double> host64(host.begin(), host.end());
+  for (size_t i = 0; i < K; ++i)
+    for (int code = 0; code < 6; ++code)
+      for (size_t j = 0; j < D; ++j) {
+        double s = i == 0 ? (double)e0[j] : 0.0;
+        for (int v = 0; v < 4; ++v) s += (double)E0[j * 4 * K + 4 * i + v] * onehot[code][v];
+        host64[h->optab + (i * 6 + code) * D + j] = s;
+      }
+  for (int code = 0; code < 6 && K == 1; ++code) {
+    double t1[NNJ_D];
+    for (size_t j = 0; j < D; ++j) {
+      double s = e0[j];
+      for (int v = 0; v < 4; ++v) s += (double)E0[j * 4 + v] * onehot[code][v];
+      t1[j] = 0.5 * s * (1.0 + erf(s * 0.70710678118654752440));
+    }
+    for (size_t f = 0; f < D; ++f) {
+      double s = e2[f];
+      for (size_t j = 0; j < D; ++j) s += (double)E2[f * D + j] * t1[j];
+      host64[h->olut + code * D + f] = s;
+    }
+  }
+  h->lo64.assign(h->cfg.num_layers, nnj_handle::Qkv64());
+  for (int l = 0; l < h->cfg.num_layers; ++l)
+    for (int a = 0; a < 2; ++a) {
+      const size_t* t = a == 0 ? h->lo[l].row : h->lo[l].col;         // Wk,bk,Wv,bv,Wq,bq,Wo,bo,ln_w,ln_b
+      const size_t oW = host64.size();
+      for (int which : {4, 0, 2}) host64.insert(host64.end(), p + t[which], p + t[which] + D * D);
+      const size_t ob = host64.size();
+      for (int which : {5, 1, 3}) host64.insert(host64.end(), p + t[which], p + t[which] + D);
+      if (a == 0) { h->lo64[l].Wrow = oW; h->lo64[l].brow = ob; } else { h->lo64[l].Wcol = oW; h->lo64[l].bcol = ob; }
+    }
+  if (h->d_w64) { hipFree(h->d_w64); h->d_w64 = nullptr; }
+  HIPCHK(h, hipMalloc(&h->d_w64, host64.size() * sizeof(double)));
+  HIPCHK(h, hipMemcpy(h->d_w64, host64.data(), host64.size() * sizeof(double), hipMemcpyHostToDevice));
   if (h->d_w) { hipFree(h->d_w); h->d_w = nullptr; }
   if (h->gexec) { hipGraphExecDestroy(h->gexec); h->gexec = nullptr; }      // captured launches point at the old weights
   HIPCHK(h, hipMalloc(&h->d_w, total * sizeof(float)));
