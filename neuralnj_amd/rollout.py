@@ -295,6 +295,16 @@ def _reinforce_loss(batch, agent, env, forced_merges, tree_scores, baseline, tem
     return policy_loss + entropy_reg * entropy_reg_strength, tables
 
 
+def episode_rng(seed, rank):
+    """Uniform stream of rank `rank`'s sampled episodes (rl_finetuning)."""
+    return np.random.default_rng([int(seed), int(rank) + 1, 1])
+
+
+def baseline_rng(seed):
+    """Uniform stream of the first, rank-independent baseline rollout (rl_finetuning): never equal to an episode stream."""
+    return np.random.default_rng([int(seed), 0, 2])
+
+
 def rl_finetuning(cfgs, batch, agent, optimizer, env, stop_step=20, seed=0, model=None, temperature=1.0, device=None,
                   dist=None):
     """Counterpart of the reference's RL_finetuning (finetune_rl_search.py:192-335) for one alignment: per episode one
@@ -318,7 +328,10 @@ def rl_finetuning(cfgs, batch, agent, optimizer, env, stop_step=20, seed=0, mode
     codes = (batch["codes"] if "codes" in batch else agent.onehot_to_codes(batch["data"].to(device)))[:1].to(device)
     mask = (batch["seq_weights"].to(device) == 0)[:1]
     T = codes.shape[1]
-    rng = np.random.default_rng([seed, rank])
+    # Two families of uniform streams with DIFFERENT non-zero tags: SeedSequence zero-pads its entropy, so [seed] and
+    # [seed, 0] are the same stream -- rank 0's first episode would replay the baseline rollout (advantage exactly 0, no
+    # gradient: ADVICE r4).  Episodes: [seed, rank + 1, 1]; the rank-independent baseline: [seed, 0, 2].
+    rng = episode_rng(seed, rank)
     agent.eval()
 
     def score(merges):
@@ -329,7 +342,7 @@ def rl_finetuning(cfgs, batch, agent, optimizer, env, stop_step=20, seed=0, mode
         # the first baseline is ONE sampled rollout shared by all episodes of the epoch (finetune_rl_search.py:213-222):
         # drawn from a rank-independent stream so that every rank starts from the same baseline and the all-reduced
         # gradient equals the single-process run's
-        u0 = torch.from_numpy(np.random.default_rng([seed]).random((1, T - 1)).astype(np.float32))
+        u0 = torch.from_numpy(baseline_rng(seed).random((1, T - 1)).astype(np.float32))
         first = ctx.rollout_sample(codes, mask, u0, temperature=temperature, replicas=1)["merges"]
         sc0, br0 = score(first)
         baseline_val = float(sc0[0])

@@ -213,3 +213,19 @@ def test_load_phy_file_sequential_policy(tmp_path):
     p.write_text("4 8\nt1 ACGTACGT\nt2 ACGTACGT\n")
     with pytest.raises(AssertionError):
         phydata.load_phy_file(str(p))
+
+
+def test_finetune_uniform_streams_never_coincide():
+    """SeedSequence zero-pads its entropy, so default_rng([s]) and default_rng([s, 0]) are ONE stream -- rank 0's
+    first episode used to replay the baseline rollout's uniforms (advantage exactly 0, no policy gradient).  The baseline
+    stream and every rank's episode stream must differ, for every rank and seed, and the ranks among themselves."""
+    from neuralnj_amd.rollout import baseline_rng, episode_rng
+    for seed in (0, 1, 7):
+        u0 = baseline_rng(seed).random(16)
+        rows = [episode_rng(seed, r).random((3, 16)) for r in range(4)]
+        for r, u in enumerate(rows):
+            assert not np.array_equal(u0, u[0]), f"seed {seed}: rank {r}'s first episode replays the baseline"
+        for a in range(4):
+            for b in range(a + 1, 4):
+                assert not np.array_equal(rows[a], rows[b])
+        assert np.array_equal(baseline_rng(seed).random(16), u0)          # rank independent and reproducible
