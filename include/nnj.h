@@ -288,10 +288,13 @@ int nnj_numeric_status(nnj_handle* h, int32_t* nonfinite_out, void* stream);
  * since the last call must be discarded exactly like non-finite ones.  NNJ_STATUS_MERGE_WEIGHTS: in a rollout the
  * attention weights of a merge come from the scorer's own logits of the picked pair (two-pass NJ step);
  * a pick for which neither source applied while the fallback pass was not scheduled is an internal error of the
- * library, reported here instead of returning a tree built on zero weights. */
+ * library, reported here instead of returning a tree built on zero weights.  NNJ_STATUS_BAD_MERGE: a merge list handed
+ * to nnj_tree_loglik / nnj_tree_optimize held a pair with i >= j or a position outside the live list (the lists live in
+ * device memory, so they are validated by the kernel that reads them): the likelihoods of that call must be discarded. */
 #define NNJ_STATUS_NONFINITE 1
 #define NNJ_STATUS_BARRIER_TIMEOUT 2
 #define NNJ_STATUS_MERGE_WEIGHTS 4
+#define NNJ_STATUS_BAD_MERGE 8
 
 /* Kernel timing for bench.py's roofline object: when enabled, every kernel launch of
  * the entry points is bracketed by a HIP event pair on the launch stream, tagged with

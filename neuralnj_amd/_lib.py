@@ -363,6 +363,10 @@ class Nnj:
         before trusting merge lists fetched to the host."""
         flag = C.c_int32(0)
         self._chk(self.lib.nnj_numeric_status(self.h, C.byref(flag), self._stream()))
+        if flag.value & 8:
+            raise ValueError(
+                "tree likelihood: a merge list held a pair with i >= j or a position outside the live list "
+                "(NNJ_STATUS_BAD_MERGE): the likelihoods of this call are invalid")
         if flag.value & 4:
             raise RuntimeError(
                 "two-pass NJ step: a merge had no source for its attention weights and no fallback was launched "

@@ -15,7 +15,7 @@
 #include "../../include/nnj.h"
 #include "nnj_encoder.hpp"
 #include "nnj_encoder64.hpp"
-#include "nnj_rowfused.hpp"
+#include "nnj_rowattn.hpp"
 #include "nnj_scorer.hpp"
 #include "nnj_scorer16.hpp"
 #include "nnj_scorer_wide.hpp"
@@ -233,11 +233,10 @@ PairGeom pair_geom(int mode, int n, int B, int C) {
   if (mode == PAIRS_INCR) {
     // wave-private kernels: grid (nsc_blocks, B), 4 partial sets per block; nsc counts PARTIALS
     g.npairs = n; g.tpw = 1; g.pg = 1; g.ppad = 64;
-    static const int wgs = getenv("NNJ_INCR_WGS") ? atoi(getenv("NNJ_INCR_WGS")) : 1024;
-    int blocks = (wgs + B - 1) / B;            // (measured flat from 512 to 3072 workgroups per launch)
+    int blocks = (1024 + B - 1) / B;           // ~1024 workgroups per launch (measured flat from 512 to 3072)
     // small batches: down to 4 sites per workgroup -- one alignment of 1024 sites then runs 256 workgroups with four busy
     // waves each, one per SIMD of every CU, instead of 128 with eight (B = 1: 3.53 -> 3.48 ms per tree; 2 sites: 4.6)
-    static const int mincs = getenv("NNJ_INCR_MINCS") ? std::max(1, atoi(getenv("NNJ_INCR_MINCS"))) : 4;
+    constexpr int mincs = 4;
     const int max_blocks = (C + mincs - 1) / mincs;
     if (blocks > max_blocks) blocks = max_blocks;
     if (blocks < 1) blocks = 1;
@@ -287,13 +286,14 @@ LoopWs loop_ws(int B, int T, int C) {
   size_t ap = 0, al = 0, sp = 0, fu = 0;
   const int Tn = std::min(T, 64);                                  // the 64-row kernels
   for (int mode = 0; mode < 2; ++mode)
-    for (int n : {Tn, std::min(Tn, 48), std::min(Tn, 32), std::min(Tn, 16)}) {   // the incremental geometry changes at n = 48, 32 and 16
-      if (n < 2) continue;
-      PairGeom g = pair_geom(mode, n, B, C);
-      ap = std::max(ap, (size_t)B * g.nsc_a * g.ppad * 64);
-      al = std::max(al, (size_t)B * g.ppad * 64);
-      sp = std::max(sp, (size_t)B * g.nsc * g.ppad);
-    }
+    for (int n : {Tn, std::min(Tn, 48), std::min(Tn, 32), std::min(Tn, 16)})     // the incremental geometry changes at n = 48, 32 and 16
+      for (int Bg : {B, 1}) {              // Bg = 1: the one-alignment launch of sampled replicas (rollout_core, rep0)
+        if (n < 2) continue;
+        PairGeom g = pair_geom(mode, n, Bg, C);
+        ap = std::max(ap, (size_t)Bg * g.nsc_a * g.ppad * 64);
+        al = std::max(al, (size_t)Bg * g.ppad * 64);
+        sp = std::max(sp, (size_t)Bg * g.nsc * g.ppad);
+      }
   if (T > 64) {                                                    // the star kernels (more than 64 live rows)
     for (int full = 0; full < 2; ++full)
       for (int n : {T, std::min(T, 128)})
@@ -332,6 +332,15 @@ LoopWs loop_ws(int B, int T, int C) {
   return w;
 }
 
+// A launch geometry against the regions loop_ws reserved (the workspace may have been sized for another batch than the one a
+// launch is for): never write past a region silently.
+int check_pair_fit(nnj_handle* h, const LoopWs& w, const PairGeom& g, int B, const char* what) {
+  if ((size_t)B * g.nsc_a * g.ppad * 64 > w.alpha - w.alpha_part || (size_t)B * g.ppad * 64 > w.score_part - w.alpha ||
+      (size_t)B * g.nsc * g.ppad > w.full - w.score_part)
+    return fail(h, NNJ_ERR_WORKSPACE, "%s (pairs=%d, B=%d, partial sets=%d) does not fit the workspace regions", what, g.npairs, B, g.nsc);
+  return NNJ_OK;
+}
+
 // Zero fill as a KERNEL.  The small-batch rollout is captured into a hipGraph and replayed (rollout_impl): with the three
 // hipMemsetAsync calls of the path captured as memset nodes every second replay returned wrong score tables for C >= 256
 // (round 4: tools/graph_check2.py, profiles/r04/graph_check.txt -- the encoder output right, the tables wrong: the zero
@@ -342,10 +351,11 @@ __global__ void k_zero_bytes(uint8_t* __restrict__ p, size_t n) {
   else for (size_t k = i; k < n; ++k) p[k] = 0;
 }
 // (p 16-byte aligned: every caller passes a workspace region)
-static void zero_async(void* p, size_t bytes, hipStream_t st) {
-  if (!bytes) return;
+static hipError_t zero_async(void* p, size_t bytes, hipStream_t st) {
+  if (!bytes) return hipSuccess;
   const size_t threads = (bytes + 15) / 16;
   hipLaunchKernelGGL(k_zero_bytes, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, static_cast<uint8_t*>(p), bytes);
+  return hipGetLastError();
 }
 
 // the scorer kernels read the site mask unconditionally (no branch in their site loops): a caller without a mask
@@ -354,7 +364,7 @@ int scorer_mask(nnj_handle* h, const uint8_t* mask, float* base, const LoopWs& w
                 const uint8_t** out) {
   if (mask) { *out = mask; return NNJ_OK; }
   uint8_t* z = reinterpret_cast<uint8_t*>(base + w.zmask);
-  zero_async(z, (size_t)B * C, st);
+  HIPCHK(h, zero_async(z, (size_t)B * C, st));
   *out = z;
   return NNJ_OK;
 }
@@ -374,7 +384,7 @@ EncWs enc_ws(int B, int T, int C) {
   w.v6 = take(nbh * g.v_bh / 4);
   w.s = take(nbh * g.s_bh);
   w.m = take(nbh * g.m_bh);
-  w.cls = take(((size_t)B * g.Cp + (size_t)B * g.nrb + 3) / 4 + 1);   // key classes + their per-256-key-block OR (k_row_fused)
+  w.cls = take(((size_t)B * g.Cp + 3) / 4 + 1);                          // key classes
   w.end = o;
   return w;
 }
@@ -444,15 +454,9 @@ int launch_encoder(nnj_handle* h, const uint8_t* codes, const float* onehot, con
                        h->cfg.patch_size);
     hipLaunchKernelGGL(k_key_classes, dim3((unsigned)(((size_t)B * g6.Cp + 255) / 256)), dim3(256), 0, st, mask, cls, B,
                        C, g6.Cp);
-    hipLaunchKernelGGL(k_key_class_blocks, dim3((unsigned)((B * g6.nrb + 255) / 256)), dim3(256), 0, st, (const uint8_t*)cls,
-                       cls + (size_t)B * g6.Cp, B * g6.nrb, g6.Cp);
     // V6 keys beyond the alignment meet probabilities that are exactly 0: they only have to be finite
-    if (g6.Cp != C) zero_async(V6, (size_t)nbh * g6.v_bh, st);
+    if (g6.Cp != C) HIPCHK(h, zero_async(V6, (size_t)nbh * g6.v_bh, st));
   }
-  // One kernel per layer for the tied row attention (nnj_rowfused.hpp) where its accumulators fit one wave's registers and
-  // its two rings the LDS: up to 52 rows (13 head tiles), at least three operand tiles.  NNJ_ROW_FUSED=0: k_row_s + k_row_pv.
-  static const bool row_fused_env = getenv("NNJ_ROW_FUSED") && atoi(getenv("NNJ_ROW_FUSED")) != 0;
-  const bool row_fused = row_fused_env && g6.nech == 1 && g6.ETc <= 13 && g6.KS >= 3;
   // reference no-grad chunking: one masked_fill(-10000) per row chunk, summed (axial_attention.py:35-64)
   int nchunks = 1;
   if ((long)T * C > 1024) { int max_rows = 1024 / C; if (max_rows < 1) max_rows = 1; nchunks = (T + max_rows - 1) / max_rows; }
@@ -471,44 +475,17 @@ int launch_encoder(nnj_handle* h, const uint8_t* codes, const float* onehot, con
       hipLaunchKernelGGL(k_qkv6, dim3(grid), dim3(512), lds_qkv, st, (const float*)x, mask,
                          attn_ptrs(h, h->lo[l].row), Q6, K6, V6, g6, B);
     }
-    if (row_fused) {
-      Scope sc(h, st, PK_ROW_PV);
-      const float qs = LOG2E / (sqrtf((float)NNJ_DH) * sqrtf((float)T));
-      const unsigned grid = (unsigned)((nbh + 7) / 8 * 8 * (g6.Cp / 128));
-#define NNJ_RF_CASE(N)                                                                                   \
-  case N: {                                                                                              \
-    const size_t lds = 3 * (NPL * 4096 + NPL * 4096) + 3 * ((N * NPL * 1024 + 4095) / 4096 * 4096);      \
-    if (int rc = set_lds(h, k_row_fused<N>, lds)) return rc;                                             \
-    hipLaunchKernelGGL(k_row_fused<N>, dim3(grid), dim3(256), lds, st, (const uint8_t*)Q6, (const uint8_t*)K6, \
-                       (const uint8_t*)V6, (const uint8_t*)cls, (const uint8_t*)(cls + (size_t)B * g6.Cp), ctx, g6, nbh, fill, qs); \
-  } break;
-      switch (g6.ETc) {
-        NNJ_RF_CASE(1) NNJ_RF_CASE(2) NNJ_RF_CASE(4) NNJ_RF_CASE(6) NNJ_RF_CASE(8) NNJ_RF_CASE(10) NNJ_RF_CASE(13)
-        default: return fail(h, NNJ_ERR_UNSUPPORTED, "row attention: no fused instantiation for %d head tiles", g6.ETc);
-      }
-#undef NNJ_RF_CASE
-    } else {
     {
       Scope sc(h, st, PK_ROW_S);
       const float qs = LOG2E / (sqrtf((float)NNJ_DH) * sqrtf((float)T));
-      // NNJ_ROWS_RS=1: operand tiles staged through registers instead of the LDS-DMA ring (round 4: correct, 33.5 vs 32.2 ms
-      // per rollout, profiles/r04/ab_rowattn_regstage.txt -- the ring stays)
-      static const bool rows_rs = getenv("NNJ_ROWS_RS") && atoi(getenv("NNJ_ROWS_RS")) != 0;
-      if (T <= 64 && rows_rs) {
-        constexpr int QW = 128;
-        const size_t lds = (size_t)RsShape<QW>::NST * RsShape<QW>::STAGE;
-        if (int rc = set_lds(h, (k_row_s<QW, 0, true>), lds)) return rc;
-        const unsigned grid = (unsigned)((long)(nbh + 7) / 8 * 8 * g6.nrb * (g6.Cp / QW));
-        hipLaunchKernelGGL((k_row_s<QW, 0, true>), dim3(grid), dim3(256), lds, st, (const uint8_t*)Q6, (const uint8_t*)K6,
-                           (const uint8_t*)cls, Sbuf, Mbuf, g6, nbh, fill, qs);
-      } else if (T <= 64) {
+      if (T <= 64) {
         constexpr int QW = 128;
         const size_t lds = (size_t)RsShape<QW>::NST * RsShape<QW>::STAGE;
         if (int rc = set_lds(h, k_row_s<QW>, lds)) return rc;
         const unsigned grid = (unsigned)((long)(nbh + 7) / 8 * 8 * g6.nrb * (g6.Cp / QW));
         hipLaunchKernelGGL(k_row_s<QW>, dim3(grid), dim3(256), lds, st, (const uint8_t*)Q6, (const uint8_t*)K6,
                            (const uint8_t*)cls, Sbuf, Mbuf, g6, nbh, fill, qs);
-      } else {              // more than 64 rows: chunked accumulation of the 8R-term logits (see k_row_s)
+      } else {              // more than 64 rows (only with NNJ_ENC64=0): chunked accumulation of the 8R-term logits (see k_row_s)
         constexpr int QW = 64, CHK = NNJ_RS_CHK;
         const size_t lds = (size_t)RsShape<QW>::NST * RsShape<QW>::STAGE;
         if (int rc = set_lds(h, (k_row_s<QW, CHK>), lds)) return rc;
@@ -520,43 +497,19 @@ int launch_encoder(nnj_handle* h, const uint8_t* codes, const float* onehot, con
     {
       Scope sc(h, st, PK_ROW_PV);
       const unsigned grid = (unsigned)((nbh + 7) / 8 * 8 * (g6.Cp / 128) * g6.nech);
-      // NNJ_PV_RS=1: V tiles staged through registers instead of the LDS-DMA ring.  Built and measured in round 4
-      // (profiles/r04/ab_rowattn_regstage.txt): correct, 36.7 vs 36.0 ms per rollout -- not faster, so the ring stays
-      static const bool pv_rs = getenv("NNJ_PV_RS") && atoi(getenv("NNJ_PV_RS")) != 0;
 #define NNJ_PV_CASE(N)                                                                                   \
   case N: {                                                                                              \
     const size_t stg = (N * NPL * 1024 + 4095) / 4096 * 4096, lds = (4 * stg <= 163840 ? 4 : 3) * stg;        \
-    if (pv_rs && 4 * stg <= 163840) {                                                                    \
-      if (int rc = set_lds(h, (k_row_pv<N, (N <= 13)>), lds)) return rc;                                 \
-      hipLaunchKernelGGL((k_row_pv<N, (N <= 13)>), dim3(grid), dim3(256), lds, st, (const uint8_t*)V6,   \
-                         (const float*)Sbuf, (const float*)Mbuf, ctx, g6, nbh);                          \
-    } else {                                                                                             \
-      if (int rc = set_lds(h, k_row_pv<N>, lds)) return rc;                                              \
-      hipLaunchKernelGGL(k_row_pv<N>, dim3(grid), dim3(256), lds, st, (const uint8_t*)V6, (const float*)Sbuf, \
-                         (const float*)Mbuf, ctx, g6, nbh);                                              \
-    }                                                                                                    \
-  } break;
-#define NNJ_PV2_CASE(N)                                                                                  \
-  case N: {                                                                                              \
-    const size_t lds = 4 * ((2 * N * NPL * 1024 + 8191) / 8192 * 8192);                                   \
-    if (int rc = set_lds(h, k_row_pv2<N>, lds)) return rc;                                               \
-    hipLaunchKernelGGL(k_row_pv2<N>, dim3(grid), dim3(512), lds, st, (const uint8_t*)V6, (const float*)Sbuf, \
+    if (int rc = set_lds(h, k_row_pv<N>, lds)) return rc;                                                \
+    hipLaunchKernelGGL(k_row_pv<N>, dim3(grid), dim3(256), lds, st, (const uint8_t*)V6, (const float*)Sbuf, \
                        (const float*)Mbuf, ctx, g6, nbh);                                                \
   } break;
-      if (g6.halves) {
-        switch (g6.ETc / 2) {
-          NNJ_PV2_CASE(5) NNJ_PV2_CASE(6) NNJ_PV2_CASE(7) NNJ_PV2_CASE(8)
-          default: return fail(h, NNJ_ERR_UNSUPPORTED, "row attention: no two-half instantiation for %d head tiles", g6.ETc);
-        }
-      } else
       switch (g6.ETc) {
         NNJ_PV_CASE(1) NNJ_PV_CASE(2) NNJ_PV_CASE(4) NNJ_PV_CASE(6) NNJ_PV_CASE(7) NNJ_PV_CASE(8) NNJ_PV_CASE(10) NNJ_PV_CASE(13)
         NNJ_PV_CASE(16)
         default: return fail(h, NNJ_ERR_UNSUPPORTED, "row attention: no instantiation for %d head tiles", g6.ETc);
       }
-#undef NNJ_PV2_CASE
 #undef NNJ_PV_CASE
-    }
     }
     {
       Scope sc(h, st, PK_TOK1);
@@ -565,9 +518,7 @@ int launch_encoder(nnj_handle* h, const uint8_t* codes, const float* onehot, con
       constexpr int NSLOT = 8 / NT;
       const unsigned grid1 = (unsigned)std::min<long>((long)(((size_t)B * C + NSLOT - 1) / NSLOT), (long)h->num_cu);
       const size_t lds = (size_t)(5 * 4096 + NSLOT * (32 * NT * 32 + 32 * NT * 32) + 16 + 448) * sizeof(float);
-      // (NNJ_TOK_SK=0: the form that computes the padded keys' exponentials too)
-      static const bool tok_sk = !(getenv("NNJ_TOK_SK") && atoi(getenv("NNJ_TOK_SK")) == 0);
-      if (NT <= 2 && tok_sk && T <= 32 * NT - 8) {
+      if (NT <= 2 && T <= 32 * NT - 8) {                  // the last eight keys are padding in every lane: k_tok1p<NT, SK>
         if (int rc = set_lds(h, (k_tok1p<NT, (NT <= 2)>), lds)) return rc;
         hipLaunchKernelGGL((k_tok1p<NT, (NT <= 2)>), dim3(grid1), dim3(512), lds, st, ctx, mask, x, attn_ptrs(h, h->lo[l].row),
                            attn_ptrs(h, h->lo[l].col), B, T, C, d.Epad, dbg, h->d_flag);
@@ -582,10 +533,10 @@ int launch_encoder(nnj_handle* h, const uint8_t* codes, const float* onehot, con
       Scope sc(h, st, PK_FFN);
       const size_t lds = (size_t)16384 * sizeof(float);
       {   // persistent FFN / QKV kernels over flat 256-token groups, one workgroup per CU
+        const size_t lds_ffn = (size_t)(8 * IMG64 + 448) * sizeof(float);   // W1 and W2 whole (8 images of 64x64) + LN / bias vectors
         const int groups_per_b = (T * C + 255) / 256;
         const long ngroups = (long)groups_per_b * B;
         const unsigned grid = (unsigned)std::min<long>(ngroups, h->num_cu);
-        const size_t lds_ffn = (size_t)(8 * IMG64 + 448) * sizeof(float);   // W1 and W2 whole (8 images of 64x64) + LN / bias vectors
         if (int rc = set_lds(h, k_ffn16, lds_ffn)) return rc;
         hipLaunchKernelGGL(k_ffn16, dim3(grid), dim3(1024), lds_ffn, st, x, ffn_ptrs(h, h->lo[l]), B, T, C, groups_per_b);
       }
@@ -712,7 +663,7 @@ int run_encoder(nnj_handle* h, const uint8_t* codes, const uint8_t* mask, float*
 int launch_row_xf(nnj_handle* h, const float* S, float* U, float* Kp, float* beta, long bstride, int slots,
                   int rows, int B, int C, hipStream_t st) {
   // (beta entries beyond the 32-site tiles of a row stay 0: see beta_stride)
-  zero_async(beta, (size_t)B * slots * beta_stride(B, C) * sizeof(float), st);
+  HIPCHK(h, zero_async(beta, (size_t)B * slots * beta_stride(B, C) * sizeof(float), st));
   Scope sc(h, st, PK_ROW_XF);
   const int nt32 = (C + 31) / 32;
   const size_t lds = 2 * 4096 * sizeof(float);
@@ -797,6 +748,7 @@ int launch_pair_scores(nnj_handle* h, const RowSet& rs, const int* ij_prev, cons
                        const LoopWs& w, int mode, int n, int B, int C, PairGeom& g, hipStream_t st) {
   if (n > 64) return launch_pair_scores_wide(h, rs, ij_prev, mask, base, w, mode, n, B, C, g, st);
   g = pair_geom(mode, n, B, C);
+  if (int rc = check_pair_fit(h, w, g, B, "pair-score launch")) return rc;
   g.score_src = base + w.score_part;
   const ScorerW sw = scorer_ptrs(h);
   const int has_ctx = n > 2 ? 1 : 0;
@@ -903,6 +855,7 @@ int launch_step2(nnj_handle* h, RowSet rs, const int* live_old, const int* ij, c
   float* S_w = const_cast<float*>(rs.S);
   float* U_w = const_cast<float*>(rs.U);
   g = pair_geom(PAIRS_INCR, n, B, C);
+  if (int rc = check_pair_fit(h, w, g, B, "NJ-step launch")) return rc;
   g.score_src = base + w.score_part;
   int* need = reinterpret_cast<int*>(base + w.need);
   int* cand_run = reinterpret_cast<int*>(base + w.cand_run);
@@ -949,10 +902,10 @@ int launch_step2(nnj_handle* h, RowSet rs, const int* live_old, const int* ij, c
     if (int rc = set_lds(h, (k_step_alpha_w<NT, NW, IL>), lds)) return rc;                                      \
     hipLaunchKernelGGL((k_step_alpha_w<NT, NW, IL>), grid, dim3(64 * NW), lds, st, rs, sw, io, n, C, g.cs);     \
   }
-    // shared tiles + the merged rows of a group of sites as one tile (nnj_step_g.hpp).  NNJ_ALPHA_G: bit mask of the
-    // tiers that use it (as NNJ_SCORE_G): 1 = up to 4 pairs (four sites per group), 2 = 5..8 (two), 4 = 17..24 (two),
-    // 8 = the remaining tiers with one site per group
-    static const int alpha_g = getenv("NNJ_ALPHA_G") ? atoi(getenv("NNJ_ALPHA_G")) : 3;
+    // Tiers (every arm that was measured and lost is in the git history and under profiles/r04, r05):
+    //   <= 4 pairs / 5..8 pairs with enough sites per wave: shared tiles, four / two sites per tile group (nnj_step_g.hpp);
+    //   17..32 pairs: one wave per site, its two tiles stage by stage; 33..48: one wave per site, tile by tile;
+    //   everything else (<= 16 pairs in small workgroups, more than 48 pairs): groups of waves share a site (k_step_alpha).
 #define NNJ_AG(NT, G, IR, NW)                                                                                   \
   {                                                                                                            \
     const size_t lds = (size_t)step_alpha_g_lds(NT, G, IR, NW) * sizeof(float);                                \
@@ -960,21 +913,13 @@ int launch_step2(nnj_handle* h, RowSet rs, const int* live_old, const int* ij, c
     hipLaunchKernelGGL((k_step_alpha_g<NT, G, IR, NW>), grid, dim3(64 * NW), lds, st, rs, sw, io, n, C, g.cs); \
   }
     const bool grp2 = g.cs >= 16, grp4 = g.cs >= 32;      // (see the score kernels below)
-    if (n > 2 && np <= 4 && (alpha_g & 1) && grp4) NNJ_AG(1, 4, 8, 8)
-    else if (n > 2 && np > 4 && np <= 8 && (alpha_g & 2) && grp2) NNJ_AG(1, 2, 8, 8)
-    else if (np > 16 && np <= 24 && (alpha_g & 4) && grp2) NNJ_AG(3, 2, 24, 8)
-    else if (n > 2 && np <= 16 && (alpha_g & 8)) NNJ_AG(1, 1, 16, 8)
-    else if (np > 16 && np <= 32 && (alpha_g & 8)) NNJ_AG(2, 1, 32, 8)
-    else if (np > 32 && np <= 48 && (alpha_g & 8)) NNJ_AG(3, 1, 48, 8)
+    if (n > 2 && np <= 4 && grp4) NNJ_AG(1, 4, 8, 8)
+    else if (n > 2 && np > 4 && np <= 8 && grp2) NNJ_AG(1, 2, 8, 8)
     else
 #undef NNJ_AG
-    if (h->step_w && (ng == 2 || ng == 3)) {
-      // NNJ_ALPHA_IL (bit 2: 17..32 pairs): step 3 of the two tiles stage by stage (three tiles: 52 registers spilled)
-      static const int alpha_il = getenv("NNJ_ALPHA_IL") ? atoi(getenv("NNJ_ALPHA_IL")) : 2;
-      if (ng == 2 && (alpha_il & 2)) NNJ_SW(2, 8, true)
-      else if (ng == 2) NNJ_SW(2, 8, false)
-      else NNJ_SW(3, 8, false)
-    } else {
+    if (h->step_w && ng == 2) NNJ_SW(2, 8, true)
+    else if (h->step_w && ng == 3) NNJ_SW(3, 8, false)
+    else {
       switch (ng) { NNJ_SA(1, 12) NNJ_SA(2, 12) NNJ_SA(3, 12) NNJ_SA(4, 12) }
     }
 #undef NNJ_SW
@@ -993,11 +938,10 @@ int launch_step2(nnj_handle* h, RowSet rs, const int* live_old, const int* ij, c
   {
     Scope sc(h, st, PK_PAIR_SCORE_INCR);
     const dim3 blk16(64 * T16_WAVES);
-    // shared 16-pair tiles (nnj_scorer_g.hpp): G sites per tile group where the pairs of one site leave a tile part
-    // empty.  NNJ_SCORE_G is a bit mask of the tiers that use it: 1 = up to 4 pairs (four sites per tile), 2 = 5..8 (two),
-    // 4 = 17..24 (three tiles for two sites), 8 = the remaining tiers with one site per group (its transposed-read
-    // image alone, for comparisons), 32 = 33..40 (five tiles for two sites, k_inc_score_s5).  Default 54 = 2 + 4 + 16 + 32.
-    static const int score_g = getenv("NNJ_SCORE_G") ? atoi(getenv("NNJ_SCORE_G")) : 54;
+    // Tiers: shared 16-pair tiles where the pairs of one site leave a tile part empty and a wave has enough
+    // sites (nnj_scorer_g.hpp: <= 4 pairs four sites per tile, 5..8 two, 17..24 three tiles per two sites, 33..40 five tiles
+    // per two sites); otherwise one wave per site (17..32: two tiles stage by stage; 33..48: tile by tile), 16-pair tiles
+    // with one wave each up to 16 pairs, the 32-pair kernel above 48.
 #define NNJ_SG(NT, G, IR, NW, ...)                                                                              \
   {                                                                                                            \
     const size_t lds = (size_t)inc_score_g_lds(NT, G, IR, NW) * sizeof(float);                                 \
@@ -1006,17 +950,12 @@ int launch_step2(nnj_handle* h, RowSet rs, const int* live_old, const int* ij, c
                        base + w.alpha, mask, base + w.score_part, n, C, g.cs);                                 \
   }
     // (a wave of these kernels walks the G sites of a group one after the other: where a workgroup has fewer than G sites
-    // per wave -- one alignment per rollout: 4 sites per workgroup -- the one-site-per-wave kernels are the shorter path:
-    // B = 1 3.40 -> 3.34 ms per tree)
+    // per wave -- one alignment per rollout: 4 sites per workgroup -- the one-site-per-wave kernels are the shorter path)
     const bool grp2 = g.cs >= 16, grp4 = g.cs >= 32;
-    if (has_ctx && np <= 4 && (score_g & 16) && grp4) NNJ_SG(1, 4, 8, 8)
-    else if (has_ctx && np <= 4 && (score_g & 1) && grp4) NNJ_SG(1, 4, 8, 12, 1)
-    else if (has_ctx && np <= 8 && np > 4 && (score_g & 2) && grp2) NNJ_SG(1, 2, 8, 12)
-    else if (np > 16 && np <= 24 && (score_g & 4) && grp2) NNJ_SG(3, 2, 24, 8)
-    else if (has_ctx && np <= 16 && (score_g & 8)) NNJ_SG(1, 1, 16, 12)
-    else if (np > 16 && np <= 32 && (score_g & 8)) NNJ_SG(2, 1, 32, 8)
-    else if (np > 32 && np <= 48 && (score_g & 8)) NNJ_SG(3, 1, 48, 8)
-    else if (np > 32 && np <= 40 && (score_g & 32) && g.cs >= 16) {   // (a wave with fewer than two sites: one site per wave is the shorter path)
+    if (has_ctx && np <= 4 && grp4) NNJ_SG(1, 4, 8, 8)
+    else if (has_ctx && np <= 8 && np > 4 && grp2) NNJ_SG(1, 2, 8, 12)
+    else if (np > 16 && np <= 24 && grp2) NNJ_SG(3, 2, 24, 8)
+    else if (np > 32 && np <= 40 && grp2) {
       // 33..40 pairs: five tiles per two sites through one image buffer in turn (k_inc_score_s5)
       const size_t lds = (size_t)inc_score_g_lds(3, 1, 48, 8) * sizeof(float);
       if (int rc = set_lds(h, (k_inc_score_s5<8>), lds)) return rc;
@@ -1037,45 +976,24 @@ int launch_step2(nnj_handle* h, RowSet rs, const int* live_old, const int* ij, c
                            base + w.score_part, n, C, g.cs, 1);
       }
     } else if (np > 32 && np <= 48) {
-      // NNJ_SCORE_IL (bit 1: 33..48 pairs, bit 2: 17..32; default 2): the tiles of a site stage by stage (k_inc_score_wi).
-      // Same box, ms per rollout of 256: two tiles 8.7 -> 7.9; three tiles as a group of two and a single 27 -> 28.4
-      // (all three at once: 45 registers spilled, 36) -- profiles/r04/ab_stage_by_stage.txt
-      static const int score_il = getenv("NNJ_SCORE_IL") ? atoi(getenv("NNJ_SCORE_IL")) : 2;
+      // three tiles, tile by tile (stage by stage they need ~300 registers: all three at once spills at two waves per SIMD
+      // -- profiles/r04/ab_stage_by_stage.txt -- and at ONE wave per SIMD with 512 registers the lost second wave costs
+      // more than the interleave gains: 52.0 -> 55.5 ms per rollout, profiles/r05/ab_one_wave_three_tiles.txt)
       const size_t lds = (size_t)(3 * IMG64 + 8 * (64 * 48 * NPL / 2) + SCORER_CONSTS + 3 * 1024) * sizeof(float);
-      if (score_il & 1) {
-        if (int rc = set_lds(h, (k_inc_score_wi<3>), lds)) return rc;
-        hipLaunchKernelGGL((k_inc_score_wi<3>), grid, dim3(512), lds, st, rs, sw, ij, base + w.alpha, mask,
-                           base + w.score_part, n, C, g.cs, 1);
-      } else {
-        if (int rc = set_lds(h, k_inc_score_w<3, true>, lds)) return rc;
-        hipLaunchKernelGGL((k_inc_score_w<3, true>), grid, dim3(512), lds, st, rs, sw, ij, base + w.alpha, mask,
-                           base + w.score_part, n, C, g.cs, 1);
-      }
+      if (int rc = set_lds(h, k_inc_score_w<3, true>, lds)) return rc;
+      hipLaunchKernelGGL((k_inc_score_w<3, true>), grid, dim3(512), lds, st, rs, sw, ij, base + w.alpha, mask,
+                         base + w.score_part, n, C, g.cs, 1);
     } else if (np > 32) {
       const size_t lds = (size_t)(3 * IMG64 + 4 * b6_floats(64, 64) + 16 + SCORER_CONSTS) * sizeof(float);
       if (int rc = set_lds(h, k_inc_score<2, true>, lds)) return rc;
       hipLaunchKernelGGL((k_inc_score<2, true>), grid, dim3(512), lds, st, rs, sw, ij, base + w.alpha, mask,
                          base + w.score_part, n, C, g.cs, h->d_flag, 1);
-    } else if (static const bool w2 = !(getenv("NNJ_SCORE_W2") && atoi(getenv("NNJ_SCORE_W2")) == 0); w2) {
-      // 17..32 pairs: one wave per site walks two 16-pair tiles (k_inc_score_w<2>), like the three-tile tier -- 0.8 % faster
-      // than the 32-pair kernel with its group barriers, 192 registers and no scratch instead of 256 + 16 bytes
-      // (NNJ_SCORE_W2=0: the 32-pair kernel)
-      static const int score_il2 = getenv("NNJ_SCORE_IL") ? atoi(getenv("NNJ_SCORE_IL")) : 2;
-      const size_t lds = (size_t)(3 * IMG64 + 8 * (64 * 32 * NPL / 2) + SCORER_CONSTS + 2 * 1024) * sizeof(float);
-      if (score_il2 & 2) {
-        if (int rc = set_lds(h, (k_inc_score_wi<2>), lds)) return rc;
-        hipLaunchKernelGGL((k_inc_score_wi<2>), grid, dim3(512), lds, st, rs, sw, ij, base + w.alpha, mask,
-                           base + w.score_part, n, C, g.cs, 1);
-      } else {
-      if (int rc = set_lds(h, (k_inc_score_w<2, true>), lds)) return rc;
-      hipLaunchKernelGGL((k_inc_score_w<2, true>), grid, dim3(512), lds, st, rs, sw, ij, base + w.alpha, mask,
-                         base + w.score_part, n, C, g.cs, 1);
-      }
     } else {
-      const size_t lds = (size_t)(3 * IMG64 + 8 * b6_floats(64, 32) + 16 + SCORER_CONSTS) * sizeof(float);
-      if (int rc = set_lds(h, k_inc_score<1, true>, lds)) return rc;
-      hipLaunchKernelGGL((k_inc_score<1, true>), grid, dim3(512), lds, st, rs, sw, ij, base + w.alpha, mask,
-                         base + w.score_part, n, C, g.cs, h->d_flag, 1);
+      // 17..32 pairs: one wave per site walks its two 16-pair tiles stage by stage (k_inc_score_wi<2>)
+      const size_t lds = (size_t)(3 * IMG64 + 8 * (64 * 32 * NPL / 2) + SCORER_CONSTS + 2 * 1024) * sizeof(float);
+      if (int rc = set_lds(h, (k_inc_score_wi<2>), lds)) return rc;
+      hipLaunchKernelGGL((k_inc_score_wi<2>), grid, dim3(512), lds, st, rs, sw, ij, base + w.alpha, mask,
+                         base + w.score_part, n, C, g.cs, 1);
     }
   }
   return NNJ_OK;
@@ -2262,7 +2180,7 @@ int lik_common(nnj_handle* h, const uint8_t* codes, int nA, const uint8_t* mask,
   base = static_cast<double*>(ws);
   int* prog = reinterpret_cast<int*>(base + w.prog);
   hipLaunchKernelGGL(k_lik_program, dim3((unsigned)B), dim3(256), 0, st, merges, prog,
-                     reinterpret_cast<int*>(base + w.colour), B, T);
+                     reinterpret_cast<int*>(base + w.colour), B, T, h->d_flag);
   const int ne = B * (T - 1) * 2;
   hipLaunchKernelGGL(k_lik_brlen_init, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, st, (const int*)prog, brlen_in, 0.1,
                      base + w.brlen, B, T);

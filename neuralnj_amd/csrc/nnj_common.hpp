@@ -28,6 +28,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define NNJ_FLAG_NONFINITE 1          // a pair-score table held a non-finite score
 #define NNJ_FLAG_BARRIER_TIMEOUT 2    // an LDS-counter barrier between partner waves gave up waiting
 #define NNJ_FLAG_MERGE_WEIGHTS 4      // two-pass step: a merge's attention weights had no source and no fallback was launched
+#define NNJ_FLAG_BAD_MERGE 8          // tree likelihood: a caller's merge list held a pair with i >= j or a position outside the live list
 
 // compile-time loop: f(std::integral_constant<int, I>) for I in [0, N)
 template <int I, int N, typename F>
@@ -341,11 +342,8 @@ __device__ __forceinline__ f32x16 mfma_f16(u32x4 a, u32x4 b, f32x16 c) {
                                                  0, 0, 0);
 }
 // c += A*B from the three leading piece products (m.h, h.m, h.h), smallest first
-// (-DNNJ_MM4: a diagnostic build that adds the fourth piece product m.m -- tools/noise_ab.py, DESIGN.md parity section)
+// (a fourth piece product m.m was measured in round 4 -- profiles/r04/noise_variants.txt, mm4_cost.txt: -11 % trees/s, no systematic gain)
 __device__ __forceinline__ f32x16 mfma_b6(const Frag3& a, const Frag3& b, f32x16 c) {
-#ifdef NNJ_MM4
-  c = mfma_f16(a.m, b.m, c);
-#endif
   c = mfma_f16(a.m, b.h, c);
   c = mfma_f16(a.h, b.m, c);
   c = mfma_f16(a.h, b.h, c);
@@ -598,9 +596,6 @@ __device__ __forceinline__ f32x4 mfma16_f16(u32x4 a, u32x4 b, f32x4 c) {
                                                  0);
 }
 __device__ __forceinline__ f32x4 mfma16_b6(const Frag3& a, const Frag3& b, f32x4 c) {
-#ifdef NNJ_MM4
-  c = mfma16_f16(a.m, b.m, c);
-#endif
   c = mfma16_f16(a.m, b.h, c);
   c = mfma16_f16(a.h, b.m, c);
   c = mfma16_f16(a.h, b.h, c);
@@ -743,10 +738,6 @@ __device__ __forceinline__ void linear_t16p_multi(V64 (&out)[NT], Frag3 (&bfr)[N
     if constexpr (mt == 0) pre(std::integral_constant<int, ks>{});     // the caller forms the B fragments of k-step ks (pure vector work)
     lds_wait_le<2 * ahead>();
     pin_frag(a[s % PF]);
-#ifdef NNJ_MM4
-#pragma unroll
-    for (int t = 0; t < NT; ++t) out[t].t[mt] = mfma16_f16(a[s % PF].m, bfr[t][ks].m, out[t].t[mt]);
-#endif
 #pragma unroll
     for (int t = 0; t < NT; ++t) out[t].t[mt] = mfma16_f16(a[s % PF].m, bfr[t][ks].h, out[t].t[mt]);
 #pragma unroll

@@ -132,18 +132,6 @@ __device__ __forceinline__ void pair_barrier(int* cnt, int& epoch, int* flag) {
   asm volatile("" ::: "memory");
 }
 
-// -DNNJ_KO_TOK=n: knock-out builds for TIMING ONLY (results wrong; tools/ko_build.sh, profiles/r04/ko_tok1p.txt):
-// 1 = no LayerNorm, 2 = no q/k/v projections, 3 = no QK^T products, 4 = no softmax (max / exp / sum), 5 = no P.V
-// products, 6 = no output projections (row and column), 7 = no fp16 split of the probabilities
-#ifndef NNJ_KO_TOK
-#define NNJ_KO_TOK 0
-#endif
-template <typename T_>
-__device__ __forceinline__ void ko_keep(T_& x) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  asm volatile("" : "+v"(x));
-#endif
-}
 // SK (NWC <= 2): the last eight keys of the last 32-key tile are beyond the rows for EVERY lane (R <= 32 NWC - 8, e.g. the
 // 50 rows of the bench: keys 56..63) -- their maximum / exponential / sum / split instructions are compiled out (round 4:
 // the knock-outs of profiles/r04/ko_tok1p.txt put the softmax at 6.2 of the kernel's 34.8 ms; an eighth of it was padding)
@@ -236,8 +224,7 @@ __global__ __launch_bounds__(512) void k_tok1p(const float* __restrict__ ctx, co
       f32x16 cx[1][2], o[1][2];
       xr[0][0] = xn[0]; xr[0][1] = xn[1];
       cx[0][0] = cn[0]; cx[0][1] = cn[1];
-      if constexpr (NNJ_KO_TOK == 6) { o[0][0] = cx[0][0]; o[0][1] = cx[0][1]; }
-      else linear6_T<2, 2, 1, true>(o, cx, W0, ct, lane);
+      linear6_T<2, 2, 1, true>(o, cx, W0, ct, lane);
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt) xr[0][mt] += o[0][mt];
     }
@@ -256,8 +243,7 @@ __global__ __launch_bounds__(512) void k_tok1p(const float* __restrict__ ctx, co
       f32x16 qh, kh, vT;
       {
         f32x16 y[2];
-        if constexpr (NNJ_KO_TOK == 1) { y[0] = xr[0][0]; y[1] = xr[0][1]; }
-        else layer_norm64(y, xr[0], ct + 64, ct + 128, hh, wc.dt);
+        layer_norm64(y, xr[0], ct + 64, ct + 128, hh, wc.dt);
         const float bvl = ct[320 + 32 * hf + tok];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -277,8 +263,7 @@ __global__ __launch_bounds__(512) void k_tok1p(const float* __restrict__ ctx, co
             const int o = wrow * 8 + wswz6<8>(wrow, 2 * ks + hh);
             Frag3 afr;
             afr.h = img[o]; afr.m = img[96 * 8 + o];
-            if constexpr (NNJ_KO_TOK == 2) { ko_keep(afr.h); ko_keep(bfr.h); }
-            else if constexpr (mt == 0) qh = mfma_b6(afr, bfr, qh);
+            if constexpr (mt == 0) qh = mfma_b6(afr, bfr, qh);
             else if constexpr (mt == 1) kh = mfma_b6(afr, bfr, kh);
             else vT = mfma_b6(bfr, afr, vT);
           });
@@ -331,17 +316,13 @@ __global__ __launch_bounds__(512) void k_tok1p(const float* __restrict__ ctx, co
           kf.m = (u32x4){am.x, am.y, 0u, 0u};
 #pragma unroll
           for (int k = 0; k < 16; ++k) sc_[jt][k] = 0.f;
-          if constexpr (NNJ_KO_TOK == 3) { ko_keep(kf.h); ko_keep(qf.h); ko_keep(sc_[jt]); }
-          else sc_[jt] = mfma_b6(kf, qf, sc_[jt]);
+          sc_[jt] = mfma_b6(kf, qf, sc_[jt]);
         }
         // element k of tile jt is key j = 32*jt + (k&3) + 8*(k>>2) + 4*hh.  A padded column gets the same score
         // for every key (axial_attention.py:220-224: -10000 everywhere): its q is scaled by 0 instead, the
         // softmax of equal scores is the same.  Keys beyond the rows exist only in the second tile (R > 32).
         float m = -INFINITY;
         float l = 0.f;
-        if constexpr (NNJ_KO_TOK == 4) {
-          l = 1.0f;
-        } else {
 #pragma unroll
         for (int jt = 0; jt < NWC; ++jt)
 #pragma unroll
@@ -363,7 +344,6 @@ __global__ __launch_bounds__(512) void k_tok1p(const float* __restrict__ ctx, co
             l += p;
           }
         l += __shfl_xor(l, 32);
-        }
         // O^T[(head, d) x query] = V^T P^T on the fp16 pipe: the probability registers 8u..8u+7 of tile jt are the B
         // operand of k-step 2jt + u as they stand; A = the whole V^T image (all four heads of the half: only the
         // rows of head g mean anything against P_g, i.e. registers 4g..4g+3 of the product -- d = 4hh + t)
@@ -373,11 +353,7 @@ __global__ __launch_bounds__(512) void k_tok1p(const float* __restrict__ ctx, co
         static_for<0, 2 * NWC>([&](auto si) {
           constexpr int ks = decltype(si)::value;
           Frag3 pf, vf;
-          if constexpr (NNJ_KO_TOK == 7) {
-            pf.h = (u32x4){__builtin_bit_cast(unsigned, sc_[ks >> 1][8 * (ks & 1)]), __builtin_bit_cast(unsigned, sc_[ks >> 1][8 * (ks & 1) + 2]),
-                           __builtin_bit_cast(unsigned, sc_[ks >> 1][8 * (ks & 1) + 4]), __builtin_bit_cast(unsigned, sc_[ks >> 1][8 * (ks & 1) + 6])};
-            pf.m = pf.h;
-          } else if constexpr (SK && ks == 2 * NWC - 1) {
+          if constexpr (SK && ks == 2 * NWC - 1) {
             // the last k-step: probabilities 12..15 of the tile are exact zeros (keys beyond the rows): no split
             unsigned h, m_;
             split2(sc_[ks >> 1][8], sc_[ks >> 1][9], h, m_); pf.h[0] = h; pf.m[0] = m_;
@@ -389,8 +365,7 @@ __global__ __launch_bounds__(512) void k_tok1p(const float* __restrict__ ctx, co
           const uint8_t* src = vimg + tok * (16 * VCH) + 16 * wswz6<VCH>(tok, 2 * ks + hh);
           vf.h = *reinterpret_cast<const u32x4*>(src);
           vf.m = *reinterpret_cast<const u32x4*>(src + VPL);
-          if constexpr (NNJ_KO_TOK == 5) { ko_keep(vf.h); ko_keep(pf.h); ko_keep(pf.m); }
-          else o = mfma_b6(vf, pf, o);
+          o = mfma_b6(vf, pf, o);
         });
         const float inv = nnj_rcp(l);
 #pragma unroll
@@ -474,8 +449,7 @@ __global__ __launch_bounds__(512) void k_tok1p(const float* __restrict__ ctx, co
     }
     load_col(col + cstride < ncols ? col + cstride : col, xn, cn);      // (last column: harmless reload; unconditional, so
     f32x16 o[1][2];                                                      //  the old values are dead across the iteration)
-    if constexpr (NNJ_KO_TOK == 6) { o[0][0] = cx[0][0]; o[0][1] = cx[0][1]; }
-    else linear6_T<2, 2, 1, true>(o, cx, Wo_l, ct + 384, lane);
+    linear6_T<2, 2, 1, true>(o, cx, Wo_l, ct + 384, lane);
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) xr[0][mt] += o[0][mt];
     store_token64(xr[0], xp, valid, hh);

@@ -38,8 +38,11 @@ constexpr int LIK_MAXCAT = 8;
 // One WORKGROUP per tree (round 4; it was one thread with a 256-entry private list in scratch memory: 658 us per call
 // at 200 taxa -- a seventh of a Search round's model optimisation, which calls it for every trial value): the position
 // list lives in LDS and "position j leaves the list" (environment.py:764-768) is a parallel shift.
+// A malformed merge (i >= j, or a position outside the live list) is REPORTED: it sets NNJ_FLAG_BAD_MERGE in the handle's
+// sticky status word (nnj_numeric_status); the program is still built (positions clamped, position i wins) so that the
+// launch sequence stays defined, but its likelihoods must be discarded.
 __global__ __launch_bounds__(256) void k_lik_program(const int* __restrict__ merges, int* __restrict__ prog,
-                                                     int* __restrict__ colour, int B, int T) {
+                                                     int* __restrict__ colour, int B, int T, int* __restrict__ flag) {
   __shared__ int ids[256];
   __shared__ int pl[512];                                  // the tree's child ids per join (for the colour pass)
   __shared__ int cl[512];
@@ -52,9 +55,10 @@ __global__ __launch_bounds__(256) void k_lik_program(const int* __restrict__ mer
   int n = T;
   for (int s = 0; s < T - 1; ++s, --n) {
     const int i = min(max(m[2 * s], 0), n - 1), j = min(max(m[2 * s + 1], 0), n - 1);
+    if (tid == 0 && (m[2 * s] != i || m[2 * s + 1] != j || i >= j)) atomicOr(flag, NNJ_FLAG_BAD_MERGE);
     if (tid == 0) { pl[2 * s] = ids[i]; pl[2 * s + 1] = ids[j]; }
     int v = (tid >= j && tid < n - 1) ? ids[tid + 1] : ids[tid];
-    if (tid == i) v = T + s;                                // (a merge with i >= j is malformed; as before, position i wins)
+    if (tid == i) v = T + s;                                // (a malformed merge, i >= j: position i wins, and the flag is set)
     __syncthreads();
     ids[tid] = v;
     __syncthreads();

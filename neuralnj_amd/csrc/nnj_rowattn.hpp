@@ -36,7 +36,6 @@ struct Ra6 {
   int ET;          // 32-row tiles of the head dimension in V6 (= nech * ETc)
   int ETc;         // ... per e-chunk of k_row_pv (bucketed, <= 16: its context accumulators)
   int nech;        // e-chunks: k_row_pv workgroups per query block (1 up to 64 rows; 100 rows: 2 x 13 tiles; 200: 4 x 13)
-  int halves;      // 1 = k_row_pv2: eight waves per workgroup, two halves of ETc / 2 tiles
   int nrb;         // Cp / 256
   int nt32;        // Cp / 32
   int nk16;        // Cp / 16
@@ -58,25 +57,18 @@ inline Ra6 ra6_geom(int T, int C, int Epad, int B) {
   static const int buckets[] = {1, 2, 4, 6, 7, 8, 10, 13, 16};
   const int need = (16 * g.KS + 31) / 32;
   g.nech = (need + 15) / 16;
-  static const bool small_cut = !(getenv("NNJ_PV_CUT") && atoi(getenv("NNJ_PV_CUT")) == 0);
-  if (small_cut) {
+  {
     const long wgs = (long)B * 8 * (g.Cp / 128);
     while (g.nech < 4 && wgs * g.nech < 256 && need >= 4 * g.nech) g.nech *= 2;
   }
   // 33..64 rows (9..16 head tiles): TWO e-chunks at every batch -- two workgroups of <= 8 accumulator tiles per CU, i.e. two
   // waves per SIMD, instead of one of 13 (50 rows: 7 + 7 tiles; twice the V6 DMA and the exponentials, 8 % padding, and
-  // still 35.5 -> 34.1 ms per rollout: one wave's DMA issue and barrier waits sit under the other workgroup's MFMAs).
-  // NNJ_PV_NECH=1: one chunk as before.
-  static const int min_nech = getenv("NNJ_PV_NECH") ? atoi(getenv("NNJ_PV_NECH")) : 2;
-  if (g.nech < min_nech && need >= 9 && need <= 16) g.nech = min_nech;
+  // still 35.5 -> 34.1 ms per rollout: one wave's DMA issue and barrier waits sit under the other workgroup's MFMAs;
+  // the same two halves inside ONE eight-wave workgroup were slower, 38.5: profiles/r04/ab_row_pv_chunks.txt).
+  if (g.nech < 2 && need >= 9 && need <= 16) g.nech = 2;
   const int per = (need + g.nech - 1) / g.nech;
   g.ETc = 16;
   for (int k : buckets) if (per <= k) { g.ETc = k; break; }
-  // NNJ_PV_HALVES=1 (with NNJ_PV_NECH=1): the two halves inside ONE workgroup of eight waves (k_row_pv2; one V6 DMA for
-  // both) -- measured SLOWER than one chunk (38.5 vs 35.8 ms per rollout: the eight-wave barrier couples the halves)
-  static const bool pv_halves = getenv("NNJ_PV_HALVES") && atoi(getenv("NNJ_PV_HALVES")) != 0;
-  g.halves = 0;
-  if (pv_halves && g.nech == 1 && need >= 9 && need <= 16) { g.halves = 1; g.ETc = 2 * ((need + 1) / 2); }
   g.ET = g.nech * g.ETc;
   g.nrb = g.Cp / 256; g.nt32 = g.Cp / 32; g.nk16 = g.Cp / 16;
   g.qk_bh = (size_t)g.KS * g.nrb * NPL * 8192;
@@ -237,16 +229,13 @@ struct RsShape {
 // accumulated CHK at a time into a zeroed accumulator and the chunk sums are added to the total by the vector
 // unit: the many roundings happen on small partial sums, only KS/CHK on the large one (same error as the
 // reference's order).  The second accumulator set is paid for by the narrower wave tile (128 keys x 32 queries).
-#ifndef NNJ_RS_COMP
-#define NNJ_RS_COMP 0
-#endif
 #ifndef NNJ_RS_CHK
 #define NNJ_RS_CHK 8
 #endif
-// RS (round 4): the operand tiles are staged through registers instead of by LDS-DMA (see k_row_pv): tile ks+2 is loaded
-// (global_load_dwordx4, a few issue cycles) behind the first MFMA groups of k-step ks, written to its ring stage
-// (ds_write_b128) behind the later groups of k-step ks+1, read in k-step ks+2.
-template <int QW, int CHK = 0, bool RS = false>
+// (Register staging of the operand tiles instead of LDS-DMA, an error-free fold of the chunk sums and one fused kernel for
+// scores and context were built and measured in round 4 -- profiles/r04/ab_rowattn_regstage.txt, noise_variants.txt,
+// ab_rowfused_*.txt; none faster / closer: the sources are in the git history and tools/experiments/.)
+template <int QW, int CHK = 0>
 __global__ __launch_bounds__(256, 2) void k_row_s(const uint8_t* __restrict__ Q6, const uint8_t* __restrict__ K6,
                                                              const uint8_t* __restrict__ cls, float* __restrict__ S,
                                                              float* __restrict__ M, Ra6 g, int nbh, float fill, float qs) {
@@ -289,27 +278,6 @@ __global__ __launch_bounds__(256, 2) void k_row_s(const uint8_t* __restrict__ Q6
   auto issue = [&](int ks, int stage) {
     static_for<0, NP>([&](auto pi) { issue_piece(pi, ks, stage); });
   };
-  u32x4 R[RS ? 2 : 1][RS ? NP : 1];                        // register staging: piece i of tile t -> R[t & 1][i]
-  auto stage_load = [&](auto pi, auto parc, int ks) {
-    constexpr int i = decltype(pi)::value, par = decltype(parc)::value;
-    const int kk = ks < KS ? ks : KS - 1;
-    const int I = wave * NP + i;
-    const uint8_t* src;
-    if (I < NPK) {
-      src = Kt + I * 1024;
-    } else {
-      const int J = I - NPK, pl = J / (QW / 32), pc = J % (QW / 32);
-      src = Qt + (size_t)pl * 8192 + pc * 1024;
-    }
-    const u32x4 v = *reinterpret_cast<const u32x4*>(src + (size_t)kk * ks_stride + lane * 16);
-    if constexpr (RS) R[par][i] = v;
-  };
-  auto stage_store = [&](auto pi, auto parc, int stage) {
-    constexpr int i = decltype(pi)::value, par = decltype(parc)::value;
-    const int I = wave * NP + i;
-    if constexpr (RS)
-      *reinterpret_cast<u32x4*>(reinterpret_cast<uint8_t*>(smem) + stage * STAGE + I * 1024 + lane * 16) = R[par][i];
-  };
   const unsigned half = 16u * (unsigned)(HH ^ ((l31 >> 3) & 1));
   const unsigned aA = lds_addr(smem) + (unsigned)(kh * 128 + l31) * 32u + half;
   const unsigned aB = lds_addr(smem) + KTB + (unsigned)(qh * 32 * NJ + l31) * 32u + half;
@@ -321,20 +289,13 @@ __global__ __launch_bounds__(256, 2) void k_row_s(const uint8_t* __restrict__ Q6
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   f32x16 tot[CHK > 0 ? 4 : 1][CHK > 0 ? NJ : 1];          // chunk sums are folded into this (CHK > 0)
-  // COMP: the fold is an error-free addition (Knuth's two-sum): what the fp32 sum of total and chunk loses goes to a
-  // second word that is added once at the end -- the roundings at the magnitude of the whole logit are gone too
-  constexpr bool COMP = CHK > 0 && NNJ_RS_COMP != 0;
-  f32x16 lo[COMP ? 4 : 1][COMP ? NJ : 1];
   if constexpr (CHK > 0) {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int j = 0; j < NJ; ++j)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          tot[i][j][r] = 0.f;
-          if constexpr (COMP) lo[i][j][r] = 0.f;
-        }
+        for (int r = 0; r < 16; ++r) tot[i][j][r] = 0.f;
   }
   Frag3 A[4], Bf[2];
   auto readA = [&](unsigned base) {
@@ -349,19 +310,11 @@ __global__ __launch_bounds__(256, 2) void k_row_s(const uint8_t* __restrict__ Q6
     lds_read_frag<j * 1024>(bfr.h, base);
     lds_read_frag<j * 1024 + QPL>(bfr.m, base);
   };
-  if constexpr (RS) {
-    static_for<0, NP>([&](auto pi) { stage_load(pi, std::integral_constant<int, 0>{}, 0); });
-    static_for<0, NP>([&](auto pi) { stage_load(pi, std::integral_constant<int, 1>{}, 1); });
-    static_for<0, NP>([&](auto pi) { stage_store(pi, std::integral_constant<int, 0>{}, 0); });
-  } else {
-    issue(0, 0);
-    if constexpr (NST == 3) issue(1, 1);
-  }
-  auto kstep = [&](int ks, auto parc) {
-    constexpr int PAR = decltype(parc)::value;               // ks & 1 (compile time: it picks the staging registers)
+  issue(0, 0);
+  if constexpr (NST == 3) issue(1, 1);
+  auto kstep = [&](int ks) {
     const unsigned so = (unsigned)(ks % NST) * STAGE;
-    if constexpr (RS) lds_wait_all();        // this wave's stores of tile ks (written during k-step ks-1) are in LDS
-    else if constexpr (NST == 3) wait_vmem_le<NP>(); else wait_vmem_le<0>();   // tile ks has landed
+    if constexpr (NST == 3) wait_vmem_le<NP>(); else wait_vmem_le<0>();   // tile ks has landed
     barrier_nofence();                       // ... for every wave; every wave is done with tile ks-1
     const int st2 = (ks + NST - 1) % NST;    // the stage of tile ks-1 takes tile ks+NST-1
     readA(aA + so);
@@ -382,15 +335,7 @@ __global__ __launch_bounds__(256, 2) void k_row_s(const uint8_t* __restrict__ Q6
         constexpr int grp = 4 * j + i, per = (NP + 4 * NJ - 2) / (4 * NJ - 1);
         static_for<0, per>([&](auto ee) {
           constexpr int piece = grp * per + decltype(ee)::value;
-          if constexpr (RS) {
-            // loads of tile ks+2 behind the first groups, stores of tile ks+1 (loaded a k-step ago) behind the last ones
-            if constexpr (piece < NP) stage_load(std::integral_constant<int, piece>{}, parc, ks + 2);
-            constexpr int sp = piece - (4 * NJ * per - NP);
-            if constexpr (sp >= 0 && sp < NP)
-              stage_store(std::integral_constant<int, sp>{}, std::integral_constant<int, PAR ^ 1>{}, (ks + 1) % NST);
-          } else {
-            if constexpr (piece < NP) issue_piece(std::integral_constant<int, piece>{}, ks + NST - 1, st2);
-          }
+          if constexpr (piece < NP) issue_piece(std::integral_constant<int, piece>{}, ks + NST - 1, st2);
         });
       });
     });
@@ -400,18 +345,7 @@ __global__ __launch_bounds__(256, 2) void k_row_s(const uint8_t* __restrict__ Q6
         for (int i = 0; i < 4; ++i)
 #pragma unroll
           for (int j = 0; j < NJ; ++j) {
-            if constexpr (COMP) {
-#pragma unroll
-              for (int r = 0; r < 16; ++r) {
-                const float a = tot[i][j][r], c = acc[i][j][r];
-                const float s_ = a + c;
-                const float bb = s_ - a;
-                lo[i][j][r] += (a - (s_ - bb)) + (c - bb);
-                tot[i][j][r] = s_;
-              }
-            } else {
-              tot[i][j] += acc[i][j];
-            }
+            tot[i][j] += acc[i][j];
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
           }
@@ -419,18 +353,15 @@ __global__ __launch_bounds__(256, 2) void k_row_s(const uint8_t* __restrict__ Q6
     }
   };
   for (int ks = 0; ks + 1 < KS; ks += 2) {
-    kstep(ks, std::integral_constant<int, 0>{});
-    kstep(ks + 1, std::integral_constant<int, 1>{});
+    kstep(ks);
+    kstep(ks + 1);
   }
-  if (KS & 1) kstep(KS - 1, std::integral_constant<int, 0>{});
+  if (KS & 1) kstep(KS - 1);
   if constexpr (CHK > 0) {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int j = 0; j < NJ; ++j) {
-        acc[i][j] = tot[i][j];
-        if constexpr (COMP) acc[i][j] += lo[i][j];
-      }
+      for (int j = 0; j < NJ; ++j) acc[i][j] = tot[i][j];
   }
   wait_vmem_le<0>();                         // nothing of the ring may still be landing when the workgroup ends
   // ---- epilogue: key classes, tile maxima, register images
@@ -486,13 +417,7 @@ __global__ __launch_bounds__(256, 2) void k_row_s(const uint8_t* __restrict__ Q6
 // one workgroup per (query block, chunk) -- each recomputes the probabilities (the exponentials are cheap next to
 // the ET x 3 MFMAs per 16 keys) and owns its slice of the context rows; the chunks of a query block sit on
 // consecutive workgroup slots of one XCD, so the score images they share are served by its L2.
-// RS (round 4): the V6 tiles are staged THROUGH REGISTERS instead of by LDS-DMA (cdna_hip_programming.md T14: issue
-// early, write late).  At one wave per SIMD an LDS-DMA instruction holds the wave for 60-185 cycles (MI355X_MICROARCH.md,
-// row "LDS-DMA piece issue cost"), seven per wave and 16 keys -- round 2's knock-out put a quarter of the kernel there.
-// A global_load_dwordx4 issues in a few cycles; the tile of k-step k+2 is loaded into registers during k-step k and
-// written to its ring stage (ds_write_b128, same linear image) during k+1, the tile of k+3 loaded during k+1 and written
-// at its end, in front of the barrier that opens k+2 (four-stage ring, one barrier per two k-steps, as before).
-template <int ET, bool RS = false>
+template <int ET>
 __global__ __launch_bounds__(256) void k_row_pv(const uint8_t* __restrict__ V6, const float* __restrict__ S,
                                                 const float* __restrict__ M, float* __restrict__ ctx, Ra6 g,
                                                 int nbh) {
@@ -524,20 +449,6 @@ __global__ __launch_bounds__(256) void k_row_pv(const uint8_t* __restrict__ V6, 
   auto issue = [&](int k, int stage) {
     static_for<0, NIW>([&](auto pi) { issue_piece(pi, k, stage); });
   };
-  // register staging (RS): piece i of tile k -> R[k & 1][i]; stage_store writes a loaded tile into its ring stage
-  u32x4 R[RS ? 2 : 1][RS ? NIW : 1];
-  auto stage_load = [&](auto pi, auto par, int k) {
-    constexpr int i = decltype(pi)::value, P = decltype(par)::value;
-    const int kk = k < nk16 ? k : nk16 - 1;
-    const unsigned I = (unsigned)(wave * NIW + i);
-    const size_t so = I * 1024u < TILE ? (size_t)(I / ET) * plane_g + (size_t)(I % ET) * 1024u : 0u;
-    R[RS ? P : 0][RS ? i : 0] = *reinterpret_cast<const u32x4*>(Vt + (size_t)kk * tile_g + so + lane * 16);
-  };
-  auto stage_store = [&](auto pi, auto par, int stage) {
-    constexpr int i = decltype(pi)::value, P = decltype(par)::value;
-    const unsigned I = (unsigned)(wave * NIW + i);
-    *reinterpret_cast<u32x4*>(reinterpret_cast<uint8_t*>(smem) + stage * STG + I * 1024u + lane * 16) = R[RS ? P : 0][RS ? i : 0];
-  };
   const float* Sq = S + (size_t)bh * g.s_bh + (size_t)qt * g.nt32 * 1024 + lane * 4;
   const float* Mq = M + (size_t)bh * g.m_bh + (size_t)qt * g.nt32 * 32 + l31;
   float m = -INFINITY;
@@ -557,18 +468,9 @@ __global__ __launch_bounds__(256) void k_row_pv(const uint8_t* __restrict__ V6, 
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
   float lsum = 0.f;
   f32x16 s_cur, s_nxt;
-  if constexpr (RS) {
-    static_assert(NST == 4, "register staging is written for the four-stage ring");
-    static_for<0, NIW>([&](auto pi) { stage_load(pi, std::integral_constant<int, 0>{}, 0); });
-    static_for<0, NIW>([&](auto pi) { stage_load(pi, std::integral_constant<int, 1>{}, 1); });
-    loadS(s_cur, 0);
-    static_for<0, NIW>([&](auto pi) { stage_store(pi, std::integral_constant<int, 0>{}, 0); });
-    static_for<0, NIW>([&](auto pi) { stage_store(pi, std::integral_constant<int, 1>{}, 1); });
-  } else {
-    issue(0, 0);
-    loadS(s_cur, 0);
-    issue(1, 1);
-  }
+  issue(0, 0);
+  loadS(s_cur, 0);
+  issue(1, 1);
   s_nxt = s_cur;
   const unsigned aA = lds_addr(smem) + (unsigned)l31 * 32u + 16u * (unsigned)(HH ^ ((l31 >> 3) & 1));
   Frag3 bfr[2];
@@ -580,8 +482,7 @@ __global__ __launch_bounds__(256) void k_row_pv(const uint8_t* __restrict__ V6, 
       // this wave has in flight), the barrier makes that true for every wave and tells that tiles k-2, k-1 are
       // read: their stages take tiles k+2 (issued during k) and k+3 (during k+1).
       if constexpr (P == 0) {
-        if constexpr (RS) lds_wait_all();         // this wave's stage stores of tiles k, k+1 (and everything else of it in LDS)
-        else wait_vmem_le<0>();
+        wait_vmem_le<0>();
         barrier_nofence();
       }
     } else {
@@ -621,21 +522,8 @@ __global__ __launch_bounds__(256) void k_row_pv(const uint8_t* __restrict__ V6, 
       pin_frag(a[t % 3]);
       if constexpr (t + 2 < ET) rd(std::integral_constant<int, t + 2>{});
       acc[t] = mfma_b6(a[t % 3], bf, acc[t]);
-      if constexpr (RS) {
-        // loads of tile k+2 behind the first MFMA groups; at odd k the tile loaded during k-1 (R[0], tile k+1 ... of the
-        // NEXT pair: k+1 is odd, so that is tile (k-1)+2) goes to its stage behind the later groups -- its loads have had
-        // a whole k-step to land (the compiler's own vmcnt wait in front of the store names exactly them)
-        if constexpr (t < NIW) stage_load(std::integral_constant<int, t>{}, par, k + 2);
-        if constexpr (P == 1 && t >= ET - NIW && t < ET)
-          stage_store(std::integral_constant<int, t - (ET - NIW)>{}, std::integral_constant<int, 0>{}, (k + 1) % NST);
-      } else {
-        if constexpr (t < NIW) issue_piece(std::integral_constant<int, t>{}, k + 2, st2);
-      }
+      if constexpr (t < NIW) issue_piece(std::integral_constant<int, t>{}, k + 2, st2);
     });
-    if constexpr (RS && P == 1) {
-      // the tile loaded during this k-step (k+2, odd) goes to its stage now, in front of the barrier of the next step
-      static_for<0, NIW>([&](auto pi) { stage_store(pi, std::integral_constant<int, 1>{}, (k + 2) % NST); });
-    }
     if constexpr (P == 1) s_cur = s_nxt;
   };
   for (int k = 0; k < nk16; k += 2) {          // nk16 is even (Cp is a multiple of 256)
@@ -655,132 +543,6 @@ __global__ __launch_bounds__(256) void k_row_pv(const uint8_t* __restrict__ V6, 
 #pragma unroll
       for (int gq = 0; gq < 4; ++gq) {
         const int e = 32 * (ech * ET + t) + 8 * gq + 4 * HH;
-        if (e < E)
-          *reinterpret_cast<f32x4*>(dst + e) = (f32x4){acc[t][4 * gq] * inv, acc[t][4 * gq + 1] * inv,
-                                                       acc[t][4 * gq + 2] * inv, acc[t][4 * gq + 3] * inv};
-      }
-  }
-}
-
-// ------------------------------------------------------------------ k_row_pv2 (round 4, late)
-// k_row_pv with EIGHT waves per workgroup: waves w and w + 4 share the 32 queries of query tile w and own one HALF of the
-// head dimension each (ET accumulator tiles: 7 + 7 for the 13 tiles of 50 rows) -- 112 accumulators per wave instead of
-// 208, two waves per SIMD, so one wave's LDS-DMA issue and barrier waits sit under the other's MFMAs.  The V6 tile of a
-// k-step (2 ET tiles, both planes) is fetched ONCE per workgroup as before; both waves of a query tile compute its
-// probabilities (the exponentials are cheap next to ET x 3 MFMAs per 16 keys).  Same products in the same order per
-// output element: bit-identical to k_row_pv.  (Two e-chunk WORKGROUPS per query block, NNJ_PV_NECH=2, measured 35.5 ->
-// 34.1 ms per rollout with twice the DMA traffic.)
-template <int ET>
-__global__ __launch_bounds__(512) void k_row_pv2(const uint8_t* __restrict__ V6, const float* __restrict__ S,
-                                                 const float* __restrict__ M, float* __restrict__ ctx, Ra6 g,
-                                                 int nbh) {
-  constexpr int ETL = 2 * ET;                                         // tiles of the V6 tile in LDS
-  constexpr unsigned TILE = ETL * NPL * 1024u;
-  constexpr unsigned STG = (TILE + 8191u) / 8192u * 8192u;            // stage size: whole KiB per wave (8 waves)
-  constexpr int NIW = STG / 8192;                                     // DMA instructions per wave and tile
-  constexpr int NST = 4;
-  static_assert(4 * STG <= 163840, "four-stage ring");
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, HH = lane >> 5;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wq = wave & 3, eh = wave >> 2;
-  const int nqb = g.Cp / 128;
-  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-  const int bh = (slot / nqb) * 8 + xcd;
-  if (bh >= nbh) return;
-  const int qb = slot % nqb, qt = qb * 4 + wq;
-  const int nk16 = g.nk16;
-  const size_t tile_g = (size_t)g.ET * NPL * 1024u;
-  const size_t plane_g = (size_t)g.ET * 1024u;
-  const uint8_t* Vt = V6 + (size_t)bh * g.v_bh;
-  auto issue_piece = [&](auto pi, int k, int stage) {
-    constexpr int i = decltype(pi)::value;
-    const int kk = k < nk16 ? k : nk16 - 1;
-    const unsigned I = (unsigned)(wave * NIW + i);
-    const size_t so = I * 1024u < TILE ? (size_t)(I / ETL) * plane_g + (size_t)(I % ETL) * 1024u : 0u;
-    lds_dma16(reinterpret_cast<const float*>(Vt + (size_t)kk * tile_g + so + lane * 16),
-              reinterpret_cast<float*>(reinterpret_cast<uint8_t*>(smem) + stage * STG + I * 1024u));
-  };
-  auto issue = [&](int k, int stage) {
-    static_for<0, NIW>([&](auto pi) { issue_piece(pi, k, stage); });
-  };
-  const float* Sq = S + (size_t)bh * g.s_bh + (size_t)qt * g.nt32 * 1024 + lane * 4;
-  const float* Mq = M + (size_t)bh * g.m_bh + (size_t)qt * g.nt32 * 32 + l31;
-  float m = -INFINITY;
-  for (int kt = 0; kt < g.nt32; ++kt) m = fmaxf(m, Mq[(size_t)kt * 32]);
-  auto loadS = [&](f32x16& s, int kt) {
-    const float* p = Sq + (size_t)kt * 1024;
-#pragma unroll
-    for (int gq = 0; gq < 4; ++gq) {
-      const f32x4 v = *reinterpret_cast<const f32x4*>(p + 256 * gq);
-      s[4 * gq] = v[0]; s[4 * gq + 1] = v[1]; s[4 * gq + 2] = v[2]; s[4 * gq + 3] = v[3];
-    }
-  };
-  f32x16 acc[ET];
-#pragma unroll
-  for (int t = 0; t < ET; ++t)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-  float lsum = 0.f;
-  f32x16 s_cur, s_nxt;
-  issue(0, 0);
-  loadS(s_cur, 0);
-  issue(1, 1);
-  s_nxt = s_cur;
-  const unsigned aA = lds_addr(smem) + (unsigned)l31 * 32u + 16u * (unsigned)(HH ^ ((l31 >> 3) & 1)) + (unsigned)(eh * ET) * 1024u;
-  Frag3 bfr[2];
-  auto kstep = [&](int k, auto par) {
-    constexpr int P = decltype(par)::value;    // k & 1
-    // four-stage ring, one barrier per two k-steps (see k_row_pv)
-    if constexpr (P == 0) {
-      wait_vmem_le<0>();
-      barrier_nofence();
-      if ((k >> 1) + 1 < g.nt32) loadS(s_nxt, (k >> 1) + 1);
-    }
-    const int st2 = (k + 2) % NST;
-    if constexpr (P == 0) {
-      f32x16 p;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { p[r] = __builtin_amdgcn_exp2f(s_cur[r] - m); lsum += p[r]; }
-      split8<0>(bfr[0], p);
-      split8<8>(bfr[1], p);
-    }
-    const Frag3& bf = bfr[P];
-    const unsigned so = aA + (unsigned)(k % NST) * STG;
-    Frag3 a[3];
-    auto rd = [&](auto ti) {
-      constexpr int t = decltype(ti)::value;
-      lds_read_frag<t * 1024>(a[t % 3].h, so);
-      lds_read_frag<t * 1024 + ETL * 1024>(a[t % 3].m, so);
-    };
-    rd(std::integral_constant<int, 0>{});
-    if constexpr (ET > 1) rd(std::integral_constant<int, 1>{});
-    static_for<0, ET>([&](auto ti) {
-      constexpr int t = decltype(ti)::value;
-      if constexpr (t + 1 < ET) lds_wait_le<NPL>(); else lds_wait_all();
-      pin_frag(a[t % 3]);
-      if constexpr (t + 2 < ET) rd(std::integral_constant<int, t + 2>{});
-      acc[t] = mfma_b6(a[t % 3], bf, acc[t]);
-      if constexpr (t < NIW) issue_piece(std::integral_constant<int, t>{}, k + 2, st2);
-    });
-    if constexpr (P == 1) s_cur = s_nxt;
-  };
-  for (int k = 0; k < nk16; k += 2) {          // nk16 is even (Cp is a multiple of 256)
-    kstep(k, std::integral_constant<int, 0>{});
-    kstep(k + 1, std::integral_constant<int, 1>{});
-  }
-  wait_vmem_le<0>();
-  lsum += __shfl_xor(lsum, 32);
-  const float inv = nnj_rcp(lsum);
-  const int q = qt * 32 + l31;
-  if (q < g.C) {
-    float* dst = ctx + ((size_t)bh * g.C + q) * g.Epad;
-    const int E = 8 * g.T;
-#pragma unroll
-    for (int t = 0; t < ET; ++t)
-#pragma unroll
-      for (int gq = 0; gq < 4; ++gq) {
-        const int e = 32 * (eh * ET + t) + 8 * gq + 4 * HH;
         if (e < E)
           *reinterpret_cast<f32x4*>(dst + e) = (f32x4){acc[t][4 * gq] * inv, acc[t][4 * gq + 1] * inv,
                                                        acc[t][4 * gq + 2] * inv, acc[t][4 * gq + 3] * inv};

@@ -671,10 +671,6 @@ __global__ __launch_bounds__(64 * NW) void k_inc_score_wi(RowSet rs, ScorerW w, 
           const int o = d * CH + wsw(d, lc);
           Frag3 a;
           a.h = im4[o]; a.m = im4[PL4 + o];
-#ifdef NNJ_MM4
-#pragma unroll
-          for (int u = 0; u < N; ++u) xg[u].t[mt] = mfma16_f16(a.m, bfr[u].m, xg[u].t[mt]);
-#endif
 #pragma unroll
           for (int u = 0; u < N; ++u) xg[u].t[mt] = mfma16_f16(a.m, bfr[u].h, xg[u].t[mt]);
 #pragma unroll

@@ -291,10 +291,6 @@ __device__ __forceinline__ void xg_from_image_multi(V64 (&xg)[N], unsigned base,
     a.h = (u32x4){ah[s % PF][0][0], ah[s % PF][0][1], ah[s % PF][1][0], ah[s % PF][1][1]};
     a.m = (u32x4){am[s % PF][0][0], am[s % PF][0][1], am[s % PF][1][0], am[s % PF][1][1]};
     pin_frag(a);
-#ifdef NNJ_MM4
-#pragma unroll
-    for (int u = 0; u < N; ++u) xg[u].t[mt] = mfma16_f16(a.m, bfr[u][ks].m, xg[u].t[mt]);
-#endif
 #pragma unroll
     for (int u = 0; u < N; ++u) xg[u].t[mt] = mfma16_f16(a.m, bfr[u][ks].h, xg[u].t[mt]);
 #pragma unroll

@@ -626,10 +626,6 @@ __global__ __launch_bounds__(64 * NW) void k_step_alpha_w(RowSet rs, ScorerW w, 
           const int o = row * 8 + wswz6<8>(row, 4 * ks + kq);
           Frag3 a;
           a.h = im4[o]; a.m = im4[PL + o];
-#ifdef NNJ_MM4
-#pragma unroll
-          for (int t = 0; t < NT; ++t) acc[t][mt] = mfma16_f16(a.m, bp[t].m, acc[t][mt]);
-#endif
 #pragma unroll
           for (int t = 0; t < NT; ++t) acc[t][mt] = mfma16_f16(a.m, bp[t].h, acc[t][mt]);
 #pragma unroll

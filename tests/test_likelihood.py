@@ -96,6 +96,29 @@ def test_hip_loglik_matches_numpy_oracle():
 
 
 @pytest.mark.gpu
+def test_hip_malformed_merge_list_is_reported():
+    """merge lists reach nnj_tree_loglik from user buffers.  A pair with i >= j (or a position outside the live
+    list) used to yield a silently wrong program; now the kernel that reads the list sets NNJ_STATUS_BAD_MERGE and
+    check_numeric raises -- and a well-formed list afterwards is clean again (the flag is cleared by the read)."""
+    from neuralnj_amd import likelihood as lk, utils
+    from neuralnj_amd._lib import Nnj
+    rng = np.random.default_rng(3)
+    g = Nnj(utils.shipped_config(), "cuda:0")
+    T, L = 7, 30
+    codes = rng.integers(0, 4, size=(1, T, L)).astype(np.uint8)
+    good = _random_tree(T, rng)[None]
+    for bad_step, bad_pair in ((2, (3, 1)), (1, (2, 2)), (0, (0, T))):
+        bad = good.copy()
+        bad[0, bad_step] = bad_pair
+        lk.tree_loglik(g, codes, bad, None, lk.subst_model(**GTR))
+        with pytest.raises(ValueError, match="BAD_MERGE"):
+            g.check_numeric()
+    lk.tree_loglik(g, codes, good, None, lk.subst_model(**GTR))
+    g.check_numeric()
+    g.close()
+
+
+@pytest.mark.gpu
 def test_hip_branch_length_optimisation():
     """Data simulated down a known tree: the optimiser must (1) never lower the likelihood, (2) reach the value a
     generic scipy optimiser finds for the same tree, (3) recover branch lengths near the simulated ones, and

@@ -15,5 +15,5 @@ for rank in ranks:
     v = bench.verify_sample(g, cfgs, packed, codes, m, 50, 1024, k=K, threads=16)
     out[rank] = {k: v[k] for k in ("ok", "score_err_rel_vs_fp32_oracle", "score_err_rel_vs_fp64", "fp32_oracle_err_rel_vs_fp64",
                                    "elem_rel_err_vs_fp64_entries_over_1pct_of_scale", "elem_rel_err_vs_fp64_top5_of_each_table",
-                                   "merge_lists_identical_to_fp64_oracle", "trees")}
+                                   "merge_lists_identical_to_fp64_oracle", "trees", "worst_table")}
     print(rank, out[rank], flush=True)
