@@ -239,7 +239,7 @@ def test_seeded_random_inputs_vs_oracle(ctx_cache):
     cfgs = utils.shipped_config()
     packed = weights.pack(cfgs, weights.seeded_state(cfgs, 21, "sharp"))
     g = ctx_cache(cfgs, packed)
-    o = _oracle(cfgs, packed)
+    o, o64 = _oracle(cfgs, packed), _oracle_f64(cfgs, packed)
     # shapes chosen to hit every kernel variant: row counts <= 16, 17..32, 33..48, 49..64 (the incremental scorer
     # changes tile shape at those points), odd T (zero-padded k-step of the row attention), L = 4 (one 16-column
     # block, mostly padding), L not a multiple of 16 / 256, L > 1024 (five 256-row operand blocks)
@@ -256,7 +256,10 @@ def test_seeded_random_inputs_vs_oracle(ctx_cache):
             mask[:, L - 8:] = True
         free = g.rollout_argmax(torch.from_numpy(codes), torch.from_numpy(mask), want_trace=True)
         merges = free["merges"].cpu().numpy()
-        ref = o.rollout_argmax(synth.codes_to_onehot(codes).astype(np.float32), mask, forced_merges=merges)
+        # More than 64 rows: the HIP encoder runs in fp64 (round 5), so the checker must not be noisier than the code it
+        # checks -- under these stress weights the plain-fp32 oracle is itself up to 1.2e-4 from the fp64 evaluation at 256
+        # rows (that distance was 1e-4-class on BOTH sides before).  The fp64 build of the oracle is the reference there.
+        ref = (o64 if T > 64 else o).rollout_argmax(synth.codes_to_onehot(codes).astype(np.float32), mask, forced_merges=merges)
         assert_logits_close(free["logits"].cpu().numpy(), ref["logits"], RTOL, f"{B}x{T}x{L}")
         scale = np.abs(ref["logits"]).max()
         decisive = ref["top2_gap"] > 4 * RTOL * scale
@@ -273,7 +276,7 @@ def test_narrow_model_seeded_inputs_vs_oracle(ctx_cache):
     cfgs.model.embed_dim, cfgs.model.num_enc_heads, cfgs.model.num_enc_layers, cfgs.model.patch_size = 32, 4, 2, 2
     packed = weights.pack(cfgs, weights.seeded_state(cfgs, 23, "sharp"))
     g = ctx_cache(cfgs, packed)
-    o = _oracle(cfgs, packed)
+    o, o64 = _oracle(cfgs, packed), _oracle_f64(cfgs, packed)
     for (B, T, L, seed) in ((2, 9, 40, 1), (1, 33, 64, 2), (2, 50, 96, 3), (1, 70, 48, 4), (1, 130, 32, 5)):
         codes = synth.synth_codes_tree(B, T, L, 100 + seed)
         mask = np.zeros((B, L), bool)
@@ -284,7 +287,7 @@ def test_narrow_model_seeded_inputs_vs_oracle(ctx_cache):
         free = g.rollout_argmax(tc, tm, want_trace=True, want_state=True)
         assert free["state"].shape == (B, T, L // 2, 32)
         merges = free["merges"].cpu().numpy()
-        ref = o.rollout_argmax(synth.codes_to_onehot(codes).astype(np.float32), mask, forced_merges=merges)
+        ref = (o64 if T > 64 else o).rollout_argmax(synth.codes_to_onehot(codes).astype(np.float32), mask, forced_merges=merges)
         assert_logits_close(free["logits"].cpu().numpy(), ref["logits"], RTOL, f"narrow model {B}x{T}x{L}")
         scale = np.abs(ref["logits"]).max()
         decisive = ref["top2_gap"] > 4 * RTOL * scale
