@@ -105,6 +105,52 @@ __device__ __forceinline__ f32x2v gelu_erf2(f32x2v x) {
   const f32x2v q = __builtin_elementwise_fma(-(p * t), e, half);
   return __builtin_elementwise_fma(x, half, ax * q);
 }
+// Two sigmoids / gate mixes at a time with PACKED fp32 arithmetic (round 5).  The compiler packs the fused multiply-adds
+// of these chains by itself but leaves the `1 + 2^x` additions and the `a - b` differences scalar (k_inc_score_w<3>: 108
+// v_add_f32 + 96 v_sub_f32 per site next to 265 v_pk_fma_f32): as packed FMAs the loop body has 8 % fewer vector
+// instructions (1053 -> 967).  Same operations per element: bit-identical.  What it buys is small -- at two waves per SIMD a
+// scalar fp32 instruction already runs at the pipe's rate, a packed one saves issue slots only: incremental scores 49.2 ->
+// 48.3 ms per rollout; in the 32-pair kernels of step 0 (25 % fewer vector instructions in the gate block) nothing, so
+// those keep the scalar form (profiles/r05/ab_packed_gates.txt).
+// (a - b and e + 1 are written as fma(a, 1, -b) / fma(e, 1, 1): exactly the same values, and the packed FMA is the one form
+// the compiler keeps packed -- plain vector differences come out as two v_sub_f32 again)
+// The multiplier 1.0 is made opaque to the optimiser (no instruction; identical calls are merged and hoisted), as the -1.0 of
+// split2 is: otherwise fma(a, 1, -b) is folded back into a - b and scalarised.
+__device__ __forceinline__ f32x2v opaque_ones() {
+  float k = 1.0f;
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm("" : "+v"(k));
+#endif
+  return (f32x2v){k, k};
+}
+__device__ __forceinline__ f32x2v pk_sub(f32x2v a, f32x2v b) { return __builtin_elementwise_fma(a, opaque_ones(), -b); }
+__device__ __forceinline__ f32x2v sigmoid_l2x2(f32x2v xs) {
+  const f32x2v e = {__builtin_amdgcn_exp2f(xs[0]), __builtin_amdgcn_exp2f(xs[1])};
+  const f32x2v d = __builtin_elementwise_fma(e, opaque_ones(), (f32x2v){1.0f, 1.0f});
+  return (f32x2v){nnj_rcp(d[0]), nnj_rcp(d[1])};
+}
+// x += sigmoid(g) * (xg - x)  for four features (g = -log2(e) x the gate's pre-activation): (1-w) x + w x_g, model.py:150-153
+__device__ __forceinline__ void gate_mix4(f32x4& x, const f32x4& xg, const f32x4& g) {
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    const f32x2v w = sigmoid_l2x2((f32x2v){g[2 * p], g[2 * p + 1]});
+    const f32x2v xv = {x[2 * p], x[2 * p + 1]}, gv = {xg[2 * p], xg[2 * p + 1]};
+    const f32x2v r = __builtin_elementwise_fma(w, pk_sub(gv, xv), xv);
+    x[2 * p] = r[0]; x[2 * p + 1] = r[1];
+  }
+}
+// out = b + sigmoid(z) * (a - b) for four features: z x_i + (1-z) x_j, model.py:105-108
+__device__ __forceinline__ f32x4 gate_sel4(const f32x4& a, const f32x4& b, const f32x4& z) {
+  f32x4 o;
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    const f32x2v w = sigmoid_l2x2((f32x2v){z[2 * p], z[2 * p + 1]});
+    const f32x2v av = {a[2 * p], a[2 * p + 1]}, bv = {b[2 * p], b[2 * p + 1]};
+    const f32x2v r = __builtin_elementwise_fma(w, pk_sub(av, bv), bv);
+    o[2 * p] = r[0]; o[2 * p + 1] = r[1];
+  }
+  return o;
+}
 // s2 += gelu(x[0..3]) * w[0..3] (two-lane accumulator; the caller adds the lanes once per site)
 __device__ __forceinline__ void gelu_dot4(f32x2v& s2, const f32x4& x, const f32x4& w) {
   const f32x2v g0 = gelu_erf2((f32x2v){x[0], x[1]}), g1 = gelu_erf2((f32x2v){x[2], x[3]});
@@ -316,7 +362,8 @@ __device__ __forceinline__ void split2(float a, float b, unsigned& h, unsigned& 
   opaque(h);
   const f16x2 hv = __builtin_bit_cast(f16x2, h);
   if constexpr (!MIX) {
-    m = cvt_pk_f16(a - (float)hv[0], b - (float)hv[1]);
+    const f32x2v r = pk_sub((f32x2v){a, b}, (f32x2v){(float)hv[0], (float)hv[1]});      // exact either way
+    m = cvt_pk_f16(r[0], r[1]);
     return;
   }
   const float k = opaque_neg_one();

@@ -55,11 +55,7 @@ __device__ __forceinline__ void gate_init16(V64& ur, const V64& um, const float*
 __device__ __forceinline__ void gate16(V64& x, const V64& sr, const V64& ur, const V64& sm) {
 #pragma unroll
   for (int mt = 0; mt < 4; ++mt) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const float z = sigmoid_l2(ur.t[mt][e]);
-      x.t[mt][e] = sm.t[mt][e] + z * (sr.t[mt][e] - sm.t[mt][e]);
-    }
+    x.t[mt] = gate_sel4(sr.t[mt], sm.t[mt], ur.t[mt]);      // S_m + sigmoid(.) (S_r - S_m), two features per instruction
     __builtin_amdgcn_sched_barrier(0);
   }
 }
@@ -284,13 +280,10 @@ __global__ __launch_bounds__(64 * T16_WAVES) void k_inc_score16(RowSet rs, Score
       });
       linear_t16p<4, false, true, 2, false>(g.t, xg, Wg_l, cv + 64, lane);
 #pragma unroll
-      for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float wg = sigmoid_l2(g.t[mt][e]);
-          x.t[mt][e] += wg * (xg.t[mt][e] - x.t[mt][e]);          // (1-w)*x + w*x_g
-          if (e == 3) __builtin_amdgcn_sched_barrier(0);
-        }
+      for (int mt = 0; mt < 4; ++mt) {
+        gate_mix4(x.t[mt], xg.t[mt], g.t[mt]);          // (1-w)*x + w*x_g
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
     V64 s1;
     linear_t16p<4, false, true, 2, false>(s1.t, x, S0_l, cv + 128, lane);
@@ -488,12 +481,7 @@ __global__ __launch_bounds__(64 * NW) void k_inc_score_w(RowSet rs, ScorerW w, c
         }
         linear_t16p<4, false, true, WPF, false>(g.t, xg, Wg_l, cv + 64, lane);
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const float wg = sigmoid_l2(g.t[mt][e]);
-            x[t].t[mt][e] += wg * (xg.t[mt][e] - x[t].t[mt][e]);        // (1-w)*x + w*x_g
-          }
+        for (int mt = 0; mt < 4; ++mt) gate_mix4(x[t].t[mt], xg.t[mt], g.t[mt]);          // (1-w)*x + w*x_g
       }
       V64 s1;
       linear_t16p<4, false, true, WPF, false>(s1.t, x[t], S0_l, cv + 128, lane);
@@ -696,12 +684,7 @@ __global__ __launch_bounds__(64 * NW) void k_inc_score_wi(RowSet rs, ScorerW w, 
 #pragma unroll
         for (int u = 0; u < N; ++u)
 #pragma unroll
-          for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              const float wg = sigmoid_l2(g[u].t[mt][e]);
-              x[T0 + u].t[mt][e] += wg * (xg[u].t[mt][e] - x[T0 + u].t[mt][e]);
-            }
+          for (int mt = 0; mt < 4; ++mt) gate_mix4(x[T0 + u].t[mt], xg[u].t[mt], g[u].t[mt]);          // (1-w)*x + w*x_g
       }
       asm volatile("" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);

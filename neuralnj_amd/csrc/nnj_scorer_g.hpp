@@ -212,12 +212,7 @@ __global__ __launch_bounds__(64 * NW) void k_inc_score_g(RowSet rs, ScorerW w, c
       });
       linear_t16p<4, false, true, WPF, false>(gg.t, xg, Wg_l, cv + 64, lane);
 #pragma unroll
-      for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float wg = sigmoid_l2(gg.t[mt][e]);
-          x[t].t[mt][e] += wg * (xg.t[mt][e] - x[t].t[mt][e]);            // (1-w)*x + w*x_g
-        }
+      for (int mt = 0; mt < 4; ++mt) gate_mix4(x[t].t[mt], xg.t[mt], gg.t[mt]);          // (1-w)*x + w*x_g
       V64 s1;
       linear_t16p<4, false, true, WPF, false>(s1.t, x[t], S0_l, cv + 128, lane);
       f32x2v s2 = {0.f, 0.f};
@@ -440,12 +435,7 @@ __global__ __launch_bounds__(64 * NW) void k_inc_score_s5(RowSet rs, ScorerW w, 
 #pragma unroll
       for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const float wg = sigmoid_l2(g[t].t[mt][e]);
-            x[t].t[mt][e] += wg * (xg[t].t[mt][e] - x[t].t[mt][e]);
-          }
+        for (int mt = 0; mt < 4; ++mt) gate_mix4(x[t].t[mt], xg[t].t[mt], g[t].t[mt]);          // (1-w)*x + w*x_g
     }
     asm volatile("" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
@@ -549,12 +539,7 @@ __global__ __launch_bounds__(64 * NW) void k_inc_score_s5(RowSet rs, ScorerW w, 
         V64 gg;
         linear_t16p<4, false, true, WPF, false>(gg.t, xgS, Wg_l, cv + 64, lane);
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const float wg = sigmoid_l2(gg.t[mt][e]);
-            xS.t[mt][e] += wg * (xgS.t[mt][e] - xS.t[mt][e]);
-          }
+        for (int mt = 0; mt < 4; ++mt) gate_mix4(xS.t[mt], xgS.t[mt], gg.t[mt]);          // (1-w)*x + w*x_g
         V64 s1;
         linear_t16p<4, false, true, WPF, false>(s1.t, xS, S0_l, cv + 128, lane);
         f32x2v s2 = {0.f, 0.f};

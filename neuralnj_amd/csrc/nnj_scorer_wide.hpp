@@ -305,12 +305,7 @@ __global__ __launch_bounds__(512) void k_wide_score(RowSet rs, ScorerW w, const 
       }
       linear_t16<4, false>(g.t, xg, Wg_l, cv + 64, lane);
 #pragma unroll
-      for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float wg = sigmoid_l2(g.t[mt][e]);
-          x[pt].t[mt][e] += wg * (xg.t[mt][e] - x[pt].t[mt][e]);       // (1-w)*x + w*x_g
-        }
+      for (int mt = 0; mt < 4; ++mt) gate_mix4(x[pt].t[mt], xg.t[mt], g.t[mt]);          // (1-w)*x + w*x_g
       V64 s1;
       linear_t16<4, false>(s1.t, x[pt], S0_l, cv + 128, lane);
       f32x2v s2 = {0.f, 0.f};

@@ -216,12 +216,7 @@ __global__ __launch_bounds__(64 * NW) void k_step_alpha_g(RowSet rs, ScorerW w, 
         V64 gg;
         linear_t16p<4, false, true>(gg.t, xg, Wg_l, cv + 64, lane);
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const float wg = sigmoid_l2(gg.t[mt][e]);
-            smd.t[mt][e] += wg * (xg.t[mt][e] - smd.t[mt][e]);
-          }
+        for (int mt = 0; mt < 4; ++mt) gate_mix4(smd.t[mt], xg.t[mt], gg.t[mt]);          // (1-w)*x + w*x_g
       }
       __builtin_amdgcn_sched_barrier(0);
       const bool writer = l15 < G && sv;                   // one replica of every site's column writes
