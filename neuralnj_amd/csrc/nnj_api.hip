@@ -571,8 +571,9 @@ int run_encoder64(nnj_handle* h, const uint8_t* codes, const float* onehot, cons
   if ((long)T * C > 1024) { int max_rows = 1024 / C; if (max_rows < 1) max_rows = 1; nchunks = (T + max_rows - 1) / max_rows; }
   const double fill = -10000.0 * nchunks;
   const double row_scale = 1.0 / (sqrt((double)NNJ_DH) * sqrt((double)T)), col_scale = 1.0 / sqrt((double)NNJ_DH);
-  const size_t lds_col = (size_t)T * 64 * sizeof(double);
-  if (int rc = set_lds(h, k64_col_attention, lds_col)) return rc;
+  const size_t lds_col = (size_t)T * 32 * sizeof(double);
+  const int nu = (T + 127) / 128;                      // query rows per thread of the column-attention kernel
+  if (int rc = nu == 1 ? set_lds(h, k64_col_attention<1>, lds_col) : set_lds(h, k64_col_attention<2>, lds_col)) return rc;
   for (int b = 0; b < B; ++b) {
     const uint8_t* mb = mask ? mask + (size_t)b * C : nullptr;
     {
@@ -619,7 +620,9 @@ int run_encoder64(nnj_handle* h, const uint8_t* codes, const float* onehot, cons
           const Gemm64 g{y, 64, 0, w + q64.Wcol, 64, 0, (int)ntok, 192, 64};
           const EpiColQkv epi{big, w + q64.bcol, col_scale};
           if (int rc = gemm64<128, 64, false, false>(h, g, epi, 1, st)) return rc;
-          hipLaunchKernelGGL(k64_col_attention, dim3((unsigned)C, 2), dim3(256), lds_col, st, (const double*)big, ctx, mb, T, C);
+          const dim3 cgrid((unsigned)C, 4);
+          if (nu == 1) hipLaunchKernelGGL(k64_col_attention<1>, cgrid, dim3(256), lds_col, st, (const double*)big, ctx, mb, T, C);
+          else hipLaunchKernelGGL(k64_col_attention<2>, cgrid, dim3(256), lds_col, st, (const double*)big, ctx, mb, T, C);
           const Gemm64 g2{ctx, 64, 0, w + lo.col[6], 64, 0, (int)ntok, 64, 64};
           const EpiResid epi2{x, w + lo.col[7]};
           if (int rc = gemm64<128, 64, false, false>(h, g2, epi2, 1, st)) return rc;

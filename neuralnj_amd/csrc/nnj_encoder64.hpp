@@ -103,7 +103,7 @@ struct Tile64 {
 };
 
 template <int BM, int BN, bool TA, bool TB, typename EPI>
-__global__ __launch_bounds__(256) void k64_gemm(Gemm64 g, EPI epi) {
+__global__ __launch_bounds__(256, 2) void k64_gemm(Gemm64 g, EPI epi) {
   extern __shared__ __attribute__((aligned(16))) double smem64[];
   using TileA = Tile64<BM, TA>;
   using TileB = Tile64<BN, TB>;
@@ -307,56 +307,73 @@ __global__ __launch_bounds__(256) void k64_softmax_rows(double* __restrict__ S, 
 }
 
 // column attention of one alignment column (axial_attention.py:190-255): qkv [token r*C + c][192] (q pre-scaled) ->
-// ctx [token][64].  One workgroup per (column, half of the heads); thread (i, head group): query row i, heads hg, hg + tpr, ...
-// of the half; the keys and values of the column's four heads sit in LDS (R <= 256 rows x 64 doubles) and are read as
-// broadcasts.  Two passes over the keys (maximum, then exponentials): one exp per (query, key, head).  Every key of a
-// padded column carries the fill -10000 (:220-224): the softmax is uniform.
+// ctx [token][64].  One workgroup per (column, PAIR of heads); thread (row group rg = tid >> 1, head tid & 1 of the pair)
+// owns the NU query rows rg, rg + 128 of its head: every key / value vector it reads from LDS (the column's k | v of the
+// two heads, [R][32] doubles = 51 KB at 200 rows: three workgroups per CU; broadcast reads) feeds NU rows' products.
+// Two passes over the keys (maximum, then exponentials): one exp per (query, key, head).  Every key of a padded column
+// carries the fill -10000 (:220-224): the softmax is uniform.
+template <int NU>
 __global__ __launch_bounds__(256) void k64_col_attention(const double* __restrict__ qkv, double* __restrict__ ctx,
                                                          const uint8_t* __restrict__ mask, int R, int C) {
-  extern __shared__ __attribute__((aligned(16))) double kv[];          // [R][64]: k[32] | v[32] of heads 4 hy .. 4 hy + 3
+  extern __shared__ __attribute__((aligned(16))) double kv[];          // [R][32]: k[16] | v[16] of heads 2 hy, 2 hy + 1
   const int c = blockIdx.x, hy = blockIdx.y, tid = threadIdx.x;
-  for (int i = tid; i < R * 32; i += 256) {
-    const int r = i >> 5, p = i & 31;                                  // p < 16: k pairs, else v pairs
-    const long src = ((long)r * C + c) * 192 + (p < 16 ? 64 : 128) + 32 * hy + 2 * (p & 15);
-    *reinterpret_cast<f64x2*>(kv + r * 64 + 2 * p) = *reinterpret_cast<const f64x2*>(qkv + src);
+  for (int i = tid; i < R * 16; i += 256) {
+    const int r = i >> 4, p = i & 15;                                  // p < 8: k pairs, else v pairs
+    const long src = ((long)r * C + c) * 192 + (p < 8 ? 64 : 128) + 16 * hy + 2 * (p & 7);
+    *reinterpret_cast<f64x2*>(kv + r * 32 + 2 * p) = *reinterpret_cast<const f64x2*>(qkv + src);
   }
   __syncthreads();
   const bool padded = mask && mask[c];
-  // R <= 64: four threads per query row (one head each); R <= 128: two; else one (four heads each)
-  const int tpr = R <= 64 ? 4 : (R <= 128 ? 2 : 1);
-  const int i = tid / tpr, hg = tid % tpr;
-  if (i >= R) return;
-  const double* qrow = qkv + ((long)i * C + c) * 192 + 32 * hy;
-  double* orow = ctx + ((long)i * C + c) * 64 + 32 * hy;
-  for (int hd = hg; hd < 4; hd += tpr) {
-    double q[8];
+  const int hd = tid & 1, rg = tid >> 1;
+  double q[NU][8], mx[NU], sum[NU], acc[NU][8];
 #pragma unroll
-    for (int d = 0; d < 8; ++d) q[d] = qrow[hd * 8 + d];
-    double mx = -1.0e300;
-    if (padded) mx = -10000.0;
-    else
-      for (int j = 0; j < R; ++j) {
-        const double* kj = kv + j * 64 + hd * 8;
+  for (int u = 0; u < NU; ++u) {
+    const int i = rg + 128 * u;
+    const double* qrow = qkv + ((long)(i < R ? i : 0) * C + c) * 192 + 16 * hy + 8 * hd;
+#pragma unroll
+    for (int d = 0; d < 8; ++d) { q[u][d] = qrow[d]; acc[u][d] = 0.0; }
+    mx[u] = padded ? -10000.0 : -1.0e300;
+    sum[u] = 0.0;
+  }
+  if (!padded)
+    for (int j = 0; j < R; ++j) {
+      const double* kj = kv + j * 32 + hd * 8;
+      double k[8];
+#pragma unroll
+      for (int d = 0; d < 8; ++d) k[d] = kj[d];
+#pragma unroll
+      for (int u = 0; u < NU; ++u) {
         double s = 0.0;
 #pragma unroll
-        for (int d = 0; d < 8; ++d) s += q[d] * kj[d];
-        mx = fmax(mx, s);
+        for (int d = 0; d < 8; ++d) s += q[u][d] * k[d];
+        mx[u] = fmax(mx[u], s);
       }
-    double sum = 0.0, acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int j = 0; j < R; ++j) {
-      const double* kj = kv + j * 64 + hd * 8;
+    }
+  for (int j = 0; j < R; ++j) {
+    const double* kj = kv + j * 32 + hd * 8;
+    double k[8], v[8];
+#pragma unroll
+    for (int d = 0; d < 8; ++d) { k[d] = kj[d]; v[d] = kj[16 + d]; }
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
       double s = 0.0;
 #pragma unroll
-      for (int d = 0; d < 8; ++d) s += q[d] * kj[d];
-      const double p = padded ? 1.0 : exp(s - mx);
-      sum += p;
-      const double* vj = kj + 32;
+      for (int d = 0; d < 8; ++d) s += q[u][d] * k[d];
+      const double p = padded ? 1.0 : exp(s - mx[u]);
+      sum[u] += p;
 #pragma unroll
-      for (int d = 0; d < 8; ++d) acc[d] += p * vj[d];
+      for (int d = 0; d < 8; ++d) acc[u][d] += p * v[d];
     }
-    const double inv = 1.0 / sum;
+  }
 #pragma unroll
-    for (int d = 0; d < 8; ++d) orow[hd * 8 + d] = acc[d] * inv;
+  for (int u = 0; u < NU; ++u) {
+    const int i = rg + 128 * u;
+    if (i < R) {
+      double* orow = ctx + ((long)i * C + c) * 64 + 16 * hy + 8 * hd;
+      const double inv = 1.0 / sum[u];
+#pragma unroll
+      for (int d = 0; d < 8; ++d) orow[d] = acc[u][d] * inv;
+    }
   }
 }
 
