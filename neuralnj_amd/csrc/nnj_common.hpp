@@ -108,7 +108,9 @@ __device__ __forceinline__ f32x2v gelu_erf2(f32x2v x) {
 // Two sigmoids / gate mixes at a time with PACKED fp32 arithmetic (round 5).  The compiler packs the fused multiply-adds
 // of these chains by itself but leaves the `1 + 2^x` additions and the `a - b` differences scalar (k_inc_score_w<3>: 108
 // v_add_f32 + 96 v_sub_f32 per site next to 265 v_pk_fma_f32): as packed FMAs the loop body has 8 % fewer vector
-// instructions (1053 -> 967).  Same operations per element: bit-identical.  What it buys is small -- at two waves per SIMD a
+// instructions (1053 -> 967).  Same values up to the fusion: the mixes are explicit FMAs now where the compiler had emitted a
+// packed multiply and a packed add in places (one rounding fewer; the tables move in the seventh digit: the e64 scan of
+// profiles/r05 is of this code).  What it buys is small -- at two waves per SIMD a
 // scalar fp32 instruction already runs at the pipe's rate, a packed one saves issue slots only: incremental scores 49.2 ->
 // 48.3 ms per rollout; in the 32-pair kernels of step 0 (25 % fewer vector instructions in the gate block) nothing, so
 // those keep the scalar form (profiles/r05/ab_packed_gates.txt).
