@@ -397,19 +397,27 @@ __global__ __launch_bounds__(64 * NW) void k_inc_score_w(RowSet rs, ScorerW w, c
 #ifdef NNJ_STAMP
   unsigned long long st_n = 0, st_load = 0, st_a = 0, st_b[4] = {0, 0, 0, 0};
 #endif
+  // Round 5: the rows of the NEXT site are requested as soon as the gate phase has consumed the current ones -- the
+  // registers are dead from there on -- so their HBM latency runs behind the chain phase (64 % of a site's cycles)
+  // instead of in front of the gate phase (stamps of round 4: 11 % of a site's cycles passed until the loads had landed).
+  V64 sr[NT], sm, um;
+  unsigned mraw = 0;
+  auto request = [&](int c) {
+    mraw = mask[(size_t)b * C + c];                                     // seq_mask (model.py:96)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) load_v64(sr[t], Sr[t] + (size_t)c * 64, kq);
+    load_v64(sm, Sm + (size_t)c * 64, kq);
+    load_v64(um, Um + (size_t)c * 64, kq);
+  };
+  if (c0 + wave < c1) request(c0 + wave);
   for (int c = c0 + wave; c < c1; c += NW) {
     asm volatile("" ::: "memory");
 #ifdef NNJ_STAMP
     const unsigned long long T0 = stamp_now();
 #endif
-    const float mc = mask[(size_t)b * C + c] ? 0.f : 1.f;               // seq_mask (model.py:96); first load of the iteration
+    const float mc = mraw ? 0.f : 1.f;
     V64 x[NT];
     {
-      V64 sr[NT], sm, um;
-#pragma unroll
-      for (int t = 0; t < NT; ++t) load_v64(sr[t], Sr[t] + (size_t)c * 64, kq);
-      load_v64(sm, Sm + (size_t)c * 64, kq);
-      load_v64(um, Um + (size_t)c * 64, kq);
 #ifdef NNJ_STAMP
       const unsigned long long T1 = stamp_now();
       st_load += T1 - T0; ++st_n;
@@ -446,6 +454,9 @@ __global__ __launch_bounds__(64 * NW) void k_inc_score_w(RowSet rs, ScorerW w, c
         __builtin_amdgcn_sched_barrier(0);
       }
     }
+    request(c + NW < c1 ? c + NW : c);                      // (last site: a harmless reload; unconditional: no branch)
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
 #ifdef NNJ_STAMP
     unsigned long long TP = stamp_now();
     st_a += TP - T0;                                        // (includes the loads: [2] - [1] is phase A proper)
@@ -593,16 +604,22 @@ __global__ __launch_bounds__(64 * NW) void k_inc_score_wi(RowSet rs, ScorerW w, 
   auto wsw = [](int d, int chunk) { if constexpr (NT == 3) return chunk; else return tswz<NT>(d, chunk); };
   unsigned short* t16 = reinterpret_cast<unsigned short*>(img);
   const u32x4* im4 = reinterpret_cast<const u32x4*>(img);
+  // the rows of the next site are requested behind the gate phase of the current one (see k_inc_score_w)
+  V64 srall[NT], sm, um;
+  unsigned mraw = 0;
+  auto request = [&](int c) {
+    mraw = mask[(size_t)b * C + c];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) load_v64(srall[t], Sr[t] + (size_t)c * 64, kq);
+    load_v64(sm, Sm + (size_t)c * 64, kq);
+    load_v64(um, Um + (size_t)c * 64, kq);
+  };
+  if (c0 + wave < c1) request(c0 + wave);
   for (int c = c0 + wave; c < c1; c += NW) {
     asm volatile("" ::: "memory");
-    const float mc = mask[(size_t)b * C + c] ? 0.f : 1.f;
+    const float mc = mraw ? 0.f : 1.f;
     V64 x[NT];
     {
-      V64 srall[NT], sm, um;
-#pragma unroll
-      for (int t = 0; t < NT; ++t) load_v64(srall[t], Sr[t] + (size_t)c * 64, kq);
-      load_v64(sm, Sm + (size_t)c * 64, kq);
-      load_v64(um, Um + (size_t)c * 64, kq);
       static_for<0, NGRP>([&](auto gi) {
         constexpr int T0 = decltype(gi)::value * NI, N = (NT - T0 < NI ? NT - T0 : NI);
         V64 ur[N];
@@ -634,6 +651,9 @@ __global__ __launch_bounds__(64 * NW) void k_inc_score_wi(RowSet rs, ScorerW w, 
         __builtin_amdgcn_sched_barrier(0);
       });
     }
+    request(c + NW < c1 ? c + NW : c);                      // (last site: a harmless reload; unconditional: no branch)
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
     static_for<0, NGRP>([&](auto gi) {
       constexpr int T0 = decltype(gi)::value * NI, N = (NT - T0 < NI ? NT - T0 : NI);
       // x_g^T = S^T alpha^T of the group's tiles: one image fragment per (k-step, d tile), N alpha fragments per k-step
