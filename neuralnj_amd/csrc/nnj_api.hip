@@ -54,7 +54,7 @@ struct nnj_handle {
   double* d_w64 = nullptr;
   struct Qkv64 { size_t Wrow, brow, Wcol, bcol; };
   std::vector<Qkv64> lo64;
-  int enc64 = 1;                 // NNJ_ENC64=0: the f16x3 encoder above 64 rows too (A/B of the parity tables only)
+  int enc64 = 1;                 // NNJ_ENC64=0: the f16x3 encoder above 64 rows too; =2: the fp64 encoder at EVERY row count (both: A/B of the parity tables only)
   size_t n_packed = 0;
   std::vector<LayerOff> lo;
   size_t oE0, oe0, oE2, oe2, oWh, obh, oWg, obg, oWgq, obgq, oWgk, obgk, oS0, os0, os2w, os2b;
@@ -410,7 +410,9 @@ Enc64Ws enc64_ws(int T, int C) {
 }
 size_t ws_floats_one(int B, int T, int C) {
   const size_t state = align_up((size_t)B * T * C * 64, 64);
-  const size_t enc = std::max(enc_ws(B, T, C).end, T > 64 ? 2 * enc64_ws(T, C).end : (size_t)0);
+  // (NNJ_ENC64=2, a diagnostic: the fp64 encoder below 65 rows too -- its scratch must then exist at every shape)
+  static const bool enc64_always = getenv("NNJ_ENC64") && atoi(getenv("NNJ_ENC64")) == 2;
+  const size_t enc = std::max(enc_ws(B, T, C).end, (T > 64 || enc64_always) ? 2 * enc64_ws(T, C).end : (size_t)0);
   const size_t loop = loop_ws(B, T, C).end;
   return state + std::max(enc, loop) + 256;
 }
@@ -653,7 +655,7 @@ int run_encoder64(nnj_handle* h, const uint8_t* codes, const float* onehot, cons
 
 int run_encoder(nnj_handle* h, const uint8_t* codes, const uint8_t* mask, float* x, float* scratch, int B, int T,
                 int C, hipStream_t st, const float* onehot = nullptr) {
-  if (T > 64 && h->enc64) return run_encoder64(h, codes, onehot, mask, x, scratch, B, T, C, st);
+  if ((T > 64 && h->enc64) || h->enc64 == 2) return run_encoder64(h, codes, onehot, mask, x, scratch, B, T, C, st);
   switch (enc_dims(B, T, C).NT) {
     case 1: return launch_encoder<1>(h, codes, onehot, mask, x, scratch, B, T, C, st);
     case 2: return launch_encoder<2>(h, codes, onehot, mask, x, scratch, B, T, C, st);
