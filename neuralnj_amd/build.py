@@ -15,10 +15,14 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libnnj_hip.so")
 STAMP = LIB + ".srchash"
-SOURCES = ["nnj_api.hip"]
+SOURCES = ["nnj_api.hip", "nnj_step0_tu.hip"]
 # No -ffast-math (nor -fassociative-math): the f16x3 operand split relies on exact IEEE subtractions
 # (x - fp16(x)); with reassociation the pieces no longer add up and the parity tests fail at 4e-4.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value"]
+# Per-translation-unit flags: the backend's scheduling strategy is a per-kernel choice that the toolchain offers per
+# translation unit only (profiles/r05/ab_sched_strategies.txt: max-ilp orders the MFMA blocks of the two step-0 kernels better, 14.85 -> 13.8
+# and 33.1 -> 32.7 ms per rollout, and makes k_tok1p spill).  Same instructions, bit-identical results.
+EXTRA_FLAGS = {"nnj_step0_tu.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp", "-Wno-unused-function"]}
 
 
 def source_files():
@@ -29,7 +33,7 @@ def source_files():
 
 
 def source_hash() -> str:
-    h = hashlib.sha256(" ".join(FLAGS + SOURCES).encode())
+    h = hashlib.sha256(" ".join(FLAGS + SOURCES + [f"{k}:{' '.join(v)}" for k, v in sorted(EXTRA_FLAGS.items())]).encode())
     for f in source_files():
         h.update(os.path.basename(f).encode())
         with open(f, "rb") as fh:
@@ -48,10 +52,24 @@ def build_hip(force: bool = False, verbose: bool = False) -> str:
     if not force and not _stale():
         return LIB
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    cmd = [hipcc] + FLAGS + ["-o", LIB] + SOURCES
+    compile_flags = [f for f in FLAGS if f != "-shared"]
+    objs, procs = [], []
+    for src in SOURCES:                      # one object per translation unit (its own flags), compiled side by side
+        obj = os.path.join(CSRC, os.path.splitext(src)[0] + ".o")
+        cmd = [hipcc] + compile_flags + EXTRA_FLAGS.get(src, []) + ["-c", "-o", obj, src]
+        if verbose:
+            print(" ".join(cmd))
+        procs.append((cmd, subprocess.Popen(cmd, cwd=CSRC)))
+        objs.append(obj)
+    for cmd, p in procs:
+        if p.wait() != 0:
+            raise subprocess.CalledProcessError(p.returncode, cmd)
+    link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
     if verbose:
-        print(" ".join(cmd))
-    subprocess.run(cmd, cwd=CSRC, check=True)
+        print(" ".join(link))
+    subprocess.run(link, cwd=CSRC, check=True)
+    for obj in objs:
+        os.remove(obj)
     with open(STAMP, "w") as f:
         f.write(source_hash() + "\n")
     return LIB

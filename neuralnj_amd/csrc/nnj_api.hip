@@ -19,6 +19,14 @@
 #include "nnj_scorer.hpp"
 #include "nnj_scorer16.hpp"
 #include "nnj_scorer_wide.hpp"
+
+// nnj_step0_tu.hip: the two all-pairs kernels of step 0, compiled with a scheduling strategy of their own
+hipError_t nnj_launch_pair_alpha_1_8(unsigned grid, size_t lds, hipStream_t st, const void* rowset, const void* scorerw,
+                                     const int* ij_prev, float* alpha_part, int mode, int n, int C, int npairs, int ppad,
+                                     int cs, int nsc, int npg, int B);
+hipError_t nnj_launch_pair_score_1_8(unsigned grid, size_t lds, hipStream_t st, const void* rowset, const void* scorerw,
+                                     const int* ij_prev, const float* alpha, const uint8_t* mask, float* score_part, int mode,
+                                     int n, int C, int npairs, int ppad, int cs, int has_ctx, int nsc, int npg, int B);
 #include "nnj_step_g.hpp"
 #include "nnj_likelihood.hpp"
 
@@ -823,9 +831,9 @@ int launch_pair_scores(nnj_handle* h, const RowSet& rs, const int* ij_prev, cons
     {
       Scope sc(h, st, PK_PAIR_ALPHA);
       const size_t lds = (2 * (IMG64 + 8192) + SCORER_CONSTS) * sizeof(float);
-      if (int rc = set_lds(h, k_pair_alpha<1, 8>, lds)) return rc;
-      hipLaunchKernelGGL((k_pair_alpha<1, 8>), grid, dim3(512), lds, st, rs, sw, ij_prev, base + w.alpha_part, mode, n, C,
-                         g.npairs, g.ppad, g.cs, g.nsc, g.pg, B);
+      // (k_pair_alpha<1, 8> and k_pair_score<1, 8> live in nnj_step0_tu.hip)
+      HIPCHK(h, nnj_launch_pair_alpha_1_8(grid.x, lds, st, &rs, &sw, ij_prev, base + w.alpha_part, mode, n, C, g.npairs, g.ppad,
+                                          g.cs, g.nsc, g.pg, B));
     }
     launch_beta_sum(h, rs, base, w, B, C, st);
     {
@@ -838,9 +846,8 @@ int launch_pair_scores(nnj_handle* h, const RowSet& rs, const int* ij_prev, cons
   {
     Scope sc(h, st, PK_PAIR_SCORE);
     const size_t lds = (size_t)(2 * IMG64 + 2 * (IMG64 + 8192) + SCORER_CONSTS) * sizeof(float);
-    if (int rc = set_lds(h, k_pair_score<1, 8>, lds)) return rc;
-    hipLaunchKernelGGL((k_pair_score<1, 8>), grid, dim3(512), lds, st, rs, sw, ij_prev, base + w.alpha, mask,
-                       base + w.score_part, mode, n, C, g.npairs, g.ppad, g.cs, has_ctx, g.nsc, g.pg, B);
+    HIPCHK(h, nnj_launch_pair_score_1_8(grid.x, lds, st, &rs, &sw, ij_prev, base + w.alpha, mask, base + w.score_part, mode, n, C,
+                                        g.npairs, g.ppad, g.cs, has_ctx, g.nsc, g.pg, B));
   }
   return NNJ_OK;
 }

@@ -36,12 +36,14 @@ __device__ __forceinline__ void stage_image_t16(float* lds, const float* __restr
   for (int i = tid; i < IMG64 / 4; i += nthreads) l4[i] = g4[i];
 }
 // the images themselves (one workgroup; `out` = 4 x IMG64 floats: A^T | W_h | W_g | S0)
+#ifndef NNJ_STEP0_TU           // (nnj_step0_tu.hip includes this file for k_pair_alpha and k_pair_score alone)
 __global__ void k_build_scorer_images(ScorerW w, float* __restrict__ out) {
   stage_weight_t16(out, w.A, 64, threadIdx.x, blockDim.x, true);
   stage_weight_t16(out + IMG64, w.Wh, 64, threadIdx.x, blockDim.x);
   stage_weight_t16(out + 2 * IMG64, w.Wg, 64, threadIdx.x, blockDim.x);
   stage_weight_t16(out + 3 * IMG64, w.S0, 64, threadIdx.x, blockDim.x);
 }
+#endif
 
 struct RowSet {                // where the rows of one call live
   const float* S;              // [B][slots][C][64]
@@ -270,6 +272,7 @@ __global__ __launch_bounds__(64 * NW) void k_pair_alpha(RowSet rs, ScorerW w, co
   }
 }
 
+#ifndef NNJ_STEP0_TU           // nnj_api.hip only
 // ------------------------------------------------------------------ k_alpha_softmax
 // alpha[b][pair][r] = softmax_r( (sum_sc part + beta_r) / sqrt(64*C) ), rows i, j of the
 // pair and r >= n excluded (model.py:118-146).  One wave per pair, lane = r.
@@ -303,6 +306,7 @@ __global__ __launch_bounds__(256) void k_alpha_softmax(RowSet rs, ScorerW w, con
   alpha_store(alpha, (long)gridDim.y * ppad * 64, ((size_t)b * ppad + p) * 64 + lane, (s > 0.f) ? e / s : 0.f);
 }
 
+#endif  // NNJ_STEP0_TU
 // ------------------------------------------------------------------ k_pair_score
 // Phase B: per (pair, site): x_g = sum_r alpha_r S_r ; g = W_g x_g + b_g ; w = sigmoid(g);
 // x = (1-w) x + w x_g ; s = s_out(x) ; score_part[b][sc][pair] = sum_{c in chunk} mask_c s
@@ -406,6 +410,7 @@ __global__ __launch_bounds__(64 * NW) void k_pair_score(RowSet rs, ScorerW w, co
   }
 }
 
+#ifndef NNJ_STEP0_TU           // nnj_api.hip only
 // ------------------------------------------------------------------ incremental NJ step
 // The n-1 new pairs (m, r) of a step, m = position of the freshly merged row.  Lane = partner
 // row r (NT tiles of 32), so every lane streams ITS OWN rows S_r, U_r straight from HBM
@@ -1398,3 +1403,4 @@ __global__ void k_replicate_u8(const uint8_t* __restrict__ src, uint8_t* __restr
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < (long)B * L) dst[i] = src[i % L];
 }
+#endif  // NNJ_STEP0_TU
