@@ -55,7 +55,7 @@ def build_hip(force: bool = False, verbose: bool = False) -> str:
     compile_flags = [f for f in FLAGS if f != "-shared"]
     objs, procs = [], []
     for src in SOURCES:                      # one object per translation unit (its own flags), compiled side by side
-        obj = os.path.join(CSRC, os.path.splitext(src)[0] + ".o")
+        obj = os.path.join(CSRC, f"{os.path.splitext(src)[0]}.{os.getpid()}.o")     # (two builders at once must not share objects)
         cmd = [hipcc] + compile_flags + EXTRA_FLAGS.get(src, []) + ["-c", "-o", obj, src]
         if verbose:
             print(" ".join(cmd))
@@ -64,10 +64,12 @@ def build_hip(force: bool = False, verbose: bool = False) -> str:
     for cmd, p in procs:
         if p.wait() != 0:
             raise subprocess.CalledProcessError(p.returncode, cmd)
-    link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    tmp_lib = f"{LIB}.{os.getpid()}.tmp"
+    link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp_lib] + objs
     if verbose:
         print(" ".join(link))
     subprocess.run(link, cwd=CSRC, check=True)
+    os.replace(tmp_lib, LIB)                 # atomic: a reader never maps a half-written library
     for obj in objs:
         os.remove(obj)
     with open(STAMP, "w") as f:
